@@ -1,0 +1,85 @@
+"""ctypes binding of libdesenet_hip.so (include/desenet_hip.h).  No CPU fallback: a missing library is a hard error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdesenet_hip.so")
+
+DSN_F32, DSN_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
+
+
+class dsn_tensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("c", C.c_int32), ("ldc", C.c_int64)]
+
+
+class dsn_conv_params(C.Structure):
+    _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+                ("act", C.c_int32), ("accumulate", C.c_int32)]
+
+
+TP = C.POINTER(dsn_tensor)
+CP = C.POINTER(dsn_conv_params)
+vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); every symbol declared in include/desenet_hip.h
+PROTOTYPES = {
+    "dsn_version": (i32, []),
+    "dsn_last_error": (C.c_char_p, []),
+    "dsn_conv2d_fwd": (i32, [TP, vp, vp, TP, TP, CP, vp]),
+    "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
+    "dsn_conv2d_wgrad_workspace_bytes": (i64, [TP, TP, CP, i32]),
+    "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, CP, vp, i64, vp]),
+    "dsn_pack_weight_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dsn_unpack_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dsn_bn_workspace_bytes": (i64, [i32]),
+    "dsn_bn_stats": (i32, [TP, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i64, vp]),
+    "dsn_bn_act_fwd": (i32, [TP, vp, vp, i32, TP, TP, vp]),
+    "dsn_bn_act_bwd": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, vp]),
+    "dsn_act_bwd": (i32, [TP, TP, i32, TP, vp]),
+    "dsn_focus_s2d": (i32, [vp, i32, i32, i32, i32, TP, vp]),
+    "dsn_maxpool_s1": (i32, [TP, TP, vp, i32, vp]),
+    "dsn_maxpool_s1_bwd": (i32, [TP, vp, TP, i32, i32, vp]),
+    "dsn_upsample_nearest2x": (i32, [TP, TP, vp]),
+    "dsn_upsample_nearest2x_bwd": (i32, [TP, TP, i32, vp]),
+    "dsn_bilinear_ac": (i32, [TP, TP, i32, vp]),
+    "dsn_bilinear_ac_bwd": (i32, [TP, i32, TP, i32, vp]),
+    "dsn_adaptive_avgpool": (i32, [TP, TP, vp]),
+    "dsn_adaptive_avgpool_bwd": (i32, [TP, TP, i32, vp]),
+    "dsn_copy": (i32, [TP, TP, i32, vp]),
+    "dsn_ffm_scale": (i32, [TP, TP, TP, vp]),
+    "dsn_ffm_scale_bwd": (i32, [TP, TP, TP, TP, TP, i32, vp]),
+    "dsn_detect_decode": (i32, [TP, vp, vp, i64, i64, i32, i32, f32, vp, vp]),
+    "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, vp]),
+    "dsn_nms_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "dsn_nms": (i32, [vp, i32, i32, i32, f32, f32, i32, i32, u64, i32, vp, vp, vp, i64, vp]),
+    "dsn_cast": (i32, [vp, vp, i32, i64, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP kernels are the only compute path of desenet_amd (there is no CPU "
+                "fallback). Build it with `python -m desenet_amd.build` (hipcc --offload-arch=gfx950).")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)   # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().dsn_last_error().decode(errors="replace")
+        raise RuntimeError(f"libdesenet_hip {what} failed (status {rc}): {msg}")

@@ -1,0 +1,85 @@
+// Shared device/host helpers for libdesenet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/desenet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing (thread-local message, never abort) -------------------------------------------------------
+void dsn_set_error(const char* fmt, ...);
+#define DSN_FAIL(code, ...)      \
+    do {                         \
+        dsn_set_error(__VA_ARGS__); \
+        return (code);           \
+    } while (0)
+#define DSN_CHECK_ARG(cond, ...) \
+    do {                         \
+        if (!(cond)) DSN_FAIL(DSN_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define DSN_LAUNCH_CHECK(what)                                                             \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) DSN_FAIL((int)e_, "%s: %s", what, hipGetErrorString(e_));    \
+    } while (0)
+
+// ---- tensor view as passed to kernels -------------------------------------------------------------------------
+struct TV {
+    void*   p;
+    int32_t n, h, w, c;
+    int64_t ldc;
+};
+static inline TV tv(const dsn_tensor* t) { return TV{t->ptr, t->n, t->h, t->w, t->c, t->ldc}; }
+static inline int64_t npix(const dsn_tensor* t) { return (int64_t)t->n * t->h * t->w; }
+static inline bool tensor_ok(const dsn_tensor* t) {
+    return t && t->ptr && (t->dtype == DSN_F32 || t->dtype == DSN_BF16) && t->n > 0 && t->h > 0 && t->w > 0 &&
+           t->c > 0 && t->ldc >= t->c;
+}
+
+// ---- element load/store in fp32 domain ------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == DSN_ACT_SILU) return v * sigmoidf_(v);
+    if (act == DSN_ACT_SIGMOID) return sigmoidf_(v);
+    return v;
+}
+// d act(u) / du
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (act == DSN_ACT_SILU) {
+        float s = sigmoidf_(u);
+        return s * (1.0f + u * (1.0f - s));
+    }
+    if (act == DSN_ACT_SIGMOID) {
+        float s = sigmoidf_(u);
+        return s * (1.0f - s);
+    }
+    return 1.0f;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+#define DSN_DISPATCH_DTYPE(dt, T, ...)                 \
+    do {                                               \
+        if ((dt) == DSN_F32) {                         \
+            typedef float T;                           \
+            __VA_ARGS__;                               \
+        } else {                                       \
+            typedef bf16_t T;                          \
+            __VA_ARGS__;                               \
+        }                                              \
+    } while (0)

@@ -1,0 +1,329 @@
+// Detect head decode (yolo.py:255-277) and non-max suppression (general.py:659-750 + torchvision.ops.nms).
+//
+// This translation unit is compiled with -ffp-contract=off: the NMS selection must be BIT-EXACT against the fp32 CPU
+// oracle, so `a1 + a2 - w*h`, `x - w/2`, `obj*cls` must round exactly like separate IEEE fp32 operations.
+//
+// NMS pipeline per image (one launch each, all images in parallel):
+//   1. nms_candidates : every prediction row (x class) that passes the confidence tests appends ONE 64-bit key
+//                       (~bits(conf) << 32 | row*nc + cls) through a per-image atomic counter.  Keys are unique, and sorting
+//                       them ascending == stable descending-confidence order of the reference's row-major candidate list,
+//                       so the arrival order of the atomics is irrelevant (deterministic result).
+//   2. nms_sort       : one 1024-thread workgroup per image: bitonic sort, LDS-resident for <= 8192 keys (the detect
+//                       setting), LDS-tiled + global passes above that (val setting: up to 151,200 keys).
+//   3. nms_greedy     : one 256-thread workgroup per image walks the sorted keys (capped at 30000) in chunks of 64: every
+//                       candidate is tested against the boxes kept so far (4 waves split the kept list), then wave 0
+//                       resolves the chunk internally with ballots; stops as soon as max_det boxes are kept.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_WH = 4096;
+constexpr int MAX_NMS = 30000;
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_LDS_KEYS = 8192;   // 64 KiB of LDS
+constexpr int MAX_DET_CAP = 4096;
+
+#define GRID_STRIDE(i, total) \
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- Detect ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void detect_decode_kernel(const T* __restrict__ t, int64_t tld, float* __restrict__ raw,
+                                     float* __restrict__ pred, int64_t pred_rows, int64_t row_off, int N, int ny, int nx,
+                                     int na, int no, float stride, const float* __restrict__ anchors) {
+    const int C = na * no;
+    const int64_t total = (int64_t)N * ny * nx * C;
+    GRID_STRIDE(i, total) {
+        const int ch = (int)(i % C);
+        int64_t p = i / C;
+        const int x = (int)(p % nx);
+        int64_t q = p / nx;
+        const int y = (int)(q % ny);
+        const int n = (int)(q / ny);
+        const int a = ch / no, o = ch - a * no;
+        const float v = to_f32<T>(t[p * tld + ch]);
+        const int64_t cell = ((int64_t)a * ny + y) * nx + x;
+        raw[(((int64_t)n * na * ny * nx) + cell) * no + o] = v;
+        if (pred) {
+            const float s = 1.0f / (1.0f + expf(-v));
+            float r;
+            if (o == 0) r = (s * 2.0f - 0.5f + (float)x) * stride;
+            else if (o == 1) r = (s * 2.0f - 0.5f + (float)y) * stride;
+            else if (o == 2) { const float u = s * 2.0f; r = u * u * anchors[2 * a]; }
+            else if (o == 3) { const float u = s * 2.0f; r = u * u * anchors[2 * a + 1]; }
+            else r = s;
+            pred[((int64_t)n * pred_rows + row_off + cell) * no + o] = r;
+        }
+    }
+}
+
+template <typename T>
+__global__ void detect_raw_bwd_kernel(const float* __restrict__ draw, T* __restrict__ dt, int64_t tld, int N, int ny,
+                                      int nx, int na, int no) {
+    const int C = na * no;
+    const int64_t total = (int64_t)N * ny * nx * C;
+    GRID_STRIDE(i, total) {
+        const int ch = (int)(i % C);
+        int64_t p = i / C;
+        const int x = (int)(p % nx);
+        int64_t q = p / nx;
+        const int y = (int)(q % ny);
+        const int n = (int)(q / ny);
+        const int a = ch / no, o = ch - a * no;
+        dt[p * tld + ch] = from_f32<T>(draw[((((int64_t)n * na + a) * ny + y) * nx + x) * no + o]);
+    }
+}
+
+// ---- NMS stage 1: candidates ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t make_key(float conf, uint32_t idx) {
+    return ((uint64_t)(~__float_as_uint(conf)) << 32) | idx;
+}
+
+__global__ void nms_candidates_kernel(const float* __restrict__ pred, int bs, int n, int nc, float conf_thres,
+                                      int multi_label, uint64_t classes_mask, uint64_t* __restrict__ keys,
+                                      int64_t cap, int32_t* __restrict__ counts) {
+    const int no = 5 + nc;
+    const int64_t total = (int64_t)bs * n;
+    GRID_STRIDE(i, total) {
+        const int b = (int)(i / n), row = (int)(i - (int64_t)b * n);
+        const float* r = pred + i * no;
+        const float obj = r[4];
+        if (!(obj > conf_thres)) continue;
+        uint64_t* kb = keys + (int64_t)b * cap;
+        if (multi_label) {
+            for (int j = 0; j < nc; ++j) {
+                const float conf = r[5 + j] * obj;
+                if (conf > conf_thres && (classes_mask == 0 || ((classes_mask >> j) & 1))) {
+                    const int slot = atomicAdd(&counts[b], 1);
+                    kb[slot] = make_key(conf, (uint32_t)(row * nc + j));
+                }
+            }
+        } else {
+            float best = r[5] * obj;
+            int bj = 0;
+            for (int j = 1; j < nc; ++j) {
+                const float conf = r[5 + j] * obj;
+                if (conf > best) { best = conf; bj = j; }
+            }
+            if (best > conf_thres && (classes_mask == 0 || ((classes_mask >> bj) & 1))) {
+                const int slot = atomicAdd(&counts[b], 1);
+                kb[slot] = make_key(best, (uint32_t)(row * nc + bj));
+            }
+        }
+    }
+}
+
+// ---- NMS stage 2: bitonic sort, one workgroup per image ---------------------------------------------------------------
+__device__ __forceinline__ void cmpswap(uint64_t& a, uint64_t& b, bool up) {
+    if ((a > b) == up) { const uint64_t t = a; a = b; b = t; }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(uint64_t* __restrict__ keys, int64_t cap,
+                                                                const int32_t* __restrict__ counts) {
+    __shared__ uint64_t s[SORT_LDS_KEYS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint64_t* k = keys + (int64_t)b * cap;
+    const int cnt = counts[b];
+    if (cnt <= 1) return;
+    int np = 1;
+    while (np < cnt) np <<= 1;
+    for (int i = cnt + tid; i < np; i += SORT_THREADS) k[i] = ~0ull;   // padding sorts to the end (cap >= np by contract)
+    __syncthreads();
+    if (np <= SORT_LDS_KEYS) {
+        for (int i = tid; i < np; i += SORT_THREADS) s[i] = k[i];
+        __syncthreads();
+        for (int size = 2; size <= np; size <<= 1)
+            for (int j = size >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (np >> 1); t += SORT_THREADS) {
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    cmpswap(s[lo], s[lo | j], (lo & size) == 0);
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < np; i += SORT_THREADS) k[i] = s[i];
+        return;
+    }
+    // large case: strides >= SORT_LDS_KEYS run on global memory, the rest of each merge runs tile-by-tile in LDS
+    for (int size = 2; size <= np; size <<= 1) {
+        int j = size >> 1;
+        for (; j >= SORT_LDS_KEYS; j >>= 1) {
+            for (int t = tid; t < (np >> 1); t += SORT_THREADS) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                uint64_t a = k[lo], c = k[lo | j];
+                if ((a > c) == ((lo & size) == 0)) { k[lo] = c; k[lo | j] = a; }
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < np; base += SORT_LDS_KEYS) {
+            for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) s[i] = k[base + i];
+            __syncthreads();
+            for (int jj = j; jj > 0; jj >>= 1) {
+                for (int t = tid; t < (SORT_LDS_KEYS >> 1); t += SORT_THREADS) {
+                    const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                    cmpswap(s[lo], s[lo | jj], ((base + lo) & size) == 0);
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) k[base + i] = s[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ---- NMS stage 3: greedy suppression ----------------------------------------------------------------------------------
+struct Box { float x1, y1, x2, y2, area; };
+
+__device__ __forceinline__ bool iou_gt(const Box& a, const Box& b, float thr) {
+    const float xx1 = fmaxf(a.x1, b.x1), yy1 = fmaxf(a.y1, b.y1);
+    const float xx2 = fminf(a.x2, b.x2), yy2 = fminf(a.y2, b.y2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (a.area + b.area - inter);
+    return ovr > thr;
+}
+
+__global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict__ pred, int n, int nc,
+                                                         const uint64_t* __restrict__ keys, int64_t cap,
+                                                         const int32_t* __restrict__ counts, float iou_thres,
+                                                         int agnostic, int max_det, float* __restrict__ out,
+                                                         int32_t* __restrict__ out_count) {
+    extern __shared__ float kept[];   // [max_det][5]
+    __shared__ unsigned long long dead_s[4];
+    __shared__ int nkept_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+    const int no = 5 + nc;
+    const uint64_t* k = keys + (int64_t)b * cap;
+    int cnt = counts[b];
+    if (cnt > MAX_NMS) cnt = MAX_NMS;
+    if (tid == 0) nkept_s = 0;
+    __syncthreads();
+    float* ob = out + (int64_t)b * max_det * 6;
+    for (int base = 0; base < cnt; base += 64) {
+        const int nkept = nkept_s;
+        if (nkept >= max_det) break;
+        const int ci = base + lane;
+        const bool valid = ci < cnt;
+        Box me{0.f, 0.f, 0.f, 0.f, 0.f};
+        float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu);
+            const int row = idx / nc, cls = idx - row * nc;
+            const float* r = pred + ((int64_t)b * n + row) * no;
+            const float hw = r[2] / 2.0f, hh = r[3] / 2.0f;
+            raw[0] = r[0] - hw; raw[1] = r[1] - hh; raw[2] = r[0] + hw; raw[3] = r[1] + hh;
+            raw[4] = r[5 + cls] * r[4];
+            raw[5] = (float)cls;
+            const float off = raw[5] * (agnostic ? 0.f : (float)MAX_WH);
+            me.x1 = raw[0] + off; me.y1 = raw[1] + off; me.x2 = raw[2] + off; me.y2 = raw[3] + off;
+            me.area = (me.x2 - me.x1) * (me.y2 - me.y1);
+        }
+        // (a) against boxes kept so far: the 4 waves split the kept list
+        bool dead = !valid;
+        for (int q = part; q < nkept && !dead; q += 4) {
+            const Box kb{kept[q * 5], kept[q * 5 + 1], kept[q * 5 + 2], kept[q * 5 + 3], kept[q * 5 + 4]};
+            dead = iou_gt(kb, me, iou_thres);
+        }
+        const unsigned long long dm = __ballot(dead);
+        if (lane == 0) dead_s[part] = dm;
+        __syncthreads();
+        if (part == 0) {
+            unsigned long long alive = ~(dead_s[0] | dead_s[1] | dead_s[2] | dead_s[3]);
+            // (b) inside the chunk: bit j of `sup` = candidate j (earlier, higher score) overlaps me
+            unsigned long long sup = 0ull;
+            for (int j = 0; j < 64; ++j) {
+                Box o;
+                o.x1 = __shfl(me.x1, j); o.y1 = __shfl(me.y1, j); o.x2 = __shfl(me.x2, j); o.y2 = __shfl(me.y2, j);
+                o.area = __shfl(me.area, j);
+                if (j < lane && iou_gt(o, me, iou_thres)) sup |= (1ull << j);
+            }
+            int nk = nkept;
+            for (int j = 0; j < 64 && nk < max_det; ++j) {
+                if (!((alive >> j) & 1ull)) continue;     // wave-uniform
+                if (lane == j) {
+                    kept[nk * 5] = me.x1; kept[nk * 5 + 1] = me.y1; kept[nk * 5 + 2] = me.x2; kept[nk * 5 + 3] = me.y2;
+                    kept[nk * 5 + 4] = me.area;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) ob[nk * 6 + e] = raw[e];
+                }
+                ++nk;
+                alive &= ~__ballot((sup >> j) & 1ull);
+            }
+            if (lane == 0) nkept_s = nk;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out_count[b] = nkept_s;
+}
+
+inline int ew_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+inline int64_t next_pow2(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline int64_t key_cap(int32_t n, int32_t nc, int32_t multi_label) {
+    return next_pow2((int64_t)n * (multi_label ? nc : 1));
+}
+
+}  // namespace
+
+extern "C" int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, int64_t pred_rows, int64_t row_off,
+                                 int32_t na, int32_t no, float stride, const float* anchors_px, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(t) && raw && na > 0 && no > 5 && t->c == na * no, "detect_decode: invalid arguments");
+    DSN_CHECK_ARG(!pred || (anchors_px && row_off >= 0 && row_off + (int64_t)na * t->h * t->w <= pred_rows),
+                  "detect_decode: pred slice out of range");
+    const int64_t total = npix(t) * t->c;
+    DSN_DISPATCH_DTYPE(t->dtype, T,
+                       hipLaunchKernelGGL(detect_decode_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)t->ptr, t->ldc, raw, pred, pred_rows, row_off,
+                                          t->n, t->h, t->w, na, no, stride, anchors_px));
+    DSN_LAUNCH_CHECK("detect_decode");
+    return DSN_OK;
+}
+
+extern "C" int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dt) && draw && na > 0 && no > 0 && dt->c == na * no, "detect_raw_bwd: invalid arguments");
+    const int64_t total = npix(dt) * dt->c;
+    DSN_DISPATCH_DTYPE(dt->dtype, T,
+                       hipLaunchKernelGGL(detect_raw_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                          (hipStream_t)stream, draw, (T*)dt->ptr, dt->ldc, dt->n, dt->h, dt->w, na, no));
+    DSN_LAUNCH_CHECK("detect_raw_bwd");
+    return DSN_OK;
+}
+
+extern "C" int64_t dsn_nms_workspace_bytes(int32_t bs, int32_t n, int32_t nc, int32_t multi_label) {
+    if (bs <= 0 || n <= 0 || nc <= 0) return 0;
+    return (int64_t)bs * key_cap(n, nc, multi_label && nc > 1) * 8 + (int64_t)((bs * 4 + 255) / 256) * 256;
+}
+
+extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, float conf_thres, float iou_thres,
+                       int32_t multi_label, int32_t agnostic, uint64_t classes_mask, int32_t max_det, float* out,
+                       int32_t* out_count, void* workspace, int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(pred && out && out_count && workspace && bs > 0 && n > 0 && nc > 0 && nc <= 64,
+                  "nms: invalid arguments");
+    DSN_CHECK_ARG(conf_thres >= 0.f && conf_thres <= 1.f, "nms: invalid confidence threshold %f", conf_thres);
+    DSN_CHECK_ARG(iou_thres >= 0.f && iou_thres <= 1.f, "nms: invalid IoU threshold %f", iou_thres);
+    DSN_CHECK_ARG(max_det > 0 && max_det <= MAX_DET_CAP, "nms: max_det must be in 1..%d", MAX_DET_CAP);
+    DSN_CHECK_ARG((int64_t)n * nc < (1ll << 31), "nms: too many candidates");
+    multi_label = multi_label && nc > 1;   // general.py:679
+    if (workspace_bytes < dsn_nms_workspace_bytes(bs, n, nc, multi_label))
+        DSN_FAIL(DSN_EWORKSPACE, "nms: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t cap = key_cap(n, nc, multi_label);
+    int32_t* counts = (int32_t*)workspace;
+    uint64_t* keys = (uint64_t*)((char*)workspace + (int64_t)((bs * 4 + 255) / 256) * 256);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)bs * 4, st);
+    if (e != hipSuccess) DSN_FAIL((int)e, "nms: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3(ew_grid((int64_t)bs * n)), dim3(256), 0, st, pred, bs, n, nc,
+                       conf_thres, multi_label, classes_mask, keys, cap, counts);
+    DSN_LAUNCH_CHECK("nms candidates");
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
+    DSN_LAUNCH_CHECK("nms sort");
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(256), (size_t)max_det * 5 * sizeof(float), st, pred, n, nc,
+                       keys, cap, counts, iou_thres, agnostic, max_det, out, out_count);
+    DSN_LAUNCH_CHECK("nms greedy");
+    return DSN_OK;
+}

@@ -1,0 +1,308 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (CDNA4): forward and data-gradient share one gather-GEMM kernel.
+//
+//   C[m][n] = sum_{tap, c}  A[m][tap, c] * B[n][tap, c]
+//     m   : destination pixel (n, y, x) of an NHWC tensor (dense in N,H,W; channel stride ldc)
+//     n   : destination channel
+//     A   : gathered source pixel vectors, src = (dst*a + b + k*d) / q per axis, zero outside the map
+//           forward : a = stride, b = -pad, d = dil,  q = 1       (src = input x,  dst = output y)
+//           dgrad   : a = 1,      b = +pad, d = -dil, q = stride  (src = dy,       dst = dx; needs divisibility)
+//     B   : packed weights [n][tap][c]   (K-contiguous per destination channel)
+//
+// Tiling: 256 threads = 4 waves (64-wide); block tile BM x BN = (WGM*MI*16) x (WGN*NI*16); K advances in 64-byte
+// chunks (16 fp32 / 32 bf16 channels of one tap), double-buffered in LDS with register-staged prefetch
+// (global loads for chunk i+1 are in flight while chunk i is on the matrix cores).
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, config 2) / v_mfma_f32_16x16x32_bf16 (configs 3-5), fp32 accumulate.
+// One 16-byte LDS fragment per lane feeds 4 fp32 MFMAs or 1 bf16 MFMA: lane l holds row (l & 15), 16-byte K-group
+// (l >> 4) -- for fp32 the K order inside a chunk is permuted identically for A and B, which a dot product ignores.
+// LDS rows are 64 B; the 16-byte slot of K-group g in row r is g ^ ((r >> 2) & 3) so that the 16 lanes of a
+// ds_read_b128 group hit 16 distinct slots of the 256-byte bank row.
+// Epilogue (fused, in registers): + bias[n] -> activation (SiLU / sigmoid) -> + residual -> (+= dst) -> store.
+#include "common.h"
+
+namespace {
+
+struct Geom {
+    int32_t M;            // destination pixels
+    int32_t Hd, Wd;       // destination map
+    int32_t Hs, Ws, Cs;   // source map, source channels (K per tap)
+    int32_t Cd;           // destination channels
+    int32_t KH, KW;
+    int32_t a, b, d, q;
+    int32_t act, accumulate;
+    int64_t sld, dld, rld;
+    int32_t tiles_m, tiles_n;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static constexpr int KC = 16;   // elements per 64-byte chunk
+    static constexpr int VEC = 4;   // elements per 16-byte vector
+    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[s]), __builtin_bit_cast(float, b[s]),
+                                                       acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    static constexpr int KC = 32;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+
+// bijective XCD-aware remap: blocks that share an XCD (bid % 8 equal) get a contiguous range of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD>
+__global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
+                                                    const float* __restrict__ bias, const T* __restrict__ res,
+                                                    T* __restrict__ dst, const Geom g) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    constexpr int KC = Mma<T>::KC, VEC = Mma<T>::VEC;
+    constexpr int AR = (BM + 63) / 64, BR = (BN + 63) / 64;   // staged rows per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 64];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + 2 * BM * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-thread staging rows -----------------------------------------------------------------------------
+    const int v = tid & 3;          // 16-byte vector within the 64-byte chunk
+    const int r0 = tid >> 2;        // row 0..63 (+64*i)
+    int32_t py[AR], px[AR];
+    int64_t nbase[AR];
+    bool rowok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int r = r0 + 64 * i;
+        const int m = m0 + r;
+        rowok[i] = (r < BM) && (m < g.M);
+        const int mm = rowok[i] ? m : 0;
+        const int x = mm % g.Wd, t = mm / g.Wd;
+        const int y = t % g.Hd, n = t / g.Hd;
+        py[i] = y * g.a + g.b;
+        px[i] = x * g.a + g.b;
+        nbase[i] = (int64_t)n * g.Hs * g.Ws;
+    }
+    const int Ktot = g.KH * g.KW * g.Cs;
+    const int cpt = (g.Cs + KC - 1) / KC;        // chunks per tap
+    const int nchunks = g.KH * g.KW * cpt;
+
+    u32x4 ra[AR], rb[BR];
+    int tap = 0, cc = 0;  // chunk counters for the NEXT load
+
+    auto load_chunk = [&]() {
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        const int c = cc * KC + v * VEC;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            u32x4 val = {0u, 0u, 0u, 0u};
+            int sy = py[i] + ky * g.d, sx = px[i] + kx * g.d;
+            bool ok = rowok[i] && sy >= 0 && sx >= 0;
+            if (g.q > 1) {
+                ok = ok && (sy % g.q == 0) && (sx % g.q == 0);
+                sy /= g.q;
+                sx /= g.q;
+            }
+            ok = ok && sy < g.Hs && sx < g.Ws;
+            if (ok) {
+                const T* p = src + (nbase[i] + (int64_t)sy * g.Ws + sx) * g.sld + c;
+                if (VECLOAD) {
+                    if (c < g.Cs) val = *reinterpret_cast<const u32x4*>(p);
+                } else {
+                    T tmp[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < g.Cs) ? p[e] : from_f32<T>(0.f);
+                    val = *reinterpret_cast<u32x4*>(tmp);
+                }
+            }
+            ra[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            u32x4 val = {0u, 0u, 0u, 0u};
+            const int r = r0 + 64 * i;
+            const int n = n0 + r;
+            if (r < BN && n < g.Cd) {
+                const T* p = wpk + (int64_t)n * Ktot + tap * g.Cs + c;
+                if (VECLOAD) {
+                    if (c < g.Cs) val = *reinterpret_cast<const u32x4*>(p);
+                } else {
+                    T tmp[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < g.Cs) ? p[e] : from_f32<T>(0.f);
+                    val = *reinterpret_cast<u32x4*>(tmp);
+                }
+            }
+            rb[i] = val;
+        }
+        if (++cc == cpt) { cc = 0; ++tap; }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int r = r0 + 64 * i;
+            if (r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * 64 + ((v ^ ((r >> 2) & 3)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int r = r0 + 64 * i;
+            if (r < BN) *reinterpret_cast<u32x4*>(sB + (buf * BN + r) * 64 + ((v ^ ((r >> 2) & 3)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int buf) {
+        u32x4 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = (wm * MI + i) * 16 + fr;
+            fa[i] = *reinterpret_cast<const u32x4*>(sA + (buf * BM + r) * 64 + ((fg ^ ((r >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int r = (wn * NI + j) * 16 + fr;
+            fb[j] = *reinterpret_cast<const u32x4*>(sB + (buf * BN + r) * 64 + ((fg ^ ((r >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+    };
+
+    // ---- main loop: register-staged double buffering ------------------------------------------------------------
+    load_chunk();
+    store_chunk(0);
+    __syncthreads();
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nchunks;
+        if (more) load_chunk();
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue -----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + (wn * NI + j) * 16 + fr;
+        if (col >= g.Cd) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + (wm * MI + i) * 16 + fg * 4 + e;
+                if (row >= g.M) continue;
+                float val = apply_act(acc[i][j][e] + bv, g.act);
+                if (res) val += to_f32<T>(res[(int64_t)row * g.rld + col]);
+                T* o = dst + (int64_t)row * g.dld + col;
+                if (g.accumulate) val += to_f32<T>(*o);
+                *o = from_f32<T>(val);
+            }
+        }
+    }
+}
+
+template <typename T, int MI, int NI, int WGM, int WGN>
+int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, Geom g, bool vec, hipStream_t st) {
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    if (vec)
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true>), grid, block, 0, st, src, w, bias, res, dst, g);
+    else
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false>), grid, block, 0, st, src, w, bias, res, dst, g);
+    DSN_LAUNCH_CHECK("igemm");
+    return DSN_OK;
+}
+
+template <typename T>
+int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, Geom g,
+           hipStream_t st) {
+    constexpr int VEC = Mma<T>::VEC;
+    const T* src = (const T*)s->ptr;
+    const T* res = r ? (const T*)r->ptr : nullptr;
+    T* dst = (T*)d->ptr;
+    const bool vec = (g.Cs % VEC == 0) && (g.sld % VEC == 0) && (((uintptr_t)src) % 16 == 0) &&
+                     (((uintptr_t)w) % 16 == 0);
+    // tile choice: wide-N tiles for wide layers, tall-skinny for narrow ones; small M prefers smaller tiles so the
+    // grid still covers the 256 CUs.
+    const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.Cd + 127) / 128);
+    if (g.Cd > 64 && big >= 256) return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, g, vec, st);
+    if (g.Cd > 32 && (int64_t)((g.M + 127) / 128) * ((g.Cd + 63) / 64) >= 192)
+        return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, g, vec, st);
+    if (g.Cd > 32) return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, g, vec, st);
+    if (g.Cd > 16) return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, g, vec, st);
+    return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, g, vec, st);
+}
+
+int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const dsn_conv_params* p) {
+    DSN_CHECK_ARG(tensor_ok(s) && tensor_ok(d) && w && p, "conv: null/invalid tensor");
+    DSN_CHECK_ARG(s->dtype == d->dtype, "conv: dtype mismatch");
+    DSN_CHECK_ARG(s->n == d->n, "conv: batch mismatch");
+    DSN_CHECK_ARG(p->kh > 0 && p->kw > 0 && p->stride > 0 && p->dil > 0 && p->pad >= 0, "conv: bad params");
+    DSN_CHECK_ARG(npix(s) < (1ll << 31) && npix(d) < (1ll << 31), "conv: too many pixels for int32 indexing");
+    return DSN_OK;
+}
+
+}  // namespace
+
+extern "C" int dsn_conv2d_fwd(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual,
+                              const dsn_tensor* y, const dsn_conv_params* p, void* stream) {
+    int rc = check_common(x, w, y, p);
+    if (rc) return rc;
+    const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
+    const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
+    DSN_CHECK_ARG(ho == y->h && wo == y->w, "conv fwd: output is %dx%d, expected %dx%d", y->h, y->w, ho, wo);
+    if (residual)
+        DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == y->dtype && residual->n == y->n &&
+                          residual->h == y->h && residual->w == y->w && residual->c == y->c,
+                      "conv fwd: residual shape mismatch");
+    Geom g{};
+    g.M = (int32_t)npix(y); g.Hd = y->h; g.Wd = y->w;
+    g.Hs = x->h; g.Ws = x->w; g.Cs = x->c; g.Cd = y->c;
+    g.KH = p->kh; g.KW = p->kw;
+    g.a = p->stride; g.b = -p->pad; g.d = p->dil; g.q = 1;
+    g.act = p->act; g.accumulate = p->accumulate;
+    g.sld = x->ldc; g.dld = y->ldc; g.rld = residual ? residual->ldc : 0;
+    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, g, (hipStream_t)stream);
+    return launch<bf16_t>(x, w, bias, residual, y, g, (hipStream_t)stream);
+}
+
+extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
+                                void* stream) {
+    int rc = check_common(dy, w, dx, p);
+    if (rc) return rc;
+    const int ho = (dx->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
+    const int wo = (dx->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
+    DSN_CHECK_ARG(ho == dy->h && wo == dy->w, "conv dgrad: dy is %dx%d, expected %dx%d", dy->h, dy->w, ho, wo);
+    Geom g{};
+    g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;
+    g.Hs = dy->h; g.Ws = dy->w; g.Cs = dy->c; g.Cd = dx->c;
+    g.KH = p->kh; g.KW = p->kw;
+    g.a = 1; g.b = p->pad; g.d = -p->dil; g.q = p->stride;
+    g.act = DSN_ACT_NONE; g.accumulate = p->accumulate;
+    g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
+    if (dy->dtype == DSN_F32) return launch<float>(dy, w, nullptr, nullptr, dx, g, (hipStream_t)stream);
+    return launch<bf16_t>(dy, w, nullptr, nullptr, dx, g, (hipStream_t)stream);
+}

@@ -1,0 +1,504 @@
+// Data-movement kernels of the hot path: Focus space-to-depth, SPP max-pools, nearest / bilinear(align_corners) resampling,
+// adaptive average pools, FFM channel scaling -- forward and backward.  All HBM/L2-bound; backward passes are written as
+// GATHERS (each destination element sums its own contributions) so results are deterministic and need no atomics.
+#include "common.h"
+
+namespace {
+
+inline int ew_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+#define GRID_STRIDE(i, total) \
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- Focus: y[n][h][w][g*C + c] = x[n][c][2h + (g&1)][2w + (g>>1)]                       (common.py:626) -------------
+template <typename T>
+__global__ void focus_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W, int cy,
+                                 int64_t yld) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * cy;
+    GRID_STRIDE(i, total) {
+        const int ch = (int)(i % cy);
+        int64_t p = i / cy;
+        const int w = (int)(p % Wo);
+        int64_t t = p / Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float v = 0.f;
+        if (ch < 4 * C) {
+            const int g = ch / C, c = ch - g * C;
+            v = x[(((int64_t)n * C + c) * H + 2 * h + (g & 1)) * W + 2 * w + (g >> 1)];
+        }
+        y[p * yld + ch] = from_f32<T>(v);
+    }
+}
+
+// ---- stride-1 max pool with -inf padding; first maximum in row-major window order (ATen max_pool2d) ----------------------
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y, int64_t yld,
+                               int32_t* __restrict__ idx, int N, int H, int W, int C, int k) {
+    const int r = k / 2;
+    const int64_t total = (int64_t)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int w = (int)(p % W);
+        const int64_t t = p / W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float best = -INFINITY;
+        int bi = -1;
+        const int h0 = h - r < 0 ? 0 : h - r, h1 = h + r >= H ? H - 1 : h + r;
+        const int w0 = w - r < 0 ? 0 : w - r, w1 = w + r >= W ? W - 1 : w + r;
+        for (int hh = h0; hh <= h1; ++hh)
+            for (int ww = w0; ww <= w1; ++ww) {
+                const int q = hh * W + ww;
+                const float v = to_f32<T>(x[((int64_t)n * H * W + q) * xld + c]);
+                if (v > best || bi < 0 || v != v) { best = v; bi = q; }
+            }
+        y[p * yld + c] = from_f32<T>(best);
+        if (idx) idx[i] = bi;
+    }
+}
+
+// dx[n][q][c] (+)= sum over outputs p whose window contains q and whose arg-max is q
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int64_t yld, const int32_t* __restrict__ idx,
+                                   T* __restrict__ dx, int64_t xld, int N, int H, int W, int C, int k, int accumulate) {
+    const int r = k / 2;
+    const int64_t total = (int64_t)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int w = (int)(p % W);
+        const int64_t t = p / W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const int q = h * W + w;
+        float s = 0.f;
+        const int h0 = h - r < 0 ? 0 : h - r, h1 = h + r >= H ? H - 1 : h + r;
+        const int w0 = w - r < 0 ? 0 : w - r, w1 = w + r >= W ? W - 1 : w + r;
+        for (int hh = h0; hh <= h1; ++hh)
+            for (int ww = w0; ww <= w1; ++ww) {
+                const int64_t op = (int64_t)n * H * W + hh * W + ww;
+                if (idx[op * C + c] == q) s += to_f32<T>(dy[op * yld + c]);
+            }
+        T* o = dx + p * xld + c;
+        if (accumulate) s += to_f32<T>(*o);
+        *o = from_f32<T>(s);
+    }
+}
+
+// ---- nearest x2 ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void up2_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y, int64_t yld, int N, int H, int W,
+                           int C) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int w = (int)(p % Wo);
+        const int64_t t = p / Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        y[p * yld + c] = x[(((int64_t)n * H + (h >> 1)) * W + (w >> 1)) * xld + c];
+    }
+}
+template <typename T>
+__global__ void up2_bwd_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld, int N, int H,
+                               int W, int C, int accumulate) {
+    const int Wo = 2 * W;
+    const int64_t total = (int64_t)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int w = (int)(p % W);
+        const int64_t t = p / W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const int64_t q = ((int64_t)n * 2 * H + 2 * h) * Wo + 2 * w;
+        float s = to_f32<T>(dy[q * yld + c]) + to_f32<T>(dy[(q + 1) * yld + c]) + to_f32<T>(dy[(q + Wo) * yld + c]) +
+                  to_f32<T>(dy[(q + Wo + 1) * yld + c]);
+        T* o = dx + p * xld + c;
+        if (accumulate) s += to_f32<T>(*o);
+        *o = from_f32<T>(s);
+    }
+}
+
+// ---- bilinear, align_corners=True (ATen upsample_bilinear2d: scale = (in-1)/(out-1), src = scale*dst) ------------------------
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_coord(int o, float scale, int in) {
+    const float s = scale * (float)o;
+    Lerp r;
+    r.i0 = (int)s;
+    if (r.i0 > in - 1) r.i0 = in - 1;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = s - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+__host__ __device__ inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T, bool NCHW_OUT>
+__global__ void bilinear_kernel(const T* __restrict__ x, int64_t xld, void* __restrict__ yv, int64_t yld, int N, int Hi,
+                                int Wi, int Ho, int Wo, int C, float sh, float sw) {
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        int c, w, h, n;
+        if (NCHW_OUT) {  // i enumerates NCHW so the fp32 stores coalesce along w
+            w = (int)(i % Wo);
+            int64_t t = i / Wo;
+            h = (int)(t % Ho); t /= Ho;
+            c = (int)(t % C);
+            n = (int)(t / C);
+        } else {
+            c = (int)(i % C);
+            int64_t t = i / C;
+            w = (int)(t % Wo); t /= Wo;
+            h = (int)(t % Ho);
+            n = (int)(t / Ho);
+        }
+        const Lerp a = lerp_coord(h, sh, Hi), b = lerp_coord(w, sw, Wi);
+        const T* base = x + (int64_t)n * Hi * Wi * xld + c;
+        const float v00 = to_f32<T>(base[((int64_t)a.i0 * Wi + b.i0) * xld]);
+        const float v01 = to_f32<T>(base[((int64_t)a.i0 * Wi + b.i1) * xld]);
+        const float v10 = to_f32<T>(base[((int64_t)a.i1 * Wi + b.i0) * xld]);
+        const float v11 = to_f32<T>(base[((int64_t)a.i1 * Wi + b.i1) * xld]);
+        const float v = a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11);
+        if (NCHW_OUT)
+            ((float*)yv)[i] = v;
+        else
+            ((T*)yv)[(((int64_t)n * Ho + h) * Wo + w) * yld + c] = from_f32<T>(v);
+    }
+}
+
+// gather form: dx[n][hi][wi][c] (+)= sum_{ho,wo} wh(ho->hi) * ww(wo->wi) * dy[n][ho][wo][c]
+template <typename T, bool NCHW_DY>
+__global__ void bilinear_bwd_kernel(const void* __restrict__ dyv, int64_t yld, T* __restrict__ dx, int64_t xld, int N,
+                                    int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+    const int64_t total = (int64_t)N * Hi * Wi * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int wi = (int)(t % Wi); t /= Wi;
+        const int hi = (int)(t % Hi);
+        const int n = (int)(t / Hi);
+        int h_lo = 0, h_hi = Ho - 1, w_lo = 0, w_hi = Wo - 1;
+        if (sh > 0.f) {
+            h_lo = (int)floorf((float)(hi - 1) / sh) - 1;
+            h_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
+            h_lo = h_lo < 0 ? 0 : h_lo;
+            h_hi = h_hi > Ho - 1 ? Ho - 1 : h_hi;
+        }
+        if (sw > 0.f) {
+            w_lo = (int)floorf((float)(wi - 1) / sw) - 1;
+            w_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
+            w_lo = w_lo < 0 ? 0 : w_lo;
+            w_hi = w_hi > Wo - 1 ? Wo - 1 : w_hi;
+        }
+        float s = 0.f;
+        for (int ho = h_lo; ho <= h_hi; ++ho) {
+            const Lerp a = lerp_coord(ho, sh, Hi);
+            const float wh = (a.i0 == hi ? a.l0 : 0.f) + (a.i1 == hi ? a.l1 : 0.f);
+            if (wh == 0.f) continue;
+            for (int wo = w_lo; wo <= w_hi; ++wo) {
+                const Lerp b = lerp_coord(wo, sw, Wi);
+                const float ww = (b.i0 == wi ? b.l0 : 0.f) + (b.i1 == wi ? b.l1 : 0.f);
+                if (ww == 0.f) continue;
+                float g;
+                if (NCHW_DY)
+                    g = ((const float*)dyv)[(((int64_t)n * C + c) * Ho + ho) * Wo + wo];
+                else
+                    g = to_f32<T>(((const T*)dyv)[(((int64_t)n * Ho + ho) * Wo + wo) * yld + c]);
+                s += wh * ww * g;
+            }
+        }
+        T* o = dx + (((int64_t)n * Hi + hi) * Wi + wi) * xld + c;
+        if (accumulate) s += to_f32<T>(*o);
+        *o = from_f32<T>(s);
+    }
+}
+
+// ---- adaptive average pool: bin o covers [floor(o*H/k), ceil((o+1)*H/k)) ------------------------------------------------
+__device__ __forceinline__ int bin_lo(int o, int in, int k) { return (o * in) / k; }
+__device__ __forceinline__ int bin_hi(int o, int in, int k) { return ((o + 1) * in + k - 1) / k; }
+
+// one block per (n, oh, ow); thread (ty, tx): tx = channel, ty strides the window's pixels; LDS fold.
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y,
+                                                               int64_t yld, int H, int W, int C, int KH, int KW) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    const int ow = b % KW, oh = (b / KW) % KH, n = b / (KW * KH);
+    const int h0 = bin_lo(oh, H, KH), h1 = bin_hi(oh, H, KH), w0 = bin_lo(ow, W, KW), w1 = bin_hi(ow, W, KW);
+    const int ww = w1 - w0, cnt = (h1 - h0) * ww;
+    const int TX = C < 256 ? C : 256, TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    for (int c0 = 0; c0 < C; c0 += TX) {
+        const int c = c0 + tx;
+        float s = 0.f;
+        if (ty < TY && c < C)
+            for (int q = ty; q < cnt; q += TY) {
+                const int hh = h0 + q / ww, wq = w0 + q % ww;
+                s += to_f32<T>(x[(((int64_t)n * H + hh) * W + wq) * xld + c]);
+            }
+        __syncthreads();
+        if (ty < TY) red[ty * TX + tx] = s;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            float tot = 0.f;
+            for (int t = 0; t < TY; ++t) tot += red[t * TX + tx];
+            y[(((int64_t)n * KH + oh) * KW + ow) * yld + c] = from_f32<T>(tot / (float)cnt);
+        }
+    }
+}
+
+template <typename T>
+__global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld,
+                                            int N, int H, int W, int C, int KH, int KW, int accumulate) {
+    const int64_t total = (int64_t)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float s = 0.f;
+        for (int oh = 0; oh < KH; ++oh) {
+            const int h0 = bin_lo(oh, H, KH), h1 = bin_hi(oh, H, KH);
+            if (h < h0 || h >= h1) continue;
+            for (int ow = 0; ow < KW; ++ow) {
+                const int w0 = bin_lo(ow, W, KW), w1 = bin_hi(ow, W, KW);
+                if (w < w0 || w >= w1) continue;
+                s += to_f32<T>(dy[(((int64_t)n * KH + oh) * KW + ow) * yld + c]) / (float)((h1 - h0) * (w1 - w0));
+            }
+        }
+        T* o = dx + (((int64_t)n * H + h) * W + w) * xld + c;
+        if (accumulate) s += to_f32<T>(*o);
+        *o = from_f32<T>(s);
+    }
+}
+
+// ---- FFM: out = feat*att + feat                                                          (common.py:240-241) --------
+template <typename T>
+__global__ void ffm_scale_kernel(const T* __restrict__ f, int64_t fld, const T* __restrict__ att, int64_t ald,
+                                 T* __restrict__ out, int64_t old_, int64_t HW, int64_t P, int C) {
+    const int64_t total = P * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const float v = to_f32<T>(f[p * fld + c]);
+        const float a = to_f32<T>(att[(p / HW) * ald + c]);
+        out[p * old_ + c] = from_f32<T>(v * a + v);
+    }
+}
+template <typename T>
+__global__ void ffm_scale_bwd_feat_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ att,
+                                          int64_t ald, T* __restrict__ dfeat, int64_t fld, int64_t HW, int64_t P, int C,
+                                          int accumulate) {
+    const int64_t total = P * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const float a = to_f32<T>(att[(p / HW) * ald + c]);
+        const float g = to_f32<T>(dout[p * dld + c]);
+        float s = g * a + g;
+        T* o = dfeat + p * fld + c;
+        if (accumulate) s += to_f32<T>(*o);
+        *o = from_f32<T>(s);
+    }
+}
+// datt[n][c] = sum_hw dout*feat : one block per image, same (ty, tx) fold as the pools
+template <typename T>
+__global__ __launch_bounds__(256) void ffm_scale_bwd_att_kernel(const T* __restrict__ dout, int64_t dld,
+                                                                const T* __restrict__ f, int64_t fld,
+                                                                T* __restrict__ datt, int64_t ald, int64_t HW, int C) {
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    const int TX = C < 256 ? C : 256, TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    for (int c0 = 0; c0 < C; c0 += TX) {
+        const int c = c0 + tx;
+        float s = 0.f;
+        if (ty < TY && c < C)
+            for (int64_t q = ty; q < HW; q += TY) {
+                const int64_t p = (int64_t)n * HW + q;
+                s += to_f32<T>(dout[p * dld + c]) * to_f32<T>(f[p * fld + c]);
+            }
+        __syncthreads();
+        if (ty < TY) red[ty * TX + tx] = s;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            float tot = 0.f;
+            for (int t = 0; t < TY; ++t) tot += red[t * TX + tx];
+            datt[(int64_t)n * ald + c] = from_f32<T>(tot);
+        }
+    }
+}
+
+inline bool same_nhwc(const dsn_tensor* a, const dsn_tensor* b) {
+    return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c && a->dtype == b->dtype;
+}
+
+}  // namespace
+
+extern "C" int dsn_focus_s2d(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
+                             void* stream) {
+    DSN_CHECK_ARG(x && tensor_ok(y) && n > 0 && c > 0, "focus_s2d: invalid arguments");
+    DSN_CHECK_ARG(h % 2 == 0 && w % 2 == 0, "focus_s2d: H and W must be even (got %dx%d)", h, w);
+    DSN_CHECK_ARG(y->n == n && y->h == h / 2 && y->w == w / 2 && y->c >= 4 * c, "focus_s2d: output shape mismatch");
+    const int64_t total = npix(y) * y->c;
+    DSN_DISPATCH_DTYPE(y->dtype, T,
+                       hipLaunchKernelGGL(focus_s2d_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x,
+                                          (T*)y->ptr, n, c, h, w, y->c, y->ldc));
+    DSN_LAUNCH_CHECK("focus_s2d");
+    return DSN_OK;
+}
+
+extern "C" int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(y) && same_nhwc(x, y) && k >= 1 && (k & 1), "maxpool_s1: invalid arguments");
+    DSN_CHECK_ARG((int64_t)x->h * x->w < (1ll << 31), "maxpool_s1: map too large");
+    const int64_t total = npix(x) * x->c;
+    DSN_DISPATCH_DTYPE(x->dtype, T,
+                       hipLaunchKernelGGL(maxpool_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                          (const T*)x->ptr, x->ldc, (T*)y->ptr, y->ldc, idx, x->n, x->h, x->w, x->c, k));
+    DSN_LAUNCH_CHECK("maxpool_s1");
+    return DSN_OK;
+}
+
+extern "C" int dsn_maxpool_s1_bwd(const dsn_tensor* dy, const int32_t* idx, const dsn_tensor* dx, int32_t k,
+                                  int32_t accumulate, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dy) && tensor_ok(dx) && same_nhwc(dy, dx) && idx && k >= 1 && (k & 1),
+                  "maxpool_s1_bwd: invalid arguments");
+    const int64_t total = npix(dx) * dx->c;
+    DSN_DISPATCH_DTYPE(dx->dtype, T,
+                       hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                          (const T*)dy->ptr, dy->ldc, idx, (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w,
+                                          dx->c, k, accumulate));
+    DSN_LAUNCH_CHECK("maxpool_s1_bwd");
+    return DSN_OK;
+}
+
+extern "C" int dsn_upsample_nearest2x(const dsn_tensor* x, const dsn_tensor* y, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(y) && x->dtype == y->dtype && y->n == x->n && y->h == 2 * x->h &&
+                      y->w == 2 * x->w && y->c == x->c,
+                  "upsample_nearest2x: shape mismatch");
+    const int64_t total = npix(y) * y->c;
+    DSN_DISPATCH_DTYPE(x->dtype, T,
+                       hipLaunchKernelGGL(up2_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                          (const T*)x->ptr, x->ldc, (T*)y->ptr, y->ldc, x->n, x->h, x->w, x->c));
+    DSN_LAUNCH_CHECK("upsample_nearest2x");
+    return DSN_OK;
+}
+
+extern "C" int dsn_upsample_nearest2x_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dx) && tensor_ok(dy) && dx->dtype == dy->dtype && dy->n == dx->n && dy->h == 2 * dx->h &&
+                      dy->w == 2 * dx->w && dy->c == dx->c,
+                  "upsample_nearest2x_bwd: shape mismatch");
+    const int64_t total = npix(dx) * dx->c;
+    DSN_DISPATCH_DTYPE(dx->dtype, T,
+                       hipLaunchKernelGGL(up2_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                          (const T*)dy->ptr, dy->ldc, (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dx->c,
+                                          accumulate));
+    DSN_LAUNCH_CHECK("upsample_nearest2x_bwd");
+    return DSN_OK;
+}
+
+extern "C" int dsn_bilinear_ac(const dsn_tensor* x, const dsn_tensor* y, int32_t out_nchw, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && y && y->ptr && y->n == x->n && y->c == x->c && y->h > 0 && y->w > 0,
+                  "bilinear_ac: invalid arguments");
+    DSN_CHECK_ARG(out_nchw ? (y->dtype == DSN_F32) : (y->dtype == x->dtype && y->ldc >= y->c),
+                  "bilinear_ac: NCHW output must be fp32; NHWC output must match the input dtype");
+    const float sh = ac_scale(x->h, y->h), sw = ac_scale(x->w, y->w);
+    const int64_t total = (int64_t)y->n * y->h * y->w * y->c;
+    hipStream_t st = (hipStream_t)stream;
+    DSN_DISPATCH_DTYPE(x->dtype, T, {
+        if (out_nchw)
+            hipLaunchKernelGGL((bilinear_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x->ptr,
+                               x->ldc, y->ptr, y->ldc, x->n, x->h, x->w, y->h, y->w, x->c, sh, sw);
+        else
+            hipLaunchKernelGGL((bilinear_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x->ptr,
+                               x->ldc, y->ptr, y->ldc, x->n, x->h, x->w, y->h, y->w, x->c, sh, sw);
+    });
+    DSN_LAUNCH_CHECK("bilinear_ac");
+    return DSN_OK;
+}
+
+extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const dsn_tensor* dx, int32_t accumulate,
+                                   void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dx) && dy && dy->ptr && dy->n == dx->n && dy->c == dx->c && dy->h > 0 && dy->w > 0,
+                  "bilinear_ac_bwd: invalid arguments");
+    DSN_CHECK_ARG(dy_nchw ? (dy->dtype == DSN_F32) : (dy->dtype == dx->dtype),
+                  "bilinear_ac_bwd: NCHW dy must be fp32; NHWC dy must match dx dtype");
+    const float sh = ac_scale(dx->h, dy->h), sw = ac_scale(dx->w, dy->w);
+    const int64_t total = npix(dx) * dx->c;
+    hipStream_t st = (hipStream_t)stream;
+    DSN_DISPATCH_DTYPE(dx->dtype, T, {
+        if (dy_nchw)
+            hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, st, dy->ptr, dy->ldc,
+                               (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dy->h, dy->w, dx->c, sh, sw, accumulate);
+        else
+            hipLaunchKernelGGL((bilinear_bwd_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, st, dy->ptr,
+                               dy->ldc, (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dy->h, dy->w, dx->c, sh, sw,
+                               accumulate);
+    });
+    DSN_LAUNCH_CHECK("bilinear_ac_bwd");
+    return DSN_OK;
+}
+
+extern "C" int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(y) && x->dtype == y->dtype && x->n == y->n && x->c == y->c,
+                  "adaptive_avgpool: invalid arguments");
+    DSN_DISPATCH_DTYPE(x->dtype, T,
+                       hipLaunchKernelGGL(adaptive_avgpool_kernel<T>, dim3(y->n * y->h * y->w), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)x->ptr, x->ldc, (T*)y->ptr, y->ldc, x->h, x->w,
+                                          x->c, y->h, y->w));
+    DSN_LAUNCH_CHECK("adaptive_avgpool");
+    return DSN_OK;
+}
+
+extern "C" int dsn_adaptive_avgpool_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dx) && tensor_ok(dy) && dx->dtype == dy->dtype && dx->n == dy->n && dx->c == dy->c,
+                  "adaptive_avgpool_bwd: invalid arguments");
+    const int64_t total = npix(dx) * dx->c;
+    DSN_DISPATCH_DTYPE(dx->dtype, T,
+                       hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)dy->ptr, dy->ldc, (T*)dx->ptr, dx->ldc, dx->n,
+                                          dx->h, dx->w, dx->c, dy->h, dy->w, accumulate));
+    DSN_LAUNCH_CHECK("adaptive_avgpool_bwd");
+    return DSN_OK;
+}
+
+extern "C" int dsn_ffm_scale(const dsn_tensor* feat, const dsn_tensor* att, const dsn_tensor* out, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(feat) && tensor_ok(att) && tensor_ok(out) && same_nhwc(feat, out) &&
+                      att->dtype == feat->dtype && att->n == feat->n && att->h == 1 && att->w == 1 && att->c == feat->c,
+                  "ffm_scale: invalid arguments");
+    const int64_t P = npix(feat);
+    DSN_DISPATCH_DTYPE(feat->dtype, T,
+                       hipLaunchKernelGGL(ffm_scale_kernel<T>, dim3(ew_grid(P * feat->c)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)feat->ptr, feat->ldc, (const T*)att->ptr,
+                                          att->ldc, (T*)out->ptr, out->ldc, (int64_t)feat->h * feat->w, P, feat->c));
+    DSN_LAUNCH_CHECK("ffm_scale");
+    return DSN_OK;
+}
+
+extern "C" int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat, const dsn_tensor* att,
+                                 const dsn_tensor* dfeat, const dsn_tensor* datt, int32_t accumulate, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dout) && tensor_ok(feat) && tensor_ok(att) && tensor_ok(dfeat) && tensor_ok(datt) &&
+                      same_nhwc(dout, feat) && same_nhwc(dfeat, feat) && same_nhwc(att, datt) && att->n == feat->n &&
+                      att->h == 1 && att->w == 1 && att->c == feat->c && att->dtype == feat->dtype,
+                  "ffm_scale_bwd: invalid arguments");
+    const int64_t P = npix(feat), HW = (int64_t)feat->h * feat->w;
+    hipStream_t st = (hipStream_t)stream;
+    DSN_DISPATCH_DTYPE(feat->dtype, T, {
+        hipLaunchKernelGGL(ffm_scale_bwd_att_kernel<T>, dim3(feat->n), dim3(256), 0, st, (const T*)dout->ptr, dout->ldc,
+                           (const T*)feat->ptr, feat->ldc, (T*)datt->ptr, datt->ldc, HW, feat->c);
+        hipLaunchKernelGGL(ffm_scale_bwd_feat_kernel<T>, dim3(ew_grid(P * feat->c)), dim3(256), 0, st,
+                           (const T*)dout->ptr, dout->ldc, (const T*)att->ptr, att->ldc, (T*)dfeat->ptr, dfeat->ldc, HW,
+                           P, feat->c, accumulate);
+    });
+    DSN_LAUNCH_CHECK("ffm_scale_bwd");
+    return DSN_OK;
+}

@@ -1,0 +1,276 @@
+// Weight gradient of a convolution on MFMA (gfx950):  dW[co][tap][ci] = sum_p dy[p][co] * x[src(p, tap)][ci]
+//
+// Per tap this is a GEMM whose REDUCTION dimension is the pixel index p (up to N*160*160 = 204,800 at batch 8) and whose
+// output is tiny (Co x Ci).  One workgroup owns a 64(co) x 64(ci) tile of ONE tap over ONE contiguous pixel range
+// (split-K); partial tiles go to fp32 slabs that a second kernel adds up in a fixed order -- deterministic, no float
+// atomics.  Both operands are pixel-major in HBM (NHWC), i.e. "K-strided" for MFMA; the 32-pixel chunks are staged
+// row-major [pixel][channel] in LDS with coalesced 16-byte loads and transposed on the way OUT of LDS:
+//   fp32 : v_mfma_f32_16x16x4_f32 takes one scalar per lane  -> plain ds_read_b32 from a padded image
+//   bf16 : v_mfma_f32_16x16x32_bf16 takes 8 K-contiguous bf16 -> two ds_read_b64_tr_b16 (hardware transpose) per fragment
+#include "common.h"
+
+namespace {
+
+struct WGeom {
+    int32_t P, Ho, Wo, Hi, Wi, Co, Ci, Cip, KH, KW, stride, pad, dil;
+    int64_t yld, xld;
+    int32_t S, ppb, tiles_co, tiles_ci;
+    int32_t accumulate;
+};
+
+constexpr int PK = 32;    // pixels per chunk
+constexpr int TB = 64;    // tile edge (co and ci)
+
+template <typename T> struct WTraits;
+template <> struct WTraits<float> {
+    static constexpr int VEC = 4, ROW = TB + 16;   // padded row (floats): lanes l and l+16 land 16 banks apart
+};
+template <> struct WTraits<bf16_t> {
+    static constexpr int VEC = 8, ROW = TB;        // 128-byte rows for the transposing read
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T, bool VECLOAD>
+__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                    float* __restrict__ out, const WGeom g) {
+    constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW;
+    constexpr int VPR = TB / VEC;          // vectors per tile row
+    constexpr int NV = VPR / 8;            // vectors per thread per operand (8 threads per row)
+    __shared__ __attribute__((aligned(16))) T sA[2][PK * ROW];
+    __shared__ __attribute__((aligned(16))) T sB[2][PK * ROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int taps = g.KH * g.KW;
+    int bid = blockIdx.x;
+    const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
+    const int tco = bid % g.tiles_co; bid /= g.tiles_co;
+    const int tap = bid % taps;
+    const int split = bid / taps;
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+    const int co0 = tco * TB, ci0 = tci * TB;
+    const int p_begin = split * g.ppb;
+    const int p_end = (p_begin + g.ppb < g.P) ? p_begin + g.ppb : g.P;
+    const int nchunks = (p_end - p_begin + PK - 1) / PK;
+
+    const int srow = tid >> 3;      // staged pixel row 0..31
+    const int sv = tid & 7;         // first vector of the row
+    u32x4 ra[NV], rb[NV];
+
+    auto load_vec = [&](const T* p, int c, int climit) -> u32x4 {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (VECLOAD) {
+            if (c < climit) v = *reinterpret_cast<const u32x4*>(p);
+        } else {
+            T tmp[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < climit) ? p[e] : from_f32<T>(0.f);
+            v = *reinterpret_cast<u32x4*>(tmp);
+        }
+        return v;
+    };
+    auto load_chunk = [&](int ch) {
+        const int p = p_begin + ch * PK + srow;
+        const bool pok = p < p_end;
+        int ox = 0, oy = 0, n = 0;
+        if (pok) {
+            ox = p % g.Wo;
+            const int t = p / g.Wo;
+            oy = t % g.Ho;
+            n = t / g.Ho;
+        }
+        const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
+        const bool xok = pok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vc = (sv + 8 * i) * VEC;
+            ra[i] = u32x4{0u, 0u, 0u, 0u};
+            rb[i] = u32x4{0u, 0u, 0u, 0u};
+            if (pok) ra[i] = load_vec(dy + (int64_t)p * g.yld + co0 + vc, co0 + vc, g.Co);
+            if (xok) rb[i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.Ci);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vc = (sv + 8 * i) * VEC;
+            *reinterpret_cast<u32x4*>(&sA[buf][srow * ROW + vc]) = ra[i];
+            *reinterpret_cast<u32x4*>(&sB[buf][srow * ROW + vc]) = rb[i];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        if constexpr (sizeof(T) == 4) {
+            const float* A = reinterpret_cast<const float*>(sA[buf]);
+            const float* B = reinterpret_cast<const float*>(sB[buf]);
+#pragma unroll
+            for (int s = 0; s < PK / 4; ++s) {
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = A[(4 * s + fg) * ROW + (wm * 2 + i) * 16 + fr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = B[(4 * s + fg) * ROW + (wn * 2 + j) * 16 + fr];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block; it receives column (lane&15),
+            // rows 0..3.  Block rows = pixels 8*fg + {0..3} then {4..7}; block columns = the fragment's 16 channels.
+            const int q = fr >> 2, pp = fr & 3;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16_t* base = &sA[buf][(8 * fg + q) * ROW + (wm * 2 + i) * 16 + 4 * pp];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+                const s16x4 hi =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+                a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16_t* base = &sB[buf][(8 * fg + q) * ROW + (wn * 2 + j) * 16 + 4 * pp];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+                const s16x4 hi =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+                b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nchunks;
+        if (more) load_chunk(it + 1);
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[row = co][col = ci]
+    float* o = out + (g.S > 1 ? (int64_t)split * g.Co * taps * g.Cip : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + (wm * 2 + i) * 16 + fg * 4 + e;
+                const int ci = ci0 + (wn * 2 + j) * 16 + fr;
+                if (co < g.Co && ci < g.Ci) {
+                    float* d = o + ((int64_t)co * taps + tap) * g.Cip + ci;
+                    float v = acc[i][j][e];
+                    if (g.S == 1 && g.accumulate) v += *d;
+                    *d = v;
+                }
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t n, int S,
+                                    int accumulate) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+inline int choose_split(const WGeom& g) {
+    const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * g.KH * g.KW;
+    int64_t s = (1024 + base - 1) / base;
+    const int64_t smax = (g.P + 255) / 256;
+    if (s > smax) s = smax;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* dy,
+                                                    const dsn_conv_params* p, int32_t ci_pad) {
+    if (!x || !dy || !p) return 0;
+    WGeom g{};
+    g.P = (int32_t)npix(dy);
+    g.tiles_co = (dy->c + TB - 1) / TB;
+    g.tiles_ci = (x->c + TB - 1) / TB;
+    g.KH = p->kh; g.KW = p->kw;
+    const int S = choose_split(g);
+    return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * ci_pad * sizeof(float) : 0;
+}
+
+extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad,
+                                const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(dy) && dw && p, "conv wgrad: null/invalid argument");
+    DSN_CHECK_ARG(x->dtype == dy->dtype && x->n == dy->n && ci_pad >= x->c, "conv wgrad: dtype/batch mismatch");
+    const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
+    const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
+    DSN_CHECK_ARG(ho == dy->h && wo == dy->w, "conv wgrad: dy is %dx%d, expected %dx%d", dy->h, dy->w, ho, wo);
+    DSN_CHECK_ARG(npix(dy) < (1ll << 31) && npix(x) < (1ll << 31), "conv wgrad: too many pixels");
+    WGeom g{};
+    g.P = (int32_t)npix(dy); g.Ho = dy->h; g.Wo = dy->w; g.Hi = x->h; g.Wi = x->w;
+    g.Co = dy->c; g.Ci = x->c; g.Cip = ci_pad;
+    g.KH = p->kh; g.KW = p->kw; g.stride = p->stride; g.pad = p->pad; g.dil = p->dil;
+    g.yld = dy->ldc; g.xld = x->ldc;
+    g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
+    g.S = choose_split(g);
+    g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
+    g.S = (g.P + g.ppb - 1) / g.ppb;
+    g.accumulate = p->accumulate;
+    const int64_t n_out = (int64_t)g.Co * g.KH * g.KW * g.Cip;
+    float* out = dw;
+    hipStream_t st = (hipStream_t)stream;
+    if (g.S > 1) {
+        if (!workspace || workspace_bytes < (int64_t)g.S * n_out * (int64_t)sizeof(float))
+            DSN_FAIL(DSN_EWORKSPACE, "conv wgrad: workspace too small (%lld bytes needed)",
+                     (long long)((int64_t)g.S * n_out * sizeof(float)));
+        out = (float*)workspace;
+    }
+    // every slab element a block does not own must read as zero in the reduction: tiles cover co<Co, ci<Ci only, the
+    // ci_pad tail is never written -> clear it when padding exists.
+    if (g.S > 1 && g.Cip != g.Ci) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)g.S * n_out * sizeof(float), st);
+        if (e != hipSuccess) DSN_FAIL((int)e, "conv wgrad: memset failed");
+    }
+    const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
+    const bool vl = (g.Co % vec == 0) && (g.Ci % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
+                    ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
+    dim3 grid(g.tiles_ci * g.tiles_co * g.KH * g.KW * g.S), block(256);
+    DSN_DISPATCH_DTYPE(x->dtype, T, {
+        if (vl)
+            hipLaunchKernelGGL((wgrad_kernel<T, true>), grid, block, 0, st, (const T*)x->ptr, (const T*)dy->ptr, out, g);
+        else
+            hipLaunchKernelGGL((wgrad_kernel<T, false>), grid, block, 0, st, (const T*)x->ptr, (const T*)dy->ptr, out, g);
+    });
+    DSN_LAUNCH_CHECK("conv wgrad");
+    if (g.S > 1) {
+        int64_t b = (n_out + 255) / 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(b > 2048 ? 2048 : b)), dim3(256), 0, st, out, dw, n_out, g.S,
+                           p->accumulate);
+        DSN_LAUNCH_CHECK("conv wgrad reduce");
+    } else if (g.Cip != g.Ci && !p->accumulate) {
+        // direct write leaves the padding lanes of dw untouched: they are defined to be zero
+        // (callers allocate dw zero-filled once; padding is never written afterwards).
+    }
+    return DSN_OK;
+}

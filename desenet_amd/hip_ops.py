@@ -1,0 +1,345 @@
+"""Thin torch-tensor wrappers over the C ABI (include/desenet_hip.h).
+
+Tensors are logical NCHW `torch.Tensor`s whose MEMORY is NHWC with an arbitrary pixel stride `ldc >= C`
+(`new_act` allocates them; `x[:, c0:c1]` of such a tensor is a zero-copy channel slice the kernels can read or write in
+place -- that is how concat buffers are built without torch.cat).  PyTorch supplies device memory and the current HIP
+stream; every FLOP and byte moved on the hot path is done by libdesenet_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_SIGMOID, ACT_SILU, DSN_BF16, DSN_F32, dsn_conv_params, dsn_tensor  # noqa: F401
+
+_DT = {torch.float32: DSN_F32, torch.bfloat16: DSN_BF16}
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("desenet_amd kernels run on an MI355X only: got a CPU tensor (there is no CPU fallback; "
+                           "the CPU oracle lives in oracle/ and is test infrastructure)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def new_act(n: int, c: int, h: int, w: int, dtype, device, zero: bool = False) -> torch.Tensor:
+    """Logical NCHW tensor backed by a fresh dense NHWC buffer."""
+    buf = (torch.zeros if zero else torch.empty)((n, h, w, c), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)
+
+
+def _nhwc_ldc(t: torch.Tensor) -> Optional[int]:
+    """Pixel stride if `t` (logical NCHW) is NHWC-dense in N,H,W with unit channel stride, else None."""
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        return None
+    if w > 1:
+        ldc = sw
+    elif h > 1:
+        ldc = sh
+    elif n > 1:
+        ldc = sn
+    else:
+        ldc = c
+    if ldc < c:
+        return None
+    if (w > 1 and sw != ldc) or (h > 1 and sh != w * ldc) or (n > 1 and sn != h * w * ldc):
+        return None
+    return ldc
+
+
+def as_act(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` itself when its memory is already NHWC(+slice); otherwise one channels-last copy (network boundary)."""
+    if t.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got shape {tuple(t.shape)}")
+    _require_gpu(t)
+    if _nhwc_ldc(t) is not None:
+        return t
+    n, c, h, w = t.shape
+    out = new_act(n, c, h, w, t.dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+def desc(t: torch.Tensor) -> dsn_tensor:
+    _require_gpu(t)
+    ldc = _nhwc_ldc(t)
+    if ldc is None:
+        raise ValueError(f"tensor with shape {tuple(t.shape)} strides {t.stride()} is not an NHWC view")
+    if t.dtype not in _DT:
+        raise TypeError(f"unsupported dtype {t.dtype} (fp32 and bf16 only)")
+    n, c, h, w = t.shape
+    return dsn_tensor(t.data_ptr(), _DT[t.dtype], n, h, w, c, ldc)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ref(d: Optional[dsn_tensor]):
+    return None if d is None else C.byref(d)
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+def conv_params(k, stride=1, pad=None, dil=1, act=ACT_NONE, accumulate=False) -> dsn_conv_params:
+    kh, kw = (k, k) if isinstance(k, int) else k
+    if pad is None:
+        pad = kh // 2
+    return dsn_conv_params(kh, kw, stride, pad, dil, act, int(accumulate))
+
+
+def conv_out_hw(h, w, k, stride, pad, dil):
+    return ((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
+
+
+def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params):
+    L = _lib.lib()
+    dx, dy = desc(x), desc(y)
+    dr = desc(residual) if residual is not None else None
+    _lib.check(L.dsn_conv2d_fwd(C.byref(dx), w_packed.data_ptr(), _p(bias), _ref(dr), C.byref(dy), C.byref(p),
+                                stream_ptr()), "conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params):
+    L = _lib.lib()
+    a, b = desc(dy), desc(dx)
+    _lib.check(L.dsn_conv2d_dgrad(C.byref(a), w_packed_dgrad.data_ptr(), C.byref(b), C.byref(p), stream_ptr()),
+               "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw_packed, ci_pad, p: dsn_conv_params):
+    L = _lib.lib()
+    a, b = desc(x), desc(dy)
+    nbytes = L.dsn_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(b), C.byref(p), ci_pad)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(L.dsn_conv2d_wgrad(C.byref(a), C.byref(b), dw_packed.data_ptr(), ci_pad, C.byref(p), ws.data_ptr(),
+                                  nbytes, stream_ptr()), "conv2d_wgrad")
+    return dw_packed
+
+
+def pack_weight_fwd(w_oihw: torch.Tensor, dtype, scale: Optional[torch.Tensor] = None, ci_pad: Optional[int] = None):
+    co, ci, kh, kw = w_oihw.shape
+    ci_pad = ci if ci_pad is None else ci_pad
+    w = w_oihw.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    out = torch.empty((co, kh, kw, ci_pad), dtype=dtype, device=w.device)
+    _lib.check(_lib.lib().dsn_pack_weight_fwd(w.data_ptr(), _p(scale), out.data_ptr(), _DT[dtype], co, ci, kh, kw, ci_pad,
+                                              stream_ptr()), "pack_weight_fwd")
+    return out
+
+
+def pack_weight_dgrad(w_oihw: torch.Tensor, dtype):
+    co, ci, kh, kw = w_oihw.shape
+    w = w_oihw.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    out = torch.empty((ci, kh, kw, co), dtype=dtype, device=w.device)
+    _lib.check(_lib.lib().dsn_pack_weight_dgrad(w.data_ptr(), out.data_ptr(), _DT[dtype], co, ci, kh, kw, stream_ptr()),
+               "pack_weight_dgrad")
+    return out
+
+
+def unpack_wgrad(dw_packed, shape_oihw, ci_pad, out: Optional[torch.Tensor] = None):
+    co, ci, kh, kw = shape_oihw
+    acc = out is not None
+    if out is None:
+        out = torch.empty(shape_oihw, dtype=torch.float32, device=dw_packed.device)
+    _lib.check(_lib.lib().dsn_unpack_wgrad(dw_packed.data_ptr(), out.data_ptr(), co, ci, kh, kw, ci_pad, int(acc),
+                                           stream_ptr()), "unpack_wgrad")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ BN + act
+_ws_cache = {}
+
+
+def _bn_ws(c, device):
+    key = (c, device)
+    if key not in _ws_cache:
+        nbytes = _lib.lib().dsn_bn_workspace_bytes(c)
+        _ws_cache[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes)
+    return _ws_cache[key]
+
+
+def bn_stats(y, gamma, beta, running_mean, running_var, momentum, eps):
+    """Returns (scale, shift, mean, rstd), each fp32 [C]; updates running stats in place when given."""
+    c = y.shape[1]
+    out = torch.empty((4, c), dtype=torch.float32, device=y.device)
+    ws, nbytes = _bn_ws(c, y.device)
+    d = desc(y)
+    _lib.check(_lib.lib().dsn_bn_stats(C.byref(d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum,
+                                       eps, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                       ws.data_ptr(), nbytes, stream_ptr()), "bn_stats")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_act_fwd(y, scale, shift, act, residual, z):
+    a, b = desc(y), desc(z)
+    r = desc(residual) if residual is not None else None
+    _lib.check(_lib.lib().dsn_bn_act_fwd(C.byref(a), _p(scale), _p(shift), act, _ref(r), C.byref(b), stream_ptr()),
+               "bn_act_fwd")
+    return z
+
+
+def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False):
+    a, b, c = desc(dz), desc(y), desc(dy)
+    ws, nbytes = _bn_ws(y.shape[1], y.device)
+    _lib.check(_lib.lib().dsn_bn_act_bwd(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),
+                                         ws.data_ptr(), nbytes, stream_ptr()), "bn_act_bwd")
+    return dy
+
+
+def act_bwd(dz, y, act, dy):
+    a, b, c = desc(dz), desc(y), desc(dy)
+    _lib.check(_lib.lib().dsn_act_bwd(C.byref(a), C.byref(b), act, C.byref(c), stream_ptr()), "act_bwd")
+    return dy
+
+
+# ------------------------------------------------------------------------------------------------ data movement
+def focus_s2d(x_nchw: torch.Tensor, y):
+    _require_gpu(x_nchw)
+    x = x_nchw
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    n, c, h, w = x.shape
+    d = desc(y)
+    _lib.check(_lib.lib().dsn_focus_s2d(x.data_ptr(), n, c, h, w, C.byref(d), stream_ptr()), "focus_s2d")
+    return y
+
+
+def maxpool_s1(x, y, k, idx: Optional[torch.Tensor] = None):
+    a, b = desc(x), desc(y)
+    _lib.check(_lib.lib().dsn_maxpool_s1(C.byref(a), C.byref(b), _p(idx), k, stream_ptr()), "maxpool_s1")
+    return y
+
+
+def maxpool_s1_bwd(dy, idx, dx, k, accumulate=False):
+    a, b = desc(dy), desc(dx)
+    _lib.check(_lib.lib().dsn_maxpool_s1_bwd(C.byref(a), idx.data_ptr(), C.byref(b), k, int(accumulate), stream_ptr()),
+               "maxpool_s1_bwd")
+    return dx
+
+
+def upsample_nearest2x(x, y):
+    a, b = desc(x), desc(y)
+    _lib.check(_lib.lib().dsn_upsample_nearest2x(C.byref(a), C.byref(b), stream_ptr()), "upsample_nearest2x")
+    return y
+
+
+def upsample_nearest2x_bwd(dy, dx, accumulate=False):
+    a, b = desc(dy), desc(dx)
+    _lib.check(_lib.lib().dsn_upsample_nearest2x_bwd(C.byref(a), C.byref(b), int(accumulate), stream_ptr()),
+               "upsample_nearest2x_bwd")
+    return dx
+
+
+def _desc_nchw(t: torch.Tensor) -> dsn_tensor:
+    """Descriptor of a CONTIGUOUS NCHW fp32 tensor (seg logits / their gradient); ldc is unused by NCHW kernels."""
+    _require_gpu(t)
+    assert t.is_contiguous() and t.dtype == torch.float32
+    n, c, h, w = t.shape
+    return dsn_tensor(t.data_ptr(), DSN_F32, n, h, w, c, c)
+
+
+def bilinear_ac(x, y, out_nchw=False):
+    a = desc(x)
+    b = _desc_nchw(y) if out_nchw else desc(y)
+    _lib.check(_lib.lib().dsn_bilinear_ac(C.byref(a), C.byref(b), int(out_nchw), stream_ptr()), "bilinear_ac")
+    return y
+
+
+def bilinear_ac_bwd(dy, dx, dy_nchw=False, accumulate=False):
+    a = _desc_nchw(dy) if dy_nchw else desc(dy)
+    b = desc(dx)
+    _lib.check(_lib.lib().dsn_bilinear_ac_bwd(C.byref(a), int(dy_nchw), C.byref(b), int(accumulate), stream_ptr()),
+               "bilinear_ac_bwd")
+    return dx
+
+
+def adaptive_avgpool(x, y):
+    a, b = desc(x), desc(y)
+    _lib.check(_lib.lib().dsn_adaptive_avgpool(C.byref(a), C.byref(b), stream_ptr()), "adaptive_avgpool")
+    return y
+
+
+def adaptive_avgpool_bwd(dy, dx, accumulate=False):
+    a, b = desc(dy), desc(dx)
+    _lib.check(_lib.lib().dsn_adaptive_avgpool_bwd(C.byref(a), C.byref(b), int(accumulate), stream_ptr()),
+               "adaptive_avgpool_bwd")
+    return dx
+
+
+def copy(x, y, accumulate=False):
+    a, b = desc(x), desc(y)
+    _lib.check(_lib.lib().dsn_copy(C.byref(a), C.byref(b), int(accumulate), stream_ptr()), "copy")
+    return y
+
+
+def ffm_scale(feat, att, out):
+    a, b, c = desc(feat), desc(att), desc(out)
+    _lib.check(_lib.lib().dsn_ffm_scale(C.byref(a), C.byref(b), C.byref(c), stream_ptr()), "ffm_scale")
+    return out
+
+
+def ffm_scale_bwd(dout, feat, att, dfeat, datt, accumulate=False):
+    a, b, c, d, e = desc(dout), desc(feat), desc(att), desc(dfeat), desc(datt)
+    _lib.check(_lib.lib().dsn_ffm_scale_bwd(C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), int(accumulate),
+                                            stream_ptr()), "ffm_scale_bwd")
+    return dfeat, datt
+
+
+# ------------------------------------------------------------------------------------------------ detect / nms
+def detect_decode(t, raw, pred, row_offset, na, no, stride, anchors_px):
+    d = desc(t)
+    total = 0 if pred is None else pred.shape[1]
+    _lib.check(_lib.lib().dsn_detect_decode(C.byref(d), raw.data_ptr(), _p(pred), total, row_offset, na, no,
+                                            float(stride), _p(anchors_px), stream_ptr()), "detect_decode")
+
+
+def detect_raw_bwd(draw, dt, na, no):
+    d = desc(dt)
+    g = draw if (draw.is_contiguous() and draw.dtype == torch.float32) else draw.float().contiguous()
+    _lib.check(_lib.lib().dsn_detect_raw_bwd(g.data_ptr(), C.byref(d), na, no, stream_ptr()), "detect_raw_bwd")
+    return dt
+
+
+def nms(pred: torch.Tensor, conf_thres, iou_thres, multi_label=False, agnostic=False, classes=None, max_det=300):
+    """Returns (out [bs, max_det, 6] fp32, count [bs] int32), both on the device."""
+    _require_gpu(pred)
+    p = pred if (pred.dtype == torch.float32 and pred.is_contiguous()) else pred.float().contiguous()
+    bs, n, no = p.shape
+    nc = no - 5
+    mask = 0
+    if classes is not None:
+        for c in classes:
+            mask |= 1 << int(c)
+        if mask == 0:
+            mask = 1 << 63 if nc < 64 else 0   # empty filter keeps nothing
+    L = _lib.lib()
+    nbytes = L.dsn_nms_workspace_bytes(bs, n, nc, int(multi_label))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+    out = torch.zeros((bs, max_det, 6), dtype=torch.float32, device=p.device)
+    cnt = torch.zeros((bs,), dtype=torch.int32, device=p.device)
+    _lib.check(L.dsn_nms(p.data_ptr(), bs, n, nc, float(conf_thres), float(iou_thres), int(multi_label), int(agnostic),
+                         mask, max_det, out.data_ptr(), cnt.data_ptr(), ws.data_ptr(), nbytes, stream_ptr()), "nms")
+    return out, cnt
+
+
+def cast(src: torch.Tensor, dtype) -> torch.Tensor:
+    s = src.detach()
+    if s.dtype != torch.float32 or not s.is_contiguous():
+        s = s.float().contiguous()
+    out = torch.empty(s.shape, dtype=dtype, device=s.device)
+    _lib.check(_lib.lib().dsn_cast(s.data_ptr(), out.data_ptr(), _DT[dtype], s.numel(), stream_ptr()), "cast")
+    return out

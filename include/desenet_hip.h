@@ -1,0 +1,174 @@
+/*
+ * desenet_hip.h -- C ABI of libdesenet_hip.so: the MI355X (gfx950) kernels behind DeSeNet's CNN hot path.
+ *
+ * The reference (splwany/DeSeNet) has NO native/FFI layer: its hot path is Python nn.Module code that reaches
+ * ATen kernels.  The drop-in boundary is therefore the module surface core.models.common / core.models.yolo
+ * (mirrored in desenet_amd/core/models/), and THIS header is what those mirrored modules bind (ctypes,
+ * desenet_amd/_lib.py).  Each entry point cites the reference statement(s) it replaces; paths are relative
+ * to the reference repository root.
+ *
+ * Conventions
+ *  - Activations are NHWC ("channels last") views: element (n,h,w,c) lives at ptr[((n*H + h)*W + w)*ldc + c],
+ *    ldc >= C.  ldc > C addresses a channel slice of a wider buffer: producers write straight into concat
+ *    buffers (torch.cat of common.py:145,185,545,615,693 and yolo.py:195 never materialises a copy).
+ *  - dtype: DSN_F32 (config 2, fp32 inference) or DSN_BF16 (configs 3-5, bf16 storage, fp32 accumulate).
+ *    Per-channel vectors (bias, BN scale/shift/statistics, gradients of weights) are always fp32.
+ *  - Weights are passed PACKED: conv fwd  [Co][KH][KW][Ci]  (dsn_pack_weight_fwd),
+ *                               conv dgrad [Ci][KH][KW][Co] (dsn_pack_weight_dgrad).
+ *  - Ownership: the caller (PyTorch caching allocator) owns every buffer; the library allocates nothing,
+ *    retains no pointer after return, and needs workspaces to be passed in (sizes from dsn_*_workspace_bytes).
+ *  - Streams: every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no hidden sync.
+ *  - Errors: 0 = success; < 0 = dsn_status (bad argument / unsupported shape); > 0 = hipError_t.  The message
+ *    of the last failure on the calling thread is returned by dsn_last_error().  Nothing aborts.
+ */
+#ifndef DESENET_HIP_H
+#define DESENET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSN_VERSION 100 /* 0.1.0 */
+
+enum { DSN_F32 = 0, DSN_BF16 = 1 };
+enum { DSN_OK = 0, DSN_EINVAL = -1, DSN_EUNSUPPORTED = -2, DSN_EWORKSPACE = -3 };
+enum { DSN_ACT_NONE = 0, DSN_ACT_SILU = 1, DSN_ACT_SIGMOID = 2 };
+
+typedef struct {
+    void*   ptr;
+    int32_t dtype;
+    int32_t n, h, w, c;
+    int64_t ldc;
+} dsn_tensor;
+
+typedef struct {
+    int32_t kh, kw;      /* kernel size                                   */
+    int32_t stride;      /* same in both directions                       */
+    int32_t pad;         /* autopad k//2 (common.py:32-39) or explicit    */
+    int32_t dil;         /* dilation (RFB2 branch1/2: 2, 3)               */
+    int32_t act;         /* DSN_ACT_* applied after bias                  */
+    int32_t accumulate;  /* 1: out += result (gradient fan-in)            */
+} dsn_conv_params;
+
+int         dsn_version(void);
+const char* dsn_last_error(void);
+
+/* ---- convolution (implicit GEMM on MFMA) -------------------------------------------------------------------
+ * dsn_conv2d_fwd: y = act(conv(x, w) + bias) + residual
+ *   replaces nn.Conv2d + folded BN + nn.SiLU of Conv.forward_fuse (common.py:55-56), the Bottleneck shortcut add
+ *   (common.py:111), the raw Conv2d of RFB2 (common.py:515-524), FFM's attention 1x1s (+SiLU / Sigmoid,
+ *   common.py:227-233), Detect.m[i] (yolo.py:258) and SegMaskPSP's classifier (yolo.py:182).
+ *   In training it produces the pre-BN conv output (bias = NULL, act = NONE).
+ *   bias, residual may be NULL.  w_packed: [Co][KH][KW][Ci], same dtype as x.
+ * dsn_conv2d_dgrad: dx (+)= conv_transpose(dy, w)   -- autograd of the above w.r.t. x (ATen convolution_backward)
+ *   w_packed: [Ci][KH][KW][Co].  p describes the FORWARD conv.
+ * dsn_conv2d_wgrad: dw[Co][KH][KW][ci_pad] (fp32, packed-fwd layout) (+)= sum_pixels dy (x) x
+ *   split-K over pixels with fp32 slabs in `workspace` (dsn_conv2d_wgrad_workspace_bytes), reduced in a fixed order.
+ *   The ci_pad - Ci padding lanes of dw are never written (allocate dw zero-filled).
+ */
+int dsn_conv2d_fwd(const dsn_tensor* x, const void* w_packed, const float* bias, const dsn_tensor* residual,
+                   const dsn_tensor* y, const dsn_conv_params* p, void* stream);
+int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w_packed, const dsn_tensor* dx, const dsn_conv_params* p,
+                     void* stream);
+int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p,
+                                         int32_t ci_pad);
+int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, const dsn_conv_params* p,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* weight packing: OIHW fp32 master weights (the state_dict layout, `...conv.weight [c2,c1,k,k]`) -> kernel layouts.
+ * ci_pad >= ci zero-pads the input-channel axis (Focus: 12 -> 16 for 16-byte bf16 loads).
+ * scale (may be NULL) multiplies output channel co: BN folding W' = diag(g/sqrt(var+eps)) W (torch_utils.py:196-216). */
+int dsn_pack_weight_fwd(const float* w_oihw, const float* scale, void* out, int32_t dtype, int32_t co, int32_t ci,
+                        int32_t kh, int32_t kw, int32_t ci_pad, void* stream);
+int dsn_pack_weight_dgrad(const float* w_oihw, void* out, int32_t dtype, int32_t co, int32_t ci, int32_t kh,
+                          int32_t kw, void* stream);
+/* dw (packed [Co][KH][KW][Ci_pad] fp32) -> OIHW fp32 gradient, grad (+)= dw */
+int dsn_unpack_wgrad(const float* dw_packed, float* grad_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
+                     int32_t ci_pad, int32_t accumulate, void* stream);
+
+/* ---- BatchNorm (training) + activation ------------------------------------------------------------------------
+ * replaces nn.BatchNorm2d in training mode + nn.SiLU inside Conv.forward (common.py:49-53), eps/momentum as set by
+ * initialize_weights (torch_utils.py:164-165).
+ * dsn_bn_stats: per-channel batch mean / biased variance of y; writes scale = g*rstd, shift = b - mean*scale,
+ *   mean, rstd; updates running_mean/var in place ((1-m)*old + m*(mean, unbiased var)).
+ *   workspace: dsn_bn_workspace_bytes(c) bytes.
+ * dsn_bn_act_fwd:  z = act(y*scale + shift) + residual      (also the eval path of un-fused BN: RFB2 quirk Q3)
+ * dsn_bn_act_bwd:  given dz, y: dy = BN/act backward, dgamma/dbeta (+)=, optional dres (+)= dz (shortcut)
+ */
+int64_t dsn_bn_workspace_bytes(int32_t c);
+int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float* beta, float* running_mean,
+                 float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                 float* rstd, void* workspace, int64_t workspace_bytes, void* stream);
+int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const float* shift, int32_t act,
+                   const dsn_tensor* residual, const dsn_tensor* z, void* stream);
+int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                   const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
+                   float* dbeta, int32_t accumulate_param_grads, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+/* act backward without BN (conv -> act, quirk Q1 path and FFM attention): dy = dz * act'(y) */
+int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const dsn_tensor* dy, void* stream);
+
+/* ---- data-movement / pooling / resampling ---------------------------------------------------------------------
+ * dsn_focus_s2d: Focus slicing + cat (common.py:626): NCHW fp32 image -> NHWC [N,H/2,W/2,c_pad], channel
+ *   g*C + c for g = 0..3 = (row,col) parity (0,0),(1,0),(0,1),(1,1); channels >= 4C are zero.  Bit-exact copy.
+ * dsn_maxpool_s1: stride-1 max pool, -inf padding (SPP, common.py:177,185); idx (int32, may be NULL in eval) gets
+ *   the flat input pixel index of the arg-max (first maximum in row-major window order, as ATen).
+ * dsn_upsample_nearest2x: nn.Upsample(None, 2, 'nearest') (yolov5s_seg.yaml:31,36).
+ * dsn_bilinear_ac: bilinear, align_corners=True (yolo.py:170,174,183; common.py:610-613); src = dst*(in-1)/(out-1).
+ *   out_nchw != 0 writes y as contiguous NCHW fp32 (the seg logits the caller sees, yolo.py:183).
+ * dsn_adaptive_avgpool: nn.AdaptiveAvgPool2d(k) (common.py:226,597-600): bin i = [floor(i*H/k), ceil((i+1)*H/k)).
+ * dsn_copy: strided NHWC copy / add (generic Concat fallback, gradient fan-in).
+ */
+int dsn_focus_s2d(const float* x_nchw, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
+                  void* stream);
+int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream);
+int dsn_maxpool_s1_bwd(const dsn_tensor* dy, const int32_t* idx, const dsn_tensor* dx, int32_t k,
+                       int32_t accumulate, void* stream);
+int dsn_upsample_nearest2x(const dsn_tensor* x, const dsn_tensor* y, void* stream);
+int dsn_upsample_nearest2x_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream);
+int dsn_bilinear_ac(const dsn_tensor* x, const dsn_tensor* y, int32_t out_nchw, void* stream);
+int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const dsn_tensor* dx, int32_t accumulate,
+                        void* stream);
+int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* stream);
+int dsn_adaptive_avgpool_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream);
+int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumulate, void* stream);
+
+/* ---- FFM channel attention (common.py:236-242): out = feat*att + feat, att: [N,1,1,C] ------------------------ */
+int dsn_ffm_scale(const dsn_tensor* feat, const dsn_tensor* att, const dsn_tensor* out, void* stream);
+/* dfeat (+)= dout*(1+att);  datt[n,c] = sum_hw dout*feat */
+int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat, const dsn_tensor* att,
+                      const dsn_tensor* dfeat, const dsn_tensor* datt, int32_t accumulate, void* stream);
+
+/* ---- Detect head (yolo.py:255-277) ------------------------------------------------------------------------------
+ * t: conv output of level i, NHWC [N,ny,nx,na*no].  raw: contiguous fp32 [N,na,ny,nx,no] (the training output and
+ * second eval output).  pred (may be NULL in training): fp32 [N, total, no] rows [row_offset, row_offset+na*ny*nx):
+ * sigmoid; xy = (2s - .5 + grid)*stride with grid[...,0]=x, [...,1]=y (yolo.py:279-282); wh = (2s)^2*anchor_px.
+ * dsn_detect_raw_bwd: d(conv output) from d(raw) (the permute's transpose).
+ */
+int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, int64_t pred_total_rows, int64_t row_offset,
+                      int32_t na, int32_t no, float stride, const float* anchors_px /* [na][2] device */,
+                      void* stream);
+int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, void* stream);
+
+/* ---- NMS (general.py:659-750 + torchvision.ops.nms) ------------------------------------------------------------
+ * pred: fp32 [bs, n, 5+nc].  For every image: candidate filter (obj > conf), conf = obj*cls, best-class or
+ * multi-label expansion, optional class filter, cap at 30000 by descending conf, class-offset boxes (4096*cls unless
+ * agnostic), greedy suppression (IoU > iou_thres, stable descending-score order), first max_det.
+ * out: fp32 [bs, max_det, 6] rows [x1,y1,x2,y2,conf,cls]; out_count: int32 [bs].
+ * classes_mask: bit c set = keep class c (0 = keep all).  workspace from dsn_nms_workspace_bytes.
+ */
+int64_t dsn_nms_workspace_bytes(int32_t bs, int32_t n, int32_t nc, int32_t multi_label);
+int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, float conf_thres, float iou_thres,
+            int32_t multi_label, int32_t agnostic, uint64_t classes_mask, int32_t max_det, float* out,
+            int32_t* out_count, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------------------------------- */
+/* dst[i] = (dtype) src[i]  (flat fp32 master -> bf16 copy) */
+int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESENET_HIP_H */

@@ -1,0 +1,377 @@
+"""Kernel-level parity: every C-ABI entry point (through desenet_amd.hip_ops) against stock PyTorch-CPU fp32 ops --
+the same ops the oracle is made of.  Tolerances: fp32 1e-3 relative (BASELINE.json), bf16 2e-2 (8-bit mantissa inputs,
+fp32 accumulate; compared with an fp32 reference computed from the SAME bf16-rounded inputs where noted)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from desenet_amd import hip_ops
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_ops
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return lo + (hi - lo) * torch.rand(shape, generator=g)
+
+
+def to_dev(ops, x, dtype):
+    """CPU NCHW fp32 -> device NHWC-backed logical-NCHW tensor of `dtype`."""
+    n, c, h, w = x.shape
+    t = ops.new_act(n, c, h, w, dtype, "cuda")
+    t.copy_(x)
+    return t
+
+
+def q(x, dtype):
+    """What the device actually sees: x rounded to dtype, as fp32."""
+    return x.to(dtype).float()
+
+
+CONV_CASES = [
+    # n, ci, h, w, co, k, s, pad, dil
+    (2, 16, 9, 7, 24, 1, 1, 0, 1),
+    (2, 8, 10, 6, 16, 3, 1, 1, 1),
+    (2, 8, 11, 7, 16, 3, 2, 1, 1),
+    (1, 32, 20, 20, 32, 3, 1, 2, 2),
+    (1, 16, 13, 17, 8, 3, 1, 3, 3),
+    (2, 64, 16, 16, 128, 1, 1, 0, 1),
+    (1, 128, 24, 24, 256, 3, 1, 1, 1),
+    (2, 256, 8, 8, 33, 1, 1, 0, 1),
+    (1, 128, 40, 40, 2, 1, 1, 0, 1),
+    (1, 12, 16, 16, 32, 3, 1, 1, 1),     # Focus conv (Ci = 12)
+    (3, 40, 5, 5, 72, 3, 2, 1, 1),
+    (1, 64, 80, 80, 64, 3, 1, 1, 1),
+    (4, 128, 1, 1, 128, 1, 1, 0, 1),     # FFM attention / 1x1 maps
+    (1, 6, 7, 5, 10, 3, 1, 1, 1),        # scalar-load path (Ci % 4 != 0)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(ops, case, dtype):
+    n, ci, h, w, co, k, s, pad, dil = case
+    x, wt, b = rnd((n, ci, h, w), 1), rnd((co, ci, k, k), 2, -0.3, 0.3), rnd((co,), 3)
+    ref = F.silu(F.conv2d(q(x, dtype), q(wt, dtype), b, s, pad, dil))
+    ho, wo = ref.shape[2:]
+    res = rnd((n, co, ho, wo), 4)
+    ref = ref + q(res, dtype)
+    xd, rd = to_dev(ops, x, dtype), to_dev(ops, res, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, ho, wo, dtype, "cuda")
+    ops.conv2d_fwd(xd, wp, b.cuda(), rd, y, ops.conv_params(k, s, pad, dil, act=ops.ACT_SILU))
+    assert_close(y.float().cpu(), ref, TOL[dtype], f"conv {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fwd_slices_and_accumulate(ops, dtype):
+    """Reads a channel slice of a wider buffer, writes into a slice of a concat buffer, then accumulates on top."""
+    n, ci, h, w, co = 2, 16, 12, 10, 24
+    big_in = rnd((n, 48, h, w), 5)
+    wt = rnd((co, ci, 3, 3), 6, -0.3, 0.3)
+    xin = to_dev(ops, big_in, dtype)
+    ref = F.conv2d(q(big_in[:, 16:32], dtype), q(wt, dtype), None, 1, 1)
+    cat = ops.new_act(n, 64, h, w, dtype, "cuda", zero=True)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    ops.conv2d_fwd(xin[:, 16:32], wp, None, None, cat[:, 8:32], ops.conv_params(3))
+    assert_close(cat[:, 8:32].float().cpu(), ref, TOL[dtype], "slice write")
+    assert float(cat[:, :8].abs().max()) == 0 and float(cat[:, 32:].abs().max()) == 0, "wrote outside the slice"
+    ops.conv2d_fwd(xin[:, 16:32], wp, None, None, cat[:, 8:32], ops.conv_params(3, accumulate=True))
+    assert_close(cat[:, 8:32].float().cpu(), 2 * ref, 2 * TOL[dtype], "accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_wgrad(ops, case, dtype):
+    n, ci, h, w, co, k, s, pad, dil = case
+    x = rnd((n, ci, h, w), 7).requires_grad_(True)
+    wt = rnd((co, ci, k, k), 8, -0.3, 0.3).requires_grad_(True)
+    xq, wq = q(x.detach(), dtype).requires_grad_(True), q(wt.detach(), dtype).requires_grad_(True)
+    y = F.conv2d(xq, wq, None, s, pad, dil)
+    gy = rnd(tuple(y.shape), 9)
+    y.backward(q(gy, dtype))
+    gd = to_dev(ops, gy, dtype)
+    p = ops.conv_params(k, s, pad, dil)
+    dx = ops.new_act(n, ci, h, w, dtype, "cuda")
+    ops.conv2d_dgrad(gd, ops.pack_weight_dgrad(wt.detach().cuda(), dtype), dx, p)
+    assert_close(dx.float().cpu(), xq.grad, TOL[dtype], f"dgrad {case}")
+    dwp = torch.zeros((co, k, k, ci), dtype=torch.float32, device="cuda")
+    ops.conv2d_wgrad(to_dev(ops, x.detach(), dtype), gd, dwp, ci, p)
+    dw = ops.unpack_wgrad(dwp, (co, ci, k, k), ci)
+    assert_close(dw.cpu(), wq.grad, TOL[dtype], f"wgrad {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_large_reduction_and_padding(ops, dtype):
+    """Split-K path (many pixel ranges) and a padded input-channel axis (Focus: 12 -> 16)."""
+    n, ci, h, w, co = 4, 12, 64, 64, 32
+    x, gy = rnd((n, ci, h, w), 10), rnd((n, co, h, w), 11)
+    wq = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(q(x, dtype), wq, None, 1, 1).backward(q(gy, dtype))
+    xpad = torch.cat([x, torch.zeros(n, 4, h, w)], 1)
+    dwp = torch.zeros((co, 3, 3, 16), dtype=torch.float32, device="cuda")
+    ops.conv2d_wgrad(to_dev(ops, xpad, dtype), to_dev(ops, gy, dtype), dwp, 16, ops.conv_params(3))
+    dw = ops.unpack_wgrad(dwp, (co, ci, 3, 3), 16)
+    assert_close(dw.cpu(), wq.grad, TOL[dtype], "wgrad split-K")
+    assert float(dwp[..., 12:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_weights(ops, dtype):
+    wt, sc = rnd((24, 12, 3, 3), 12), rnd((24,), 13, 0.5, 1.5)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype, sc.cuda(), ci_pad=16)
+    ref = torch.zeros(24, 3, 3, 16)
+    ref[..., :12] = (wt * sc.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
+    assert_close(wp.float().cpu(), ref, 1e-6 if dtype == torch.float32 else 8e-3)
+    wd = ops.pack_weight_dgrad(wt.cuda(), dtype)
+    assert_close(wd.float().cpu(), q(wt, dtype).permute(1, 2, 3, 0), 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 24, 9, 7), (4, 64, 40, 40), (1, 6, 5, 5), (2, 512, 20, 20), (8, 32, 160, 160)])
+def test_bn_train_fwd_bwd(ops, shape, dtype):
+    """BatchNorm2d(train, eps 1e-3, momentum .03) + SiLU (+ shortcut), forward and backward, vs ATen."""
+    n, c, h, w = shape
+    y = rnd(shape, 14, -2, 2)
+    yq = q(y, dtype).requires_grad_(True)
+    gamma, beta = rnd((c,), 15, 0.5, 1.5).requires_grad_(True), rnd((c,), 16, -0.1, 0.1).requires_grad_(True)
+    rm, rv = rnd((c,), 17, -0.1, 0.1), rnd((c,), 18, 0.5, 1.5)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    res = rnd(shape, 19)
+    z_ref = F.silu(F.batch_norm(yq, rm_ref, rv_ref, gamma, beta, True, 0.03, 1e-3)) + q(res, dtype)
+    gz = rnd(shape, 20)
+    z_ref.backward(q(gz, dtype))
+
+    yd = to_dev(ops, y, dtype)
+    rmd, rvd = rm.cuda(), rv.cuda()
+    scale, shift, mean, rstd = ops.bn_stats(yd, gamma.detach().cuda(), beta.detach().cuda(), rmd, rvd, 0.03, 1e-3)
+    assert_close(rmd.cpu(), rm_ref, 1e-4, "running_mean")
+    assert_close(rvd.cpu(), rv_ref, 1e-4, "running_var")
+    z = ops.new_act(n, c, h, w, dtype, "cuda")
+    ops.bn_act_fwd(yd, scale, shift, ops.ACT_SILU, to_dev(ops, res, dtype), z)
+    assert_close(z.float().cpu(), z_ref.detach(), TOL[dtype], "bn_act_fwd")
+    dy = ops.new_act(n, c, h, w, dtype, "cuda")
+    dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    ops.bn_act_bwd(to_dev(ops, gz, dtype), yd, scale, shift, mean, rstd, ops.ACT_SILU, dy, dg, db)
+    assert_close(dy.float().cpu(), yq.grad, 3 * TOL[dtype], "bn_act_bwd dy")
+    assert_close(dg.cpu(), gamma.grad, 2 * TOL[dtype], "dgamma")
+    assert_close(db.cpu(), beta.grad, 2 * TOL[dtype], "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_act_bwd_and_eval_affine(ops, dtype):
+    y, gz = rnd((2, 16, 5, 7), 21, -3, 3), rnd((2, 16, 5, 7), 22)
+    yq = q(y, dtype).requires_grad_(True)
+    F.silu(yq).backward(q(gz, dtype))
+    dy = ops.new_act(2, 16, 5, 7, dtype, "cuda")
+    ops.act_bwd(to_dev(ops, gz, dtype), to_dev(ops, y, dtype), ops.ACT_SILU, dy)
+    assert_close(dy.float().cpu(), yq.grad, TOL[dtype], "silu bwd")
+    sc, sh = rnd((16,), 23, 0.5, 1.5), rnd((16,), 24)
+    z = ops.new_act(2, 16, 5, 7, dtype, "cuda")
+    ops.bn_act_fwd(to_dev(ops, y, dtype), sc.cuda(), sh.cuda(), ops.ACT_SIGMOID, None, z)
+    ref = torch.sigmoid(q(y, dtype) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert_close(z.float().cpu(), ref, TOL[dtype], "affine+sigmoid")
+
+
+def test_focus_s2d_bit_exact(ops):
+    g = golden("modules")
+    x = torch.from_numpy(g["focus_s2d/x0"])
+    y = ops.new_act(1, 12, 4, 6, torch.float32, "cuda")
+    ops.focus_s2d(x.cuda(), y)
+    assert np.array_equal(y.cpu().numpy(), g["focus_s2d/y0"])
+    y16 = ops.new_act(1, 16, 4, 6, torch.bfloat16, "cuda")
+    ops.focus_s2d(x.cuda(), y16)
+    assert np.array_equal(y16[:, :12].float().cpu().numpy(), torch.from_numpy(g["focus_s2d/y0"]).bfloat16().float().numpy())
+    assert float(y16[:, 12:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [5, 9, 13])
+def test_maxpool(ops, k, dtype):
+    x = rnd((2, 16, 15, 11), 25)
+    xq = q(x, dtype).requires_grad_(True)
+    ref = F.max_pool2d(xq, k, 1, k // 2)
+    gy = rnd(tuple(ref.shape), 26)
+    ref.backward(q(gy, dtype))
+    xd = to_dev(ops, x, dtype)
+    y = ops.new_act(2, 16, 15, 11, dtype, "cuda")
+    idx = torch.empty((2, 15, 11, 16), dtype=torch.int32, device="cuda")
+    ops.maxpool_s1(xd, y, k, idx)
+    assert torch.equal(y.float().cpu(), ref.detach()), "max pool values are exact"
+    if dtype == torch.float32:   # bf16 inputs tie often; ATen's tie rule is checked on the tie-free fp32 data
+        dx = ops.new_act(2, 16, 15, 11, dtype, "cuda")
+        ops.maxpool_s1_bwd(to_dev(ops, gy, dtype), idx, dx, k)
+        assert_close(dx.float().cpu(), xq.grad, 1e-5, "maxpool bwd")
+
+
+def test_maxpool_ties_first_max(ops):
+    x = torch.zeros(1, 4, 6, 6)
+    xq = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xq, 5, 1, 2)
+    ref.backward(torch.ones_like(ref))
+    y = ops.new_act(1, 4, 6, 6, torch.float32, "cuda")
+    idx = torch.empty((1, 6, 6, 4), dtype=torch.int32, device="cuda")
+    ops.maxpool_s1(to_dev(ops, x, torch.float32), y, 5, idx)
+    dx = ops.new_act(1, 4, 6, 6, torch.float32, "cuda")
+    ops.maxpool_s1_bwd(to_dev(ops, torch.ones(1, 4, 6, 6), torch.float32), idx, dx, 5)
+    assert torch.equal(dx.cpu(), xq.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_upsample_nearest(ops, dtype):
+    g = golden("modules")
+    a, b = torch.from_numpy(g["upcat_train/x0"]), torch.from_numpy(g["upcat_train/x1"])
+    cat = ops.new_act(2, 12, 10, 14, dtype, "cuda")
+    ops.upsample_nearest2x(to_dev(ops, a, dtype), cat[:, :8])
+    ops.copy(to_dev(ops, b, dtype), cat[:, 8:])
+    assert torch.equal(cat.float().cpu(), q(torch.from_numpy(g["upcat_train/y0"]), dtype))
+    gy = torch.from_numpy(g["upcat_train/gy0"])
+    gd = to_dev(ops, gy, dtype)
+    dx = ops.new_act(2, 8, 5, 7, dtype, "cuda")
+    ops.upsample_nearest2x_bwd(gd[:, :8], dx)
+    ref = F.avg_pool2d(q(gy[:, :8], dtype), 2) * 4
+    assert_close(dx.float().cpu(), ref, TOL[dtype], "nearest bwd")
+    if dtype == torch.float32:
+        assert_close(dx.cpu(), g["upcat_train/dx0"], 1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [((2, 8, 5, 7), (10, 14)), ((1, 16, 1, 1), (9, 9)), ((2, 4, 6, 6), (20, 14)),
+                                  ((1, 2, 16, 12), (128, 96)), ((2, 8, 3, 2), (12, 8))])
+def test_bilinear_align_corners(ops, case, dtype):
+    shape, out = case
+    x = rnd(shape, 27)
+    xq = q(x, dtype).requires_grad_(True)
+    ref = F.interpolate(xq, out, mode="bilinear", align_corners=True)
+    gy = rnd(tuple(ref.shape), 28)
+    ref.backward(q(gy, dtype) if dtype != torch.float32 else gy)
+    xd = to_dev(ops, x, dtype)
+    y = ops.new_act(shape[0], shape[1], out[0], out[1], dtype, "cuda")
+    ops.bilinear_ac(xd, y)
+    assert_close(y.float().cpu(), ref.detach(), TOL[dtype], "bilinear fwd")
+    yn = torch.empty((shape[0], shape[1], out[0], out[1]), device="cuda")
+    ops.bilinear_ac(xd, yn, out_nchw=True)
+    assert yn.is_contiguous()
+    assert_close(yn.cpu(), ref.detach(), 1e-5, "bilinear fwd NCHW fp32 out")
+    dx = ops.new_act(*shape, dtype, "cuda")
+    ops.bilinear_ac_bwd(to_dev(ops, gy, dtype), dx)
+    assert_close(dx.float().cpu(), xq.grad, TOL[dtype], "bilinear bwd")
+    dx2 = ops.new_act(*shape, dtype, "cuda")
+    ops.bilinear_ac_bwd((q(gy, dtype) if dtype != torch.float32 else gy).cuda().contiguous(), dx2, dy_nchw=True)
+    assert_close(dx2.float().cpu(), xq.grad, TOL[dtype], "bilinear bwd from NCHW dy")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [1, 2, 3, 6])
+def test_adaptive_avgpool(ops, k, dtype):
+    x = rnd((2, 16, 20, 14), 29)
+    xq = q(x, dtype).requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xq, k)
+    gy = rnd(tuple(ref.shape), 30)
+    ref.backward(q(gy, dtype))
+    y = ops.new_act(2, 16, k, k, dtype, "cuda")
+    ops.adaptive_avgpool(to_dev(ops, x, dtype), y)
+    assert_close(y.float().cpu(), ref.detach(), TOL[dtype], "adaptive pool")
+    dx = ops.new_act(2, 16, 20, 14, dtype, "cuda")
+    ops.adaptive_avgpool_bwd(to_dev(ops, gy, dtype), dx)
+    assert_close(dx.float().cpu(), xq.grad, TOL[dtype], "adaptive pool bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ffm_scale(ops, dtype):
+    f, a = rnd((2, 16, 8, 6), 31), rnd((2, 16, 1, 1), 32, 0, 1)
+    fq, aq = q(f, dtype).requires_grad_(True), q(a, dtype).requires_grad_(True)
+    ref = fq * aq + fq
+    g = rnd((2, 16, 8, 6), 33)
+    ref.backward(q(g, dtype))
+    fd, ad = to_dev(ops, f, dtype), to_dev(ops, a, dtype)
+    out = ops.new_act(2, 16, 8, 6, dtype, "cuda")
+    ops.ffm_scale(fd, ad, out)
+    assert_close(out.float().cpu(), ref.detach(), TOL[dtype], "ffm_scale")
+    df, da = ops.new_act(2, 16, 8, 6, dtype, "cuda"), ops.new_act(2, 16, 1, 1, dtype, "cuda")
+    ops.ffm_scale_bwd(to_dev(ops, g, dtype), fd, ad, df, da)
+    assert_close(df.float().cpu(), fq.grad, TOL[dtype], "ffm dfeat")
+    assert_close(da.float().cpu(), aq.grad, TOL[dtype], "ffm datt")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detect_decode(ops, dtype):
+    """Detect eval branch (yolo.py:262-275) incl. grid[...,0]=x / [...,1]=y indexing and pixel anchors, vs the oracle."""
+    from oracle import desenet_ref as R
+    na, no, ny, nx, n = 3, 11, 6, 9, 2
+    t = rnd((n, na * no, ny, nx), 34, -3, 3)
+    anchors = torch.tensor([[10., 13.], [16., 30.], [33., 23.]])
+    tq = q(t, dtype)
+    y = tq.view(n, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+    s = y.sigmoid()
+    xy = (s[..., 0:2] * 2.0 - 0.5 + R.make_grid(nx, ny)) * 8.0
+    wh = (s[..., 2:4] * 2) ** 2 * anchors.view(1, na, 1, 1, 2)
+    ref = torch.cat((xy, wh, s[..., 4:]), -1).view(n, -1, no)
+    raw = torch.empty((n, na, ny, nx, no), device="cuda")
+    pred = torch.zeros((n, na * ny * nx + 5, no), device="cuda")
+    ops.detect_decode(to_dev(ops, t, dtype), raw, pred, 5, na, no, 8.0, anchors.cuda())
+    assert torch.equal(raw.cpu(), y), "raw is a pure permutation"
+    assert_close(pred[:, 5:].cpu(), ref, 1e-5, "decode")
+    assert float(pred[:, :5].abs().max()) == 0
+    dt = ops.new_act(n, na * no, ny, nx, dtype, "cuda")
+    ops.detect_raw_bwd(raw, dt, na, no)
+    assert torch.equal(dt.float().cpu(), tq)
+
+
+NMS_CASES = ["default", "val_multilabel", "agnostic", "classes", "ties", "maxdet", "empty", "over30000", "iou_edge"]
+
+
+@pytest.mark.parametrize("case", NMS_CASES)
+def test_nms_bit_exact_vs_golden(ops, case):
+    """Selection AND values bit-exact against the reference's non_max_suppression (greedy step = published algorithm)."""
+    import ast
+    g = golden("nms")
+    kw = ast.literal_eval(str(g[f"{case}/kw"]))
+    pred = torch.from_numpy(g[f"{case}/pred"]).cuda()
+    out, cnt = ops.nms(pred, kw["conf_thres"], kw["iou_thres"], kw.get("multi_label", False), kw.get("agnostic", False),
+                       kw.get("classes"), kw["max_det"])
+    cnt = cnt.cpu().tolist()
+    assert cnt == [int(v) for v in g[f"{case}/n"]]
+    for i, c in enumerate(cnt):
+        np.testing.assert_array_equal(out[i, :c].cpu().numpy(), g[f"{case}/out{i}"])
+
+
+def test_nms_vs_oracle_random_large(ops):
+    """25200 x 6 candidates at the val setting (conf .001, multi-label): exercises the >8192-key sort and the 30000 cap."""
+    from oracle import nms_ref
+    rng = np.random.RandomState(0)
+    p = np.zeros((2, 25200, 11), np.float32)
+    p[..., 0:2] = rng.uniform(0, 640, (2, 25200, 2))
+    p[..., 2:4] = rng.uniform(4, 200, (2, 25200, 2))
+    p[..., 4:] = rng.uniform(0, 1, (2, 25200, 7))
+    ref = nms_ref.non_max_suppression(p, 0.001, 0.6, multi_label=True, max_det=300)
+    out, cnt = ops.nms(torch.from_numpy(p).cuda(), 0.001, 0.6, multi_label=True, max_det=300)
+    for i, r in enumerate(ref):
+        assert int(cnt[i]) == r.shape[0]
+        np.testing.assert_array_equal(out[i, :r.shape[0]].cpu().numpy(), r)
+    ref = nms_ref.non_max_suppression(p, 0.25, 0.45, max_det=1000)
+    out, cnt = ops.nms(torch.from_numpy(p).cuda(), 0.25, 0.45, max_det=1000)
+    for i, r in enumerate(ref):
+        assert int(cnt[i]) == r.shape[0]
+        np.testing.assert_array_equal(out[i, :r.shape[0]].cpu().numpy(), r)
+
+
+def test_errors_are_reported_not_fatal(ops):
+    x = ops.new_act(1, 8, 4, 4, torch.float32, "cuda")
+    y = ops.new_act(1, 8, 5, 5, torch.float32, "cuda")
+    w = torch.zeros(8, 3, 3, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="expected 4x4"):
+        ops.conv2d_fwd(x, w, None, None, y, ops.conv_params(3))
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops.desc(torch.zeros(1, 8, 4, 4))
