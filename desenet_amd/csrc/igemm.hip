@@ -38,10 +38,13 @@ template <> struct Mma<float> {
     static constexpr int KC = 16;   // elements per 64-byte chunk
     static constexpr int VEC = 4;   // elements per 16-byte vector
     __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[s]), __builtin_bit_cast(float, b[s]),
-                                                       acc, 0, 0, 0);
+        // bit-cast the whole vector first: indexing the u32 vector inside __builtin_bit_cast(float, a[s]) made hipcc
+        // (ROCm 7.2) feed element 0 to all four MFMAs.
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
     }
 };
 template <> struct Mma<bf16_t> {
