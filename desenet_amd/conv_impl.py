@@ -1,0 +1,177 @@
+"""Conv2d (+BatchNorm2d) (+activation) block on the HIP kernels: the work-horse behind Conv, the raw Conv2d+BN+SiLU triples
+of RFB2, FFM's attention 1x1s, Detect.m and the seg classifier.
+
+Numerical contract (what the reference computes):
+  eval  : act(conv(x, W) * g/sqrt(var+eps) + (b - mean*g/sqrt(var+eps)))  -- ONE launch: the BN affine is folded into the
+          packed weights + epilogue bias (identical math for a fused and an un-fused model; torch_utils.py:196-216).
+  Q1    : an un-fused `Conv` on a 1x1 map skips BN altogether (common.py:53) -- `q1=True` -- while a fused one applies it.
+  train : y = conv(x, W) ; batch statistics (eps 1e-3, momentum .03; torch_utils.py:164-165) ; z = act(BN(y)) [+ shortcut]
+          backward: dy from (dz, y) ; dW = wgrad(x, dy) ; dx = dgrad(dy, W).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops as ops
+from .hip_ops import ACT_NONE, ACT_SIGMOID, ACT_SILU
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03
+
+
+def act_code(act) -> int:
+    if act is None or isinstance(act, nn.Identity):
+        return ACT_NONE
+    if isinstance(act, nn.SiLU):
+        return ACT_SILU
+    if isinstance(act, nn.Sigmoid):
+        return ACT_SIGMOID
+    raise NotImplementedError(f"activation {type(act).__name__} has no HIP epilogue (SiLU, Sigmoid, Identity only)")
+
+
+def _conv_geom(conv: nn.Conv2d):
+    k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    if conv.groups != 1 or k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or d[0] != d[1] or conv.padding_mode != "zeros":
+        raise NotImplementedError("HIP conv supports square kernels, groups=1, zero padding (all DeSeNet-s convs)")
+    return k[0], s[0], p[0], d[0]
+
+
+def _ver(*ts):
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+
+
+def _cache(conv):
+    c = conv.__dict__.get("_dsn_cache")
+    if c is None:
+        c = conv.__dict__["_dsn_cache"] = {}
+    return c
+
+
+def packed_fwd(conv: nn.Conv2d, dtype, ci_pad: Optional[int] = None, bn: Optional[nn.BatchNorm2d] = None):
+    """(w_packed [Co][KH][KW][ci_pad], bias fp32 [Co] | None); BN running stats folded in when `bn` is given (eval)."""
+    key = ("fwd", dtype, ci_pad, bn is not None)
+    ver = _ver(conv.weight, conv.bias, *((bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else ()))
+    hit = _cache(conv).get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    scale = bias = None
+    if bn is not None:   # host-side per-channel vectors (computed once per weight version)
+        g = bn.weight if bn.weight is not None else torch.ones_like(bn.running_var)
+        b = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_var)
+        scale = (g.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)).contiguous()
+        bias = b.detach().float() - bn.running_mean.float() * scale
+        if conv.bias is not None:
+            bias = bias + conv.bias.detach().float() * scale
+        bias = bias.contiguous()
+    elif conv.bias is not None:
+        bias = conv.bias.detach().float().contiguous()
+    w = ops.pack_weight_fwd(conv.weight, dtype, scale, ci_pad)
+    _cache(conv)[key] = (ver, w, bias)
+    return w, bias
+
+
+def packed_dgrad(conv: nn.Conv2d, dtype):
+    key = ("dgrad", dtype)
+    ver = _ver(conv.weight)
+    hit = _cache(conv).get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    w = ops.pack_weight_dgrad(conv.weight, dtype)
+    _cache(conv)[key] = (ver, w)
+    return w
+
+
+def out_shape(conv: nn.Conv2d, x):
+    k, s, p, d = _conv_geom(conv)
+    ho, wo = ops.conv_out_hw(x.shape[2], x.shape[3], k, s, p, d)
+    return x.shape[0], conv.out_channels, ho, wo
+
+
+def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, training: bool, tape=None, out=None,
+                   residual=None, q1: bool = False, ci_pad: Optional[int] = None):
+    """x: NHWC-backed activation (channels may be zero-padded up to ci_pad).  Returns z (written into `out` if given)."""
+    k, s, p, d = _conv_geom(conv)
+    n, co, ho, wo = out_shape(conv, x)
+    dtype = x.dtype
+    if out is None:
+        out = ops.new_act(n, co, ho, wo, dtype, x.device)
+    skip_bn = bn is None or (q1 and x.shape[2] * x.shape[3] == 1)
+    train_bn = training and not skip_bn
+    if tape is None and not train_bn:
+        # inference: one fused launch
+        w, bias = packed_fwd(conv, dtype, ci_pad, None if skip_bn else bn)
+        ops.conv2d_fwd(x, w, bias, residual, out, ops.conv_params(k, s, p, d, act))
+        return out
+    # training (or eval-mode forward that must stay differentiable)
+    w, bias = packed_fwd(conv, dtype, ci_pad, None)
+    plain = skip_bn and act == ACT_NONE and residual is None
+    y = out if plain else ops.new_act(n, co, ho, wo, dtype, x.device)
+    ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE))
+    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, y=y, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
+    if plain:
+        pass
+    elif skip_bn:
+        ops.bn_act_fwd(y, None, None, act, residual, out)
+    elif train_bn:
+        scale, shift, mean, rstd = ops.bn_stats(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        ops.bn_act_fwd(y, scale, shift, act, residual, out)
+        rec.update(scale=scale, shift=shift, mean=mean, rstd=rstd, frozen=False)
+    else:
+        # eval-mode BN kept differentiable (running statistics are constants): z = act(y*scale + shift)
+        g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_var)
+        b = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(bn.running_var)
+        scale = (g / torch.sqrt(bn.running_var.float() + bn.eps)).contiguous()
+        shift = (b - bn.running_mean.float() * scale).contiguous()
+        ops.bn_act_fwd(y, scale, shift, act, residual, out)
+        rec.update(scale=scale, shift=shift, frozen=True)
+    if tape is not None:
+        tape.push(rec)
+    return out
+
+
+def _channel_sum(t):
+    """Per-channel sum over N,H,W of an NHWC activation (fp32 [C]) via the BN statistics kernel (mean * count)."""
+    c = t.shape[1]
+    _, _, mean, _ = ops.bn_stats(t, None, None, None, None, 0.0, 1.0)
+    return mean * float(t.shape[0] * t.shape[2] * t.shape[3])
+
+
+def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
+    """Backward of conv_block_fwd.  dz: gradient of the block output (the caller routes dz to a shortcut itself)."""
+    rec = tape.pop()
+    conv, bn, act, x, y = rec["conv"], rec["bn"], rec["act"], rec["x"], rec["y"]
+    k, s, p, d = rec["geom"]
+    dtype = x.dtype
+    if rec["plain"]:
+        dy = dz
+    elif bn is None:
+        dy = ops.act_bwd(dz, y, act, ops.new_act(*y.shape, dtype, y.device)) if act != ACT_NONE else dz
+    elif rec["frozen"]:
+        raise NotImplementedError("backward through eval-mode BatchNorm is not part of the DeSeNet training path")
+    else:
+        dy = ops.new_act(*y.shape, dtype, y.device)
+        dg = torch.empty_like(rec["scale"])
+        db = torch.empty_like(rec["scale"])
+        ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, dg, db)
+        tape.add_grad(bn.weight, dg)
+        tape.add_grad(bn.bias, db)
+    if conv.weight.requires_grad:
+        co, ci, kh, kw = conv.weight.shape
+        cip = rec["ci_pad"] or ci
+        dwp = torch.zeros((co, kh, kw, cip), dtype=torch.float32, device=x.device)
+        ops.conv2d_wgrad(x, dy, dwp, cip, ops.conv_params(k, s, p, d))
+        tape.add_grad(conv.weight, ops.unpack_wgrad(dwp, (co, ci, kh, kw), cip))
+    if conv.bias is not None and conv.bias.requires_grad:
+        tape.add_grad(conv.bias, _channel_sum(dy))
+    if not need_dx:
+        return None
+    if dx is None:
+        dx = ops.new_act(*x.shape, dtype, x.device)
+        acc = False
+    ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc))
+    return dx

@@ -1,0 +1,430 @@
+"""Drop-in mirror of the reference's `core.models.common` for the DeSeNet-s hot path, running on libdesenet_hip.so.
+
+Same class names, constructor signatures, attribute names and therefore the same `state_dict` keys/shapes as the
+reference (so `intersect_dicts` loading, EMA and checkpoints interchange through `state_dict`):
+
+    autopad, Conv              core/models/common.py:32-56       Bottleneck   :101-111      C3      :133-145
+    SPP                        :172-185                          FFM          :222-242      RFB2    :504-545
+    PyramidPooling             :588-615                          Focus        :618-627      Concat  :686-693
+
+`nn.Conv2d` / `nn.BatchNorm2d` children are kept as PARAMETER CONTAINERS only (their ATen forward is never called);
+every forward/backward is HIP kernels through desenet_amd.hip_ops.  Activations are logical NCHW tensors stored NHWC.
+Modules of the reference that DeSeNet-s never instantiates (DWConv, TransformerBlock, GhostConv, AutoShape, ...) are
+out of scope.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Union
+
+import torch
+import torch.nn as nn
+
+from ... import hip_ops as ops
+from ...conv_impl import act_code, conv_block_bwd, conv_block_fwd, out_shape
+from ...hip_ops import ACT_NONE, ACT_SIGMOID, ACT_SILU
+from ...runtime import compute_dtype, run_module
+
+
+def autopad(k: Union[int, List[int]], p=None):
+    """'same' padding (reference common.py:32-39)."""
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def _as_input(x: torch.Tensor) -> torch.Tensor:
+    """Bring a caller tensor to the compute dtype / NHWC storage (no-op inside a network)."""
+    dt = compute_dtype()
+    if x.dtype != dt:
+        x = x.to(dt)
+    return ops.as_act(x)
+
+
+class HipModule(nn.Module):
+    def forward(self, x):
+        return run_module(self, x)
+
+    def fwd(self, x, tape=None, out=None):  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class Conv(HipModule):
+    """Conv2d(bias=False) + BatchNorm2d + SiLU, BN skipped on 1x1 maps while un-fused (quirk Q1)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        ap = autopad(k, p)
+        assert isinstance(ap, int)
+        self.conv = nn.Conv2d(c1, c2, k, s, ap, groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    @property
+    def fused(self) -> bool:
+        return not hasattr(self, "bn")
+
+    def fwd(self, x, tape=None, out=None, residual=None, ci_pad=None):
+        x = _as_input(x)
+        bn = None if self.fused else self.bn
+        return conv_block_fwd(x, self.conv, bn, act_code(self.act), self.training, tape, out, residual,
+                              q1=not self.fused, ci_pad=ci_pad)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        return conv_block_bwd(tape, dy, dx, acc, need_dx)
+
+    def forward_fuse(self, x):   # reference API (common.py:55-56); the fused state is detected from the missing `bn`
+        return self.forward(x)
+
+
+class Bottleneck(HipModule):
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def fwd(self, x, tape=None, out=None):
+        x = _as_input(x)
+        t = self.cv1.fwd(x, tape)
+        return self.cv2.fwd(t, tape, out, residual=x if self.add else None)   # shortcut add fused in the epilogue
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        dt = self.cv2.bwd(tape, dy)
+        if self.add and need_dx:
+            if dx is None:
+                dx = ops.new_act(*dy.shape, dy.dtype, dy.device)
+                ops.copy(dy, dx)
+            else:
+                ops.copy(dy, dx, accumulate=acc)
+            acc = True
+        return self.cv1.bwd(tape, dt, dx, acc, need_dx)
+
+
+class C3(HipModule):
+    """cv3(cat(m(cv1(x)), cv2(x))): the cat is never materialised -- both producers write into slices of one buffer."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    def fwd(self, x, tape=None, out=None):
+        x = _as_input(x)
+        c_ = self.cv1.conv.out_channels
+        n, _, h, w = x.shape
+        cat = ops.new_act(n, 2 * c_, h, w, x.dtype, x.device)
+        blocks = list(self.m)
+        a = self.cv1.fwd(x, tape, cat[:, :c_] if not blocks else None)
+        for i, b in enumerate(blocks):
+            a = b.fwd(a, tape, cat[:, :c_] if i == len(blocks) - 1 else None)
+        self.cv2.fwd(x, tape, cat[:, c_:])
+        return self.cv3.fwd(cat, tape, out)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        c_ = self.cv1.conv.out_channels
+        dcat = self.cv3.bwd(tape, dy)
+        dx = self.cv2.bwd(tape, dcat[:, c_:], dx, acc, need_dx)
+        da = dcat[:, :c_]
+        for b in reversed(list(self.m)):
+            da = b.bwd(tape, da)
+        return self.cv1.bwd(tape, da, dx, True, need_dx)
+
+
+class SPP(HipModule):
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+
+    def fwd(self, x, tape=None, out=None):
+        x = _as_input(x)
+        c_ = self.cv1.conv.out_channels
+        n, _, h, w = x.shape
+        cat = ops.new_act(n, c_ * (len(self.m) + 1), h, w, x.dtype, x.device)
+        x0 = self.cv1.fwd(x, tape, cat[:, :c_])
+        idxs = []
+        for i, mp in enumerate(self.m, 1):
+            idx = torch.empty((n, h, w, c_), dtype=torch.int32, device=x.device) if tape is not None else None
+            ops.maxpool_s1(x0, cat[:, i * c_:(i + 1) * c_], int(mp.kernel_size), idx)
+            idxs.append(idx)
+        if tape is not None:
+            tape.push(idxs)
+        return self.cv2.fwd(cat, tape, out)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        c_ = self.cv1.conv.out_channels
+        dcat = self.cv2.bwd(tape, dy)
+        idxs = tape.pop()
+        d0 = dcat[:, :c_]
+        for i, (mp, idx) in enumerate(zip(self.m, idxs), 1):
+            ops.maxpool_s1_bwd(dcat[:, i * c_:(i + 1) * c_], idx, d0, int(mp.kernel_size), accumulate=True)
+        return self.cv1.bwd(tape, d0, dx, acc, need_dx)
+
+
+class Focus(HipModule):
+    """Space-to-depth straight from the NCHW image into the conv's NHWC input (bit-exact index map)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
+
+    def fwd(self, x, tape=None, out=None):
+        if not x.is_cuda:
+            raise RuntimeError("desenet_amd kernels run on an MI355X only: got a CPU tensor (there is no CPU fallback)")
+        dt = compute_dtype()
+        n, c, h, w = x.shape
+        vec = 4 if dt == torch.float32 else 8
+        cpad = (4 * c + vec - 1) // vec * vec          # 12 -> 12 (fp32) / 16 (bf16): 16-byte channel vectors
+        s2d = ops.new_act(n, cpad, h // 2, w // 2, dt, x.device)
+        ops.focus_s2d(x, s2d)
+        return self.conv.fwd(s2d, tape, out, ci_pad=cpad)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        if need_dx:
+            raise NotImplementedError("gradient w.r.t. the input image is not part of the training path")
+        return self.conv.bwd(tape, dy, need_dx=False)
+
+
+class Concat(HipModule):
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    @staticmethod
+    def _adjacent(xs):
+        """xs are consecutive channel slices of ONE NHWC buffer -> the covering view, else None."""
+        x0 = xs[0]
+        es = x0.element_size()
+        ptr = x0.data_ptr()
+        for t in xs:
+            if (t.dtype != x0.dtype or t.shape[0] != x0.shape[0] or t.shape[2:] != x0.shape[2:]
+                    or t.stride() != x0.stride() or t.data_ptr() != ptr
+                    or t.untyped_storage().data_ptr() != x0.untyped_storage().data_ptr()):
+                return None
+            ptr += t.shape[1] * es
+        ctot = sum(t.shape[1] for t in xs)
+        ldc = ops._nhwc_ldc(x0)
+        if ldc is None or ldc < ctot:
+            return None
+        return torch.as_strided(x0, (x0.shape[0], ctot, x0.shape[2], x0.shape[3]), x0.stride(), x0.storage_offset())
+
+    def fwd(self, xs, tape=None, out=None):
+        assert self.d == 1, "channel concat only"
+        xs = [_as_input(t) for t in xs]
+        sizes = [t.shape[1] for t in xs]
+        if tape is not None:
+            tape.push(sizes)
+        merged = self._adjacent(xs) if out is None else None
+        if merged is not None:
+            return merged
+        n, _, h, w = xs[0].shape
+        if out is None:
+            out = ops.new_act(n, sum(sizes), h, w, xs[0].dtype, xs[0].device)
+        c0 = 0
+        for t in xs:
+            dst = out[:, c0:c0 + t.shape[1]]
+            if dst.data_ptr() != t.data_ptr():
+                ops.copy(t, dst)
+            c0 += t.shape[1]
+        return out
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        sizes = tape.pop()
+        outs, c0 = [], 0
+        for i, c in enumerate(sizes):
+            g = dy[:, c0:c0 + c]
+            if dx is not None and dx[i] is not None:
+                ops.copy(g, dx[i], accumulate=bool(acc[i]) if isinstance(acc, (list, tuple)) else bool(acc))
+                g = dx[i]
+            outs.append(g)
+            c0 += c
+        return outs
+
+
+class Upsample(nn.Upsample, HipModule):
+    """nn.Upsample(None, 2, 'nearest') of the model yaml (yolov5s_seg.yaml:31,36)."""
+
+    def forward(self, x):
+        return run_module(self, x)
+
+    def fwd(self, x, tape=None, out=None):
+        if self.mode != "nearest" or float(self.scale_factor) != 2.0:
+            raise NotImplementedError("only nearest x2 up-sampling is on the DeSeNet path")
+        x = _as_input(x)
+        n, c, h, w = x.shape
+        if out is None:
+            out = ops.new_act(n, c, 2 * h, 2 * w, x.dtype, x.device)
+        if tape is not None:
+            tape.push((n, c, h, w))
+        return ops.upsample_nearest2x(x, out)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        n, c, h, w = tape.pop()
+        if not need_dx:
+            return None
+        if dx is None:
+            dx, acc = ops.new_act(n, c, h, w, dy.dtype, dy.device), False
+        return ops.upsample_nearest2x_bwd(dy, dx, accumulate=acc)
+
+
+# ----------------------------------------------------------------------------------------------------- seg blocks
+class _ConvBnAct(nn.Sequential):
+    """The raw nn.Conv2d + nn.BatchNorm2d + nn.SiLU triple of RFB2.branch1/2 (never folded by Model.fuse(): quirk Q3)."""
+
+    def __init__(self, c, d):
+        super().__init__(nn.Conv2d(c, c, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
+                         nn.BatchNorm2d(c), nn.SiLU())
+
+    def forward(self, x):
+        return run_module(self, x)
+
+    def fwd(self, x, tape=None, out=None):
+        return conv_block_fwd(_as_input(x), self[0], self[1], ACT_SILU, self.training, tape, out)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        return conv_block_bwd(tape, dy, dx, acc, need_dx)
+
+
+class RFB2(HipModule):
+    def __init__(self, in_planes, out_planes, map_reduce=4, d=[2, 3], has_global=False):
+        super().__init__()
+        if has_global:
+            raise NotImplementedError("RFB2(has_global=True) is not instantiated by SegMaskPSP (yolo.py:178)")
+        self.out_channels = out_planes
+        self.has_global = has_global
+        inter = in_planes // map_reduce
+        self.branch0 = nn.Sequential(Conv(in_planes, inter, k=1, s=1), Conv(inter, inter, k=3, s=1))
+        self.branch1 = _ConvBnAct(inter, d[0])
+        self.branch2 = _ConvBnAct(inter, d[1])
+        self.branch3 = nn.Sequential(Conv(in_planes, inter, k=1, s=1))
+        self.ConvLinear = Conv(4 * inter, out_planes, k=1, s=1)
+
+    def fwd(self, x, tape=None, out=None):
+        x = _as_input(x)
+        i = self.branch1[0].in_channels
+        n, _, h, w = x.shape
+        cat = ops.new_act(n, 4 * i, h, w, x.dtype, x.device)     # [x0 | x1 | x2 | x3]
+        self.branch3[0].fwd(x, tape, cat[:, 3 * i:])
+        t = self.branch0[0].fwd(x, tape)
+        x0 = self.branch0[1].fwd(t, tape, cat[:, :i])
+        x1 = self.branch1.fwd(x0, tape, cat[:, i:2 * i])
+        self.branch2.fwd(x1, tape, cat[:, 2 * i:3 * i])
+        return self.ConvLinear.fwd(cat, tape, out)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        i = self.branch1[0].in_channels
+        dcat = self.ConvLinear.bwd(tape, dy)
+        d1 = self.branch2.bwd(tape, dcat[:, 2 * i:3 * i], dcat[:, i:2 * i], True)     # dx1 += ...
+        d0 = self.branch1.bwd(tape, d1, dcat[:, :i], True)                            # dx0 += ...
+        dt = self.branch0[1].bwd(tape, d0)
+        dx = self.branch0[0].bwd(tape, dt, dx, acc, need_dx)
+        return self.branch3[0].bwd(tape, dcat[:, 3 * i:], dx, True, need_dx)
+
+
+class PyramidPooling(HipModule):
+    def __init__(self, in_channels, k=[1, 2, 3, 6], short_cut=False):
+        super().__init__()
+        self.short_cut = short_cut
+        self.pool1, self.pool2, self.pool3, self.pool4 = (nn.AdaptiveAvgPool2d(v) for v in k)
+        oc = in_channels // 4
+        self.conv1 = Conv(in_channels, oc, k=1)
+        self.conv2 = Conv(in_channels, oc, k=1)
+        self.conv3 = Conv(in_channels, oc, k=1)
+        self.conv4 = Conv(in_channels, oc, k=1)
+
+    def _branches(self):
+        return [(self.pool1, self.conv1), (self.pool2, self.conv2), (self.pool3, self.conv3), (self.pool4, self.conv4)]
+
+    def fwd(self, x, tape=None, out=None):
+        """`out` (optional): the full [x | f1..f4] buffer whose first slice already IS x (SegMaskPSP arranges that)."""
+        x = _as_input(x)
+        n, c, h, w = x.shape
+        oc = self.conv1.conv.out_channels
+        base = c if self.short_cut else 0
+        if out is None:
+            out = ops.new_act(n, base + 4 * oc, h, w, x.dtype, x.device)
+        if self.short_cut and out[:, :c].data_ptr() != x.data_ptr():
+            ops.copy(x, out[:, :c])
+        for j, (pool, conv) in enumerate(self._branches()):
+            ksz = pool.output_size if isinstance(pool.output_size, int) else pool.output_size[0]
+            pooled = ops.adaptive_avgpool(x, ops.new_act(n, c, ksz, ksz, x.dtype, x.device))
+            f = conv.fwd(pooled, tape)
+            ops.bilinear_ac(f, out[:, base + j * oc: base + (j + 1) * oc])
+        if tape is not None:
+            tape.push((n, c, h, w))
+        return out
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        n, c, h, w = tape.pop()
+        oc = self.conv1.conv.out_channels
+        base = c if self.short_cut else 0
+        if dx is None:
+            dx, acc = ops.new_act(n, c, h, w, dy.dtype, dy.device), False
+            if self.short_cut:
+                ops.copy(dy[:, :c], dx)
+                acc = True
+        elif self.short_cut:
+            ops.copy(dy[:, :c], dx, accumulate=acc)
+            acc = True
+        for j, (pool, conv) in reversed(list(enumerate(self._branches()))):
+            ksz = pool.output_size if isinstance(pool.output_size, int) else pool.output_size[0]
+            df = ops.bilinear_ac_bwd(dy[:, base + j * oc: base + (j + 1) * oc],
+                                     ops.new_act(n, oc, ksz, ksz, dy.dtype, dy.device))
+            dpool = conv.bwd(tape, df)
+            ops.adaptive_avgpool_bwd(dpool, dx, accumulate=acc)
+            acc = True
+        return dx
+
+
+class FFM(HipModule):
+    def __init__(self, in_chan, out_chan, reduction=1, is_cat=True, k=1):
+        super().__init__()
+        self.convblk = Conv(in_chan, out_chan, k=k, s=1)
+        self.channel_attention = nn.Sequential(
+            nn.AdaptiveAvgPool2d(1),
+            nn.Conv2d(out_chan, out_chan // reduction, kernel_size=1, stride=1, padding=0, bias=False),
+            nn.SiLU(inplace=True),
+            nn.Conv2d(out_chan // reduction, out_chan, kernel_size=1, stride=1, padding=0, bias=False),
+            nn.Sigmoid(),
+        )
+        self.is_cat = is_cat
+
+    def fwd(self, x, tape=None, out=None):
+        if self.is_cat:
+            x = Concat._adjacent([_as_input(t) for t in x]) if isinstance(x, (list, tuple)) else x
+            if x is None:
+                raise NotImplementedError("FFM(is_cat=True) expects adjacent slices; SegMaskPSP uses is_cat=False")
+        x = _as_input(x)
+        ca = self.channel_attention
+        feat = self.convblk.fwd(x, tape)
+        n, c, h, w = feat.shape
+        gap = ops.adaptive_avgpool(feat, ops.new_act(n, c, 1, 1, feat.dtype, feat.device))
+        a1 = conv_block_fwd(gap, ca[1], None, ACT_SILU, self.training, tape)
+        att = conv_block_fwd(a1, ca[3], None, ACT_SIGMOID, self.training, tape)
+        if out is None:
+            out = ops.new_act(n, c, h, w, feat.dtype, feat.device)
+        ops.ffm_scale(feat, att, out)
+        if tape is not None:
+            tape.push((feat, att))
+        return out
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        feat, att = tape.pop()
+        n, c, h, w = feat.shape
+        dfeat = ops.new_act(n, c, h, w, feat.dtype, feat.device)
+        datt = ops.new_act(n, c, 1, 1, feat.dtype, feat.device)
+        ops.ffm_scale_bwd(dy, feat, att, dfeat, datt)
+        da1 = conv_block_bwd(tape, datt)
+        dgap = conv_block_bwd(tape, da1)
+        ops.adaptive_avgpool_bwd(dgap, dfeat, accumulate=True)
+        return self.convblk.bwd(tape, dfeat, dx, acc, need_dx)

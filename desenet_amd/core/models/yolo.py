@@ -1,0 +1,386 @@
+"""Drop-in mirror of the reference's `core.models.yolo` (DeSeNet-s path) on libdesenet_hip.so.
+
+    SegMaskPSP   core/models/yolo.py:156-197        Detect       :238-282
+    Model        :285-440  (forward :326-356, _initialize_biases :388-396, fuse :409-417)
+    parse_model  :443-499
+
+Differences that are deliberate and documented in INTEGRATION.md:
+  * strides are derived from the graph (product of layer strides) instead of a 256x256 probe forward on the CPU
+    (yolo.py:313-315) -- there is no CPU compute path; the values are identical ([8, 16, 32]);
+  * module names in the yaml are resolved from an explicit table, not `eval` (yolo.py:451);
+  * the whole network is ONE autograd node: concat buffers are planned so producers write straight into them, and
+    backward walks the layer list in reverse, accumulating fan-in gradients in place.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from ... import hip_ops as ops
+from ...conv_impl import conv_block_bwd, conv_block_fwd
+from ...hip_ops import ACT_NONE
+from ...runtime import run_module
+from ..utils.autoanchor import check_anchor_order
+from ..utils.general import make_divisible
+from ..utils.torch_utils import fuse_conv_and_bn, initialize_weights, model_info
+from .common import (C3, FFM, RFB2, SPP, Bottleneck, Concat, Conv, Focus, HipModule, PyramidPooling, Upsample,
+                     _as_input)
+
+LOGGER = logging.getLogger(__name__)
+
+
+class _Bilinear(nn.Upsample):
+    """nn.Upsample(scale_factor=s, mode='bilinear', align_corners=True) placeholder inside the seg head's Sequentials
+    (keeps the reference's child indices, hence its state_dict keys); the work is done by SegMaskPSP.fwd."""
+
+
+class SegMaskPSP(HipModule):
+    """PSP-style segmentation head: 3-level fusion -> RFB2 -> PyramidPooling -> FFM -> 1x1 classifier -> x8 bilinear."""
+
+    def __init__(self, n_segcls=19, n=1, c_hid=256, shortcut=False, ch=()):
+        super().__init__()
+        self.c_in8, self.c_in16, self.c_in32 = ch[0], ch[1], ch[2]
+        self.c_out = n_segcls
+        self.m8 = nn.Sequential(Conv(self.c_in8, c_hid, k=1))
+        self.m16 = nn.Sequential(Conv(self.c_in16, c_hid, k=1),
+                                 _Bilinear(scale_factor=2, mode="bilinear", align_corners=True))
+        self.m32 = nn.Sequential(Conv(self.c_in32, c_hid, k=1),
+                                 _Bilinear(scale_factor=4, mode="bilinear", align_corners=True))
+        self.out = nn.Sequential(
+            RFB2(c_hid * 3, c_hid, d=[2, 3], map_reduce=6),
+            PyramidPooling(c_hid, k=[1, 2, 3, 6], short_cut=True),
+            FFM(c_hid * 2, c_hid, k=3, is_cat=False),
+            nn.Conv2d(c_hid, self.c_out, kernel_size=1, padding=0),
+            _Bilinear(scale_factor=8, mode="bilinear", align_corners=True),
+        )
+
+    def fwd(self, xs, tape=None, out=None):
+        x8, x16, x32 = (_as_input(t) for t in xs)
+        c = self.m8[0].conv.out_channels
+        n, _, h, w = x8.shape
+        dt, dev = x8.dtype, x8.device
+        cat = ops.new_act(n, 3 * c, h, w, dt, dev)                      # [m8 | up2(m16) | up4(m32)]
+        self.m8[0].fwd(x8, tape, cat[:, :c])
+        f16 = self.m16[0].fwd(x16, tape)
+        ops.bilinear_ac(f16, cat[:, c:2 * c])
+        f32 = self.m32[0].fwd(x32, tape)
+        ops.bilinear_ac(f32, cat[:, 2 * c:])
+        pp = ops.new_act(n, 2 * c, h, w, dt, dev)                       # [rfb2 out | pyramid feats]
+        self.out[0].fwd(cat, tape, pp[:, :c])
+        self.out[1].fwd(pp[:, :c], tape, pp)
+        y = self.out[2].fwd(pp, tape)
+        logits = conv_block_fwd(y, self.out[3], None, ACT_NONE, self.training, tape)
+        seg = torch.empty((n, self.c_out, 8 * h, 8 * w), dtype=torch.float32, device=dev)   # caller-facing NCHW fp32
+        ops.bilinear_ac(logits, seg, out_nchw=True)
+        if tape is not None:
+            tape.push((f16.shape, f32.shape, logits.shape, dt))
+        return seg
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        s16, s32, sl, dt = tape.pop()
+        dev = dy.device
+        c = self.m8[0].conv.out_channels
+        g = dy if (dy.dtype == torch.float32 and dy.is_contiguous()) else dy.float().contiguous()
+        dlog = ops.bilinear_ac_bwd(g, ops.new_act(*sl, dt, dev), dy_nchw=True)
+        d_y = conv_block_bwd(tape, dlog)
+        dpp = self.out[2].bwd(tape, d_y)
+        drfb = self.out[1].bwd(tape, dpp)
+        dcat = self.out[0].bwd(tape, drfb)
+        dxs = list(dx) if dx is not None else [None, None, None]
+        accs = list(acc) if isinstance(acc, (list, tuple)) else [acc] * 3
+        df32 = ops.bilinear_ac_bwd(dcat[:, 2 * c:], ops.new_act(*s32, dt, dev))
+        dxs[2] = self.m32[0].bwd(tape, df32, dxs[2], accs[2], need_dx)
+        df16 = ops.bilinear_ac_bwd(dcat[:, c:2 * c], ops.new_act(*s16, dt, dev))
+        dxs[1] = self.m16[0].bwd(tape, df16, dxs[1], accs[1], need_dx)
+        dxs[0] = self.m8[0].bwd(tape, dcat[:, :c], dxs[0], accs[0], need_dx)
+        return dxs
+
+
+class Detect(HipModule):
+    stride = None
+    onnx_dynamic = False
+
+    def __init__(self, nc=80, anchors=(), ch=(), inplace=True):
+        super().__init__()
+        self.nc = nc
+        self.no = nc + 5
+        self.nl = len(anchors)
+        self.na = len(anchors[0]) // 2
+        self.grid = [torch.zeros(1)] * self.nl
+        a = torch.tensor(anchors).float().view(self.nl, -1, 2)
+        self.register_buffer("anchors", a)
+        self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
+        self.inplace = inplace
+
+    def fwd(self, xs, tape=None, out=None):
+        xs = [_as_input(t) for t in xs]
+        n = xs[0].shape[0]
+        dev = xs[0].device
+        total = sum(self.na * t.shape[2] * t.shape[3] for t in xs)
+        pred = None if self.training else torch.empty((n, total, self.no), dtype=torch.float32, device=dev)
+        raws, row = [], 0
+        anchors_px = self.anchor_grid.view(self.nl, self.na, 2).float().contiguous()
+        for i, x in enumerate(xs):
+            t = conv_block_fwd(x, self.m[i], None, ACT_NONE, self.training, tape)
+            _, _, ny, nx = t.shape
+            raw = torch.empty((n, self.na, ny, nx, self.no), dtype=torch.float32, device=dev)
+            ops.detect_decode(t, raw, pred, row, self.na, self.no, float(self.stride[i]), anchors_px[i])
+            raws.append(raw)
+            row += self.na * ny * nx
+        if tape is not None:
+            tape.push([(tuple(x.shape), x.dtype) for x in xs])
+        return raws if self.training else (pred, raws)
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+        metas = tape.pop()
+        draws = dy if self.training else dy[1]
+        dxs = list(dx) if dx is not None else [None] * self.nl
+        accs = list(acc) if isinstance(acc, (list, tuple)) else [acc] * self.nl
+        for i in reversed(range(self.nl)):
+            (n, _, ny, nx), dt = metas[i]
+            dtl = ops.detect_raw_bwd(draws[i], ops.new_act(n, self.na * self.no, ny, nx, dt, draws[i].device), self.na,
+                                     self.no)
+            dxs[i] = conv_block_bwd(tape, dtl, dxs[i], accs[i], need_dx)
+        return dxs
+
+
+# name table replacing the reference's eval() of yaml strings (yolo.py:451)
+MODULES = {"Conv": Conv, "Focus": Focus, "C3": C3, "SPP": SPP, "Bottleneck": Bottleneck, "Concat": Concat,
+           "nn.Upsample": Upsample, "Upsample": Upsample, "SegMaskPSP": SegMaskPSP, "Detect": Detect}
+
+
+def parse_model(d, ch):
+    """yaml dict -> (nn.Sequential of layers with .i/.f/._type/.np attached, sorted save list); yolo.py:443-499."""
+    LOGGER.info("\n%3s%18s%3s%10s  %-40s%-30s" % ("", "from", "n", "params", "module", "arguments"))
+    anchors, de_nc, se_nc, gd, gw = d["anchors"], d["de_nc"], d["se_nc"], d["depth_multiple"], d["width_multiple"]
+    na = (len(anchors[0]) // 2) if isinstance(anchors, list) else anchors
+    no = na * (de_nc + 5)
+    names = {"de_nc": de_nc, "se_nc": se_nc, "anchors": anchors, "None": None, "False": False, "True": True}
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, mname, args) in enumerate(d["backbone"] + d["head"]):
+        if mname not in MODULES:
+            raise NotImplementedError(f"module '{mname}' is outside the DeSeNet-s hot path (SURVEY.md 2, rows 20-22)")
+        m = MODULES[mname]
+        args = [names[a] if isinstance(a, str) and a in names else a for a in args]
+        n = n_ = max(round(n * gd), 1) if n > 1 else n
+        if m in (Conv, Bottleneck, SPP, Focus, C3):
+            c1, c2 = ch[f], args[0]
+            if c2 != no:
+                c2 = make_divisible(c2 * gw, 8)
+            args = [c1, c2, *args[1:]]
+            if m is C3:
+                args.insert(2, n)
+                n = 1
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+            if isinstance(args[1], int):
+                args[1] = [list(range(args[1] * 2))] * len(f)
+        elif m is SegMaskPSP:
+            args[1] = max(round(args[1] * gd), 1) if args[1] > 1 else args[1]
+            args[2] = make_divisible(args[2] * gw, 8)
+            args.append([ch[x] for x in f])
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*[m(*args) for _ in range(n)]) if n > 1 else m(*args)
+        t = f"{m.__module__}.{m.__name__}".replace("desenet_amd.", "")
+        np_ = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_._type, m_.np = i, f, t, np_
+        LOGGER.info("%3s%18s%3s%10.0f  %-40s%-30s" % (i, f, n_, np_, t, args))
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+def _layer_stride(m) -> float:
+    """Spatial reduction of one top-level layer (replaces the probe forward of yolo.py:313-315)."""
+    if isinstance(m, Focus):
+        return 2.0 * m.conv.conv.stride[0]
+    if isinstance(m, Conv):
+        return float(m.conv.stride[0])
+    if isinstance(m, Upsample):
+        return 1.0 / float(m.scale_factor)
+    return 1.0
+
+
+class Model(HipModule):
+    def __init__(self, cfg="desenet_s.yaml", ch=3, nc=None, anchors=None):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = cfg
+        else:
+            import yaml
+            cfg = Path(cfg)
+            if not cfg.exists():
+                cfg = Path(__file__).resolve().parents[2] / "cfg" / cfg.name
+            self.yaml_file = cfg.name
+            with open(cfg, "r", encoding="utf-8") as f:
+                self.yaml = yaml.safe_load(f)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["de_nc"]:
+            LOGGER.info(f"Overriding model.yaml de_nc={self.yaml['de_nc']} with de_nc={nc}")
+            self.yaml["de_nc"] = nc
+        if anchors:
+            LOGGER.info(f"Overriding model.yaml anchors with anchors={anchors}")
+            self.yaml["anchors"] = round(anchors)
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=[ch])
+        self.seg_index = next((m.i for m in self.model if isinstance(m, SegMaskPSP)), len(self.model) - 2)
+        self.save.append(self.seg_index)   # reference hard-codes 24 (yolo.py:305)
+        self.de_names = [str(i) for i in range(self.yaml["de_nc"])]
+        self.se_names = [str(i) for i in range(self.yaml["se_nc"])]
+        self.inplace = self.yaml.get("inplace", True)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.inplace = self.inplace
+            m.stride = torch.tensor(self._infer_strides(m))
+            m.anchors /= m.stride.view(-1, 1, 1)
+            check_anchor_order(m)
+            self.stride = m.stride
+            self._initialize_biases()
+        initialize_weights(self)
+        self._plan_concats()
+        self.info()
+        LOGGER.info("")
+
+    # ---- construction helpers -------------------------------------------------------------------------------------
+    def _infer_strides(self, det):
+        scale = []
+        for m in self.model:
+            src = m.f if isinstance(m.f, int) else m.f[0]
+            prev = 1.0 if m.i == 0 else scale[src if src >= 0 else m.i + src]
+            scale.append(prev * _layer_stride(m))
+        return [scale[j] for j in det.f]
+
+    def _initialize_biases(self, cf=None):
+        m = self.model[-1]
+        for mi, s in zip(m.m, m.stride):
+            b = mi.bias.view(m.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (m.nc - 0.99)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def _plan_concats(self):
+        """For every Concat layer: which producer layer writes which channel range of its buffer."""
+        self._cat_slot = {}
+        chans = {}
+        for m in self.model:
+            if isinstance(m, Concat):
+                c0 = 0
+                srcs = [m.i + j if j < 0 else j for j in m.f]
+                sizes = [chans[s] for s in srcs]
+                ok = all(s not in self._cat_slot and not isinstance(self.model[s], (Concat, Detect, SegMaskPSP))
+                         for s in srcs) and len(set(srcs)) == len(srcs)
+                if ok:
+                    for s, c in zip(srcs, sizes):
+                        self._cat_slot[s] = (m.i, c0, c, sum(sizes))
+                        c0 += c
+                chans[m.i] = sum(sizes)
+            else:
+                chans[m.i] = self._out_channels(m, chans)
+
+    @staticmethod
+    def _out_channels(m, chans):
+        if isinstance(m, Focus):
+            return m.conv.conv.out_channels
+        if isinstance(m, Conv):
+            return m.conv.out_channels
+        if isinstance(m, C3):
+            return m.cv3.conv.out_channels
+        if isinstance(m, SPP):
+            return m.cv2.conv.out_channels
+        if isinstance(m, Upsample):
+            return chans[m.i - 1 if m.f == -1 else m.f]
+        return 0
+
+    # ---- forward / backward ---------------------------------------------------------------------------------------
+    def forward(self, x, augment=False, profile=False, visualize=False):
+        if augment or profile or visualize:
+            raise NotImplementedError("augment / profile / visualize are outside the hot path (SURVEY.md 2 row 5)")
+        return run_module(self, x)
+
+    def fwd(self, x, tape=None, out=None):
+        y = []
+        cats = {}
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            dst = None
+            slot = self._cat_slot.get(m.i)
+            if slot is not None:
+                cat_i, c0, c, ctot = slot
+                n, h, w = self._out_nhw(m, x)
+                buf = cats.get(cat_i)
+                if buf is None:
+                    buf = cats[cat_i] = ops.new_act(n, ctot, h, w, self._dtype_of(x), self._device_of(x))
+                dst = buf[:, c0:c0 + c]
+            x = m.fwd(x, tape, dst) if dst is not None else m.fwd(x, tape)
+            y.append(x if m.i in self.save else None)
+        return x, y[self.seg_index]
+
+    @staticmethod
+    def _dtype_of(x):
+        from ...runtime import compute_dtype
+        return compute_dtype()
+
+    @staticmethod
+    def _device_of(x):
+        return (x[0] if isinstance(x, (list, tuple)) else x).device
+
+    @staticmethod
+    def _out_nhw(m, x):
+        n, _, h, w = x.shape
+        if isinstance(m, Upsample):
+            return n, 2 * h, 2 * w
+        if isinstance(m, Conv):
+            k, s, p = m.conv.kernel_size[0], m.conv.stride[0], m.conv.padding[0]
+            ho, wo = ops.conv_out_hw(h, w, k, s, p, 1)
+            return n, ho, wo
+        return n, h, w
+
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=False):
+        if need_dx:
+            raise NotImplementedError("gradient w.r.t. the input image is not part of the training path")
+        d_det, d_seg = dy
+        grads = {len(self.model) - 1: d_det, self.seg_index: d_seg}
+        for m in reversed(list(self.model)):
+            g = grads.pop(m.i, None)
+            if g is None:
+                raise RuntimeError(f"layer {m.i} ({m._type}) received no gradient")
+            if m.i == 0:
+                m.bwd(tape, g, need_dx=False)
+                break
+            srcs = [m.i - 1] if m.f == -1 else ([m.f] if isinstance(m.f, int) else
+                                               [m.i + j if j < 0 else j for j in m.f])
+            if isinstance(m.f, int):
+                have = grads.get(srcs[0])
+                grads[srcs[0]] = m.bwd(tape, g, have, have is not None)
+            else:
+                have = [grads.get(s) for s in srcs]
+                outs = m.bwd(tape, g, have, [h is not None for h in have])
+                for s, o in zip(srcs, outs):
+                    grads[s] = o
+        return None
+
+    # ---- reference API ----------------------------------------------------------------------------------------------
+    def fuse(self):
+        """Fold BatchNorm into every `Conv` (and only those: RFB2's raw Conv2d+BN pairs stay, quirk Q3); yolo.py:409-417."""
+        LOGGER.info("Fusing layers... ")
+        for m in self.model.modules():
+            if isinstance(m, Conv) and hasattr(m, "bn"):
+                m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                delattr(m, "bn")
+        self.info()
+        return self
+
+    def info(self, verbose=False, img_size=640):
+        model_info(self, verbose, img_size)

@@ -1,0 +1,71 @@
+"""Mirror of the hot-path pieces of the reference's `core.utils.general`: make_divisible (:411-413), xywh2xyxy (:523-530),
+box_iou (:626-648), scale_coords / clip_coords (:598-623) and non_max_suppression (:659-750).
+
+`non_max_suppression` keeps the reference signature and return type (a list of (n_i, 6) tensors [xyxy, conf, cls]) but
+runs as three HIP kernels (candidate keys -> per-image bitonic sort -> greedy suppression; csrc/detect_nms.hip) instead of
+a Python loop over images around torchvision.ops.nms.  Unsupported reference options raise instead of silently differing:
+`labels` (auto-labelling apriori boxes) and merge-NMS (disabled in the reference, `merge = False`).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from ... import hip_ops as ops
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def xywh2xyxy(x):
+    y = x.clone() if isinstance(x, torch.Tensor) else x.copy()
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def clip_coords(boxes, shape):
+    if isinstance(boxes, torch.Tensor):
+        boxes[:, 0].clamp_(0, shape[1])
+        boxes[:, 1].clamp_(0, shape[0])
+        boxes[:, 2].clamp_(0, shape[1])
+        boxes[:, 3].clamp_(0, shape[0])
+    else:
+        boxes[:, [0, 2]] = boxes[:, [0, 2]].clip(0, shape[1])
+        boxes[:, [1, 3]] = boxes[:, [1, 3]].clip(0, shape[0])
+
+
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    clip_coords(coords, img0_shape)
+    return coords
+
+
+def box_iou(box1, box2):
+    area1 = (box1[:, 2] - box1[:, 0]) * (box1[:, 3] - box1[:, 1])
+    area2 = (box2[:, 2] - box2[:, 0]) * (box2[:, 3] - box2[:, 1])
+    inter = (torch.min(box1[:, None, 2:], box2[:, 2:]) - torch.max(box1[:, None, :2], box2[:, :2])).clamp(0).prod(2)
+    return inter / (area1[:, None] + area2 - inter)
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_det=300):
+    """prediction: (bs, n, 5+nc) -> list of (n_i, 6) tensors [x1, y1, x2, y2, conf, cls] per image."""
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if labels:
+        raise NotImplementedError("apriori `labels` (auto-labelling) are outside the hot path")
+    out, cnt = ops.nms(prediction, conf_thres, iou_thres, multi_label, agnostic, classes, max_det)
+    counts = cnt.cpu().tolist()      # the one host sync (the reference syncs per image on x.shape[0])
+    return [out[i, :c] for i, c in enumerate(counts)]

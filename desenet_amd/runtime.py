@@ -1,0 +1,142 @@
+"""Host-side runtime shared by the mirrored modules: compute dtype, the backward tape, the autograd bridge.
+
+Every mirrored module (desenet_amd/core/models/*) implements
+
+    fwd(x, tape=None, out=None)      enqueue HIP kernels; `tape` (None in inference) records what backward needs;
+                                     `out` is an optional pre-allocated NHWC view to write into (concat-by-construction)
+    bwd(tape, dy, dx=None, acc=False, need_dx=True)
+                                     enqueue the backward kernels; writes (or, with acc, adds) the input gradient into
+                                     `dx` when given; parameter gradients go to tape.grads
+
+and composite modules call their children's fwd/bwd directly, so ONE autograd node (HipFunction) covers whatever
+module the caller invoked -- the whole Model in training (scripts/train.py:352 `model(imgs)`), or a single block in a
+unit test.  PyTorch's autograd only sees that node: no per-op Python dispatch, no ATen kernels on the hot path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """fp32 (config 2: inference parity) or bf16 storage with fp32 accumulation (configs 3-5)."""
+    global _compute_dtype
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _compute_dtype = dtype
+
+
+def compute_dtype():
+    """bf16 inside any torch.autocast region (the reference trains under amp.autocast, train.py:351), else the default."""
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return _compute_dtype
+
+
+class Tape:
+    """LIFO of forward records with a replayable cursor (two backward() calls on one forward, train.py:366-367)."""
+
+    def __init__(self):
+        self.stack: List[object] = []
+        self.cursor = 0
+        self.grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
+
+    def push(self, rec):
+        self.stack.append(rec)
+
+    def begin_backward(self):
+        self.cursor = len(self.stack)
+        self.grads = {}
+
+    def pop(self):
+        self.cursor -= 1
+        return self.stack[self.cursor]
+
+    def add_grad(self, param, g: torch.Tensor):
+        if param is None or not param.requires_grad:
+            return
+        if param in self.grads:
+            self.grads[param].add_(g)          # same parameter used twice in one graph: rare, not on the hot path
+        else:
+            self.grads[param] = g
+
+
+def _flatten(x, out):
+    if torch.is_tensor(x):
+        out.append(x)
+        return "t"
+    return [_flatten(e, out) for e in x], type(x)
+
+
+def flatten(x):
+    out: List[torch.Tensor] = []
+    spec = _flatten(x, out)
+    return out, spec
+
+
+def unflatten(spec, it):
+    if spec == "t":
+        return next(it)
+    items, typ = spec
+    vals = [unflatten(s, it) for s in items]
+    return tuple(vals) if typ is tuple else vals
+
+
+def _ops():
+    from . import hip_ops
+    return hip_ops
+
+
+class HipFunction(torch.autograd.Function):
+    """One autograd node around module.fwd / module.bwd."""
+
+    @staticmethod
+    def forward(ctx, module, n_in, in_spec, holder, *tensors):
+        inputs = unflatten(in_spec, iter(tensors[:n_in]))
+        tape = Tape()
+        with torch.no_grad():
+            out = module.fwd(inputs, tape)
+        outs, out_spec = flatten(out)
+        holder.append(out_spec)
+        ctx.module, ctx.tape, ctx.n_in, ctx.out_spec = module, tape, n_in, out_spec
+        ctx.params = tensors[n_in:]
+        ctx.in_needs = [t.requires_grad for t in tensors[:n_in]]
+        ctx.out_meta = [(o.shape, o.dtype, o.device) for o in outs]
+        # outputs that are NHWC-backed activations: their incoming gradients are brought to the same storage/dtype
+        ctx.out_is_act = [o.dim() == 4 and _ops()._nhwc_ldc(o) is not None and o.stride(1) == 1 for o in outs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        grads = [g if g is not None else torch.zeros(s, dtype=d, device=dev)
+                 for g, (s, d, dev) in zip(grads, ctx.out_meta)]
+        grads = [_ops().as_act(g.to(d)) if is_act else g
+                 for g, is_act, (_, d, _) in zip(grads, ctx.out_is_act, ctx.out_meta)]
+        dy = unflatten(ctx.out_spec, iter(grads))
+        tape = ctx.tape
+        tape.begin_backward()
+        with torch.no_grad():
+            dx = ctx.module.bwd(tape, dy, need_dx=any(ctx.in_needs))
+        dxs: List[Optional[torch.Tensor]] = []
+        if dx is not None:
+            dxs, _ = flatten(dx)
+        dxs = list(dxs) + [None] * (ctx.n_in - len(dxs))
+        dxs = [d if need else None for d, need in zip(dxs, ctx.in_needs)]
+        pg = [tape.grads.get(p) if isinstance(p, torch.nn.Parameter) else None for p in ctx.params]
+        return (None, None, None, None, *dxs, *pg)
+
+
+def run_module(module, x):
+    """nn.Module.forward of every mirrored module: through autograd when gradients are wanted, else plain fwd."""
+    ins, in_spec = flatten(x)
+    params = [p for p in module.parameters() if p.requires_grad]
+    want = torch.is_grad_enabled() and (bool(params) or any(t.requires_grad for t in ins))
+    if not want:
+        with torch.no_grad():
+            return module.fwd(x, None)
+    holder: list = []
+    outs = HipFunction.apply(module, len(ins), in_spec, holder, *ins, *params)
+    return unflatten(holder[0], iter(outs))

@@ -1,0 +1,167 @@
+"""Module-level parity on the MI355X: the mirrored core.models.common / core.models.yolo classes (HIP kernels through the
+C ABI) against golden vectors captured from the REFERENCE's own modules (tests/golden/modules.npz), forward and backward.
+
+Tolerances (max-abs error / max-abs reference, per tensor):
+  fp32 : 1e-3  (BASELINE.json: "within 1e-3 rel for fp32 conv/BN outputs"); gradients 2e-3
+  bf16 : 4e-2 forward / 8e-2 gradients against the fp32 goldens (bf16 storage of every activation, fp32 accumulate)
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, case_weights, golden
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = {torch.float32: 1e-3, torch.bfloat16: 4e-2}
+BWD_TOL = {torch.float32: 2e-3, torch.bfloat16: 8e-2}
+ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+@pytest.fixture(scope="module")
+def dsn():
+    import desenet_amd
+    from desenet_amd.core.models import common, yolo
+    assert torch.cuda.is_available()
+    return desenet_amd, common, yolo
+
+
+def _detect(yolo):
+    det = yolo.Detect(6, ANCHORS, ch=(16, 32, 64))
+    det.stride = torch.tensor([8.0, 16.0, 32.0])
+    det.anchors /= det.stride.view(-1, 1, 1)
+    return det
+
+
+CASES = {
+    # name: (factory(common, yolo), n_inputs, list_input)
+    "conv_k1": (lambda c, y: c.Conv(16, 24, 1, 1), 1, False),
+    "conv_k3s1": (lambda c, y: c.Conv(8, 16, 3, 1), 1, False),
+    "conv_k3s2": (lambda c, y: c.Conv(8, 16, 3, 2), 1, False),
+    "conv_q1": (lambda c, y: c.Conv(16, 8, 1), 1, False),
+    "conv_noact": (lambda c, y: c.Conv(8, 8, 1, 1, act=False), 1, False),
+    "focus": (lambda c, y: c.Focus(3, 16, 3), 1, False),
+    "bneck_add": (lambda c, y: c.Bottleneck(16, 16, True), 1, False),
+    "bneck_noadd": (lambda c, y: c.Bottleneck(16, 16, False), 1, False),
+    "c3_n1": (lambda c, y: c.C3(16, 16, 1), 1, False),
+    "c3_n3": (lambda c, y: c.C3(16, 32, 3), 1, False),
+    "c3_n1_noshort": (lambda c, y: c.C3(32, 16, 1, False), 1, False),
+    "spp": (lambda c, y: c.SPP(16, 16, (5, 9, 13)), 1, False),
+    "rfb2": (lambda c, y: c.RFB2(48, 16, map_reduce=6, d=[2, 3]), 1, False),
+    "pyramid": (lambda c, y: c.PyramidPooling(16, k=[1, 2, 3, 6], short_cut=True), 1, False),
+    "ffm": (lambda c, y: c.FFM(32, 16, k=3, is_cat=False), 1, False),
+    "segpsp": (lambda c, y: y.SegMaskPSP(2, 1, 24, False, ch=(16, 32, 64)), 3, True),
+    "detect": (lambda c, y: _detect(y), 3, True),
+}
+
+
+def _flat(y):
+    if torch.is_tensor(y):
+        return [y]
+    out = []
+    for e in y:
+        out.extend(_flat(e))
+    return out
+
+
+def _build(dsn, name, mode, dtype):
+    desenet_amd, common, yolo = dsn
+    from desenet_amd.core.utils.torch_utils import initialize_weights
+    factory, n_in, is_list = CASES[name]
+    g = golden("modules")
+    case = f"{name}_{mode}"
+    m = factory(common, yolo)
+    initialize_weights(m)
+    m.load_state_dict(case_weights(g, case), strict=True)
+    m = m.cuda().train(mode == "train")
+    desenet_amd.set_compute_dtype(dtype)
+    xs = [torch.from_numpy(g[f"{case}/x{j}"]).cuda() for j in range(n_in)]
+    return m, xs, is_list, g, case
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_module_eval(dsn, name, dtype):
+    m, xs, is_list, g, case = _build(dsn, name, "eval", dtype)
+    try:
+        with torch.no_grad():
+            y = m(xs) if is_list else m(xs[0])
+        for j, o in enumerate(_flat(y)):
+            assert_close(o.float().cpu(), g[f"{case}/y{j}"], FWD_TOL[dtype], f"{case} y{j}")
+    finally:
+        dsn[0].set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_module_train_fwd_bwd(dsn, name, dtype):
+    m, xs, is_list, g, case = _build(dsn, name, "train", dtype)
+    try:
+        needs_dx = name != "focus"          # the image never needs a gradient (no un-Focus kernel on the hot path)
+        xs = [x.requires_grad_(needs_dx) for x in xs]
+        y = m(xs) if is_list else m(xs[0])
+        outs = _flat(y)
+        for j, o in enumerate(outs):
+            assert_close(o.float().cpu(), g[f"{case}/y{j}"], FWD_TOL[dtype], f"{case} y{j}")
+        gys = [torch.from_numpy(g[f"{case}/gy{j}"]).cuda().to(outs[j].dtype) for j in range(len(outs))]
+        torch.autograd.backward(outs, gys)
+        tol = BWD_TOL[dtype]
+        # bf16 rounding creates ties inside the 5/9/13 max-pool windows that do not exist in the fp32 golden, so the
+        # arg-max (hence the routing of dx) legitimately differs; the tie rule itself is pinned in test_kernels_gpu.
+        if needs_dx and not (name == "spp" and dtype == torch.bfloat16):
+            for j, x in enumerate(xs):
+                assert_close(x.grad.float().cpu(), g[f"{case}/dx{j}"], tol, f"{case} dx{j}")
+        for k, p in m.named_parameters():
+            if name == "spp" and dtype == torch.bfloat16 and k.startswith("cv1."):
+                continue                      # upstream of the tie-affected pools (see above)
+            ref = g[f"{case}/dw/{k}"]
+            if ref.size == 0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{case}: {k} must stay grad-less (Q1)"
+            else:
+                assert_close(p.grad.float().cpu(), ref, tol, f"{case} dw {k}")
+        sd = m.state_dict()
+        for k in sd:
+            ak = f"{case}/after/{k}"
+            if ak in g.files:
+                assert_close(sd[k].float().cpu(), g[ak], 2e-3 if dtype == torch.float32 else 2e-2, f"{case} {k}")
+    finally:
+        dsn[0].set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("case,k,s", [("conv_k3s2_fused", 3, 2), ("conv_q1_fused", 1, 1)])
+def test_fused_conv(dsn, case, k, s):
+    """fuse_conv_and_bn + forward_fuse: the fused Q1 conv applies the folded BN, the un-fused one skips it."""
+    _, common, _ = dsn
+    from desenet_amd.core.utils.torch_utils import fuse_conv_and_bn, initialize_weights
+    g = golden("modules")
+    w = case_weights(g, case)
+    co, ci = w["conv.weight"].shape[:2]
+    m = common.Conv(ci, co, k, s)
+    initialize_weights(m)
+    m.load_state_dict(w)
+    m.conv = fuse_conv_and_bn(m.conv, m.bn)
+    delattr(m, "bn")
+    for kk, v in case_weights(g, case, "wf").items():
+        assert_close(m.state_dict()[kk], v, 1e-5, kk)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g[f"{case}/x0"]).cuda())
+    assert_close(y.cpu(), g[f"{case}/y0"], 1e-3, case)
+
+
+def test_concat_zero_copy_and_fallback(dsn):
+    _, common, _ = dsn
+    from desenet_amd import hip_ops as ops
+    g = golden("modules")
+    a, b = torch.from_numpy(g["upcat_eval/x0"]).cuda(), torch.from_numpy(g["upcat_eval/x1"]).cuda()
+    up, cat = common.Upsample(None, 2, "nearest"), common.Concat(1)
+    with torch.no_grad():
+        y = cat([up(a), b])                       # separate buffers -> copy fallback
+    assert np.array_equal(y.cpu().numpy(), g["upcat_eval/y0"])
+    buf = ops.new_act(2, 12, 10, 14, torch.float32, "cuda")
+    with torch.no_grad():
+        up.fwd(ops.as_act(a), None, buf[:, :8])
+        ops.copy(ops.as_act(b), buf[:, 8:])
+        z = cat([buf[:, :8], buf[:, 8:]])         # adjacent slices -> the covering view, no copy
+    assert z.data_ptr() == buf.data_ptr()
+    assert np.array_equal(z.cpu().numpy(), g["upcat_eval/y0"])

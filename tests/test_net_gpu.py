@@ -1,0 +1,190 @@
+"""Whole-network parity on the MI355X: mirrored Model (HIP) vs golden vectors from the reference (tests/golden/net.npz,
+train.npz) and vs the CPU oracle on the same seeded inputs.
+
+fp32 tolerance 1e-3 relative per output tensor (BASELINE.json); losses 1e-3; gradients 5e-3 at 640x640 and 2e-2 at the
+tiny 128x128 / batch-2 case (batch statistics over 8..32 samples amplify rounding).
+
+bf16 (bf16 storage of every activation, fp32 accumulation) is judged against the SAME fp32 goldens.  This random-weight,
+80-layer, batch-statistics network is chaotic in bf16: PyTorch's own CPU bf16 autocast of the oracle deviates from fp32 by
+0.18-0.53 (raw logits, max-norm relative), 0.36 (seg logits), 4% (global gradient norm) and 0.5-0.7 median per-parameter
+gradient error (measured with /tmp-style script recorded in DESIGN.md).  Whole-net bf16 bounds are therefore loose --
+eval logits 0.25, train logits 0.6, losses 3e-2, gradient norm 25% -- and the TIGHT bf16 checks live at kernel and module
+level (tests/test_kernels_gpu.py 2e-2, tests/test_modules_gpu.py 4e-2 / 8e-2)."""
+import numpy as np
+import pytest
+import torch
+
+from desenet_amd.synth import synth_images, synth_targets, synthetic_checkpoint
+from tests.util import assert_close, golden, load_cfg, rel_err, stats, subsample
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net():
+    import desenet_amd
+    from desenet_amd.core.models.yolo import Model
+    m = Model("desenet_s.yaml", ch=3, nc=6)
+    sd = m.state_dict()
+    synthetic_checkpoint(sd)
+    m.load_state_dict(sd)
+    return desenet_amd, m.cuda()
+
+
+def _outs(det, seg):
+    if isinstance(det, tuple):
+        return {"pred": det[0], "raw0": det[1][0], "raw1": det[1][1], "raw2": det[1][2], "seg": seg}
+    return {"raw0": det[0], "raw1": det[1], "raw2": det[2], "seg": seg}
+
+
+def _check(tag, det, seg, full, tol, skip=()):
+    g = golden("net")
+    for k, v in _outs(det, seg).items():
+        if k in skip:
+            continue
+        v = v.float().cpu()
+        assert list(v.shape) == [int(i) for i in g[f"{tag}/{k}/shape"]]
+        if full:
+            assert_close(v, g[f"{tag}/{k}/full"], tol, f"{tag} {k}")
+        else:
+            assert_close(subsample(v), g[f"{tag}/{k}/sub"], tol, f"{tag} {k}")
+            np.testing.assert_allclose(stats(v)[:2], g[f"{tag}/{k}/stats"][:2], rtol=50 * tol)
+
+
+CASES = [("n1_128", 1, 128, 11, True), ("n2_64x96", 2, (64, 96), 12, True), ("n1_640", 1, 640, 1, False)]
+
+
+@pytest.mark.parametrize("tag,bs,size,seed,full", CASES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 0.25)])
+def test_eval_unfused(net, tag, bs, size, seed, full, dtype, tol):
+    dsn, m = net
+    dsn.set_compute_dtype(dtype)
+    try:
+        m.eval()
+        with torch.no_grad():
+            det, seg = m(synth_images(bs, size, seed).cuda())
+        # decoded boxes ((2s)^2 * anchor, up to 1492 px) amplify bf16 logit noise; the decode itself is pinned in fp32
+        _check(f"{tag}/eval", det, seg, full, tol, skip=("pred",) if dtype == torch.bfloat16 else ())
+    finally:
+        dsn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("tag,bs,size,seed,full", CASES)
+def test_eval_fused(net, tag, bs, size, seed, full):
+    """Model.fuse(): folded state_dict equals the reference's, and the fused forward (where PyramidPooling.conv1 DOES apply
+    its folded BN, quirk Q1) matches the reference's fused forward."""
+    import copy
+    _, m = net
+    mf = copy.deepcopy(m).eval().fuse()
+    g = golden("net")
+    fsd = mf.state_dict()
+    assert sorted(fsd.keys()) == sorted(str(k) for k in g["fused_sd/keys"])
+    for k in g.files:
+        if k.startswith("fused_sd/model"):
+            assert_close(fsd[k[len("fused_sd/"):]].cpu(), g[k], 1e-5, k)
+    with torch.no_grad():
+        det, seg = mf(synth_images(bs, size, seed).cuda())
+    _check(f"{tag}/fused", det, seg, full, 1e-3)
+
+
+def test_train_forward_batch_stats(net):
+    import copy
+    _, m = net
+    mt = copy.deepcopy(m).train()
+    with torch.no_grad():
+        det, seg = mt(synth_images(2, (64, 96), 12).cuda())
+    _check("n2_64x96/train", det, seg, True, 1e-3)
+    g = golden("net")
+    sd = mt.state_dict()
+    for k in g.files:
+        if k.startswith("n2_64x96/train/after/"):
+            assert_close(sd[k.split("/after/")[1]].cpu(), g[k], 1e-3, k)
+    assert int(sd["model.0.conv.bn.num_batches_tracked"]) == 1
+
+
+def test_eval_vs_oracle_fresh_input(net):
+    """Same seeded input through the HIP model and the CPU oracle (no golden involved)."""
+    from oracle import desenet_ref as R
+    _, m = net
+    cfg = load_cfg()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = synth_images(2, (96, 160), 77)
+    with torch.no_grad():
+        rdet, rseg, _ = R.forward(cfg, sd, x)
+        m.eval()
+        det, seg = m(x.cuda())
+    assert_close(det[0].cpu(), rdet[0], 1e-3, "pred")
+    assert_close(seg.cpu(), rseg, 1e-3, "seg")
+
+
+def _train_step(dsn, m, bs, size, seed, dtype):
+    import copy
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from oracle.loss_ref import scale_hyp
+    mt = copy.deepcopy(m).train()
+    mt.hyp = dict(scale_hyp(6, size), label_smoothing=0.0)
+    dsn.set_compute_dtype(dtype)
+    try:
+        x = synth_images(bs, size, seed).cuda()
+        det_t, seg_t = synth_targets(bs, size, seed)
+        det_pred, seg_pred = mt(x)
+        det_loss, items = ComputeLoss(mt)(det_pred, det_t.cuda())
+        seg_loss = SegmentationLosses()(seg_pred, seg_t.cuda())
+        (det_loss * 0.14 + seg_loss * 1.0).backward()      # train.py:362-367, both backwards summed
+    finally:
+        dsn.set_compute_dtype(torch.float32)
+    return mt, det_loss, items, seg_loss, det_pred, seg_pred
+
+
+@pytest.mark.parametrize("tag,bs,size,seed", [("n2_128", 2, 128, 21), ("n1_640", 1, 640, 3)])
+@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 0.25)])
+def test_train_step_gradients(net, tag, bs, size, seed, dtype, ltol, gtol):
+    """G3: losses, global gradient norm, per-parameter gradient energy, selected full gradients, and the grad-less set."""
+    dsn, m = net
+    g = golden("train")
+    mt, det_loss, items, seg_loss, det_pred, seg_pred = _train_step(dsn, m, bs, size, seed, dtype)
+    assert_close(det_loss.cpu(), g[f"{tag}/det_loss"], ltol, "det_loss")
+    assert_close(items.cpu(), g[f"{tag}/loss_items"], ltol, "loss_items")
+    assert_close(seg_loss.cpu(), g[f"{tag}/seg_loss"], ltol, "seg_loss")
+    fp32 = dtype == torch.float32
+    if fp32 and tag == "n2_128":
+        gtol = 2e-2
+    if tag == "n2_128":
+        for j in range(3):
+            assert_close(det_pred[j].float().cpu(), g[f"{tag}/raw{j}"], 1e-3 if fp32 else 0.6, f"raw{j}")
+        assert_close(seg_pred.float().cpu(), g[f"{tag}/seg"], 1e-3 if fp32 else 0.6, "seg")
+    params = dict(mt.named_parameters())
+    gradless = sorted(k for k, p in params.items() if p.grad is None)
+    assert gradless == sorted(str(k) for k in g[f"{tag}/gradless"])
+    names = [str(k) for k in g[f"{tag}/grad_names"]]
+    sq = np.array([(params[k].grad.double() ** 2).sum().item() for k in names])
+    np.testing.assert_allclose(np.sqrt(sq.sum()), g[f"{tag}/grad_l2"], rtol=gtol)
+    if not fp32:
+        return
+    np.testing.assert_allclose(np.sqrt(sq), np.sqrt(g[f"{tag}/grad_sq"]), rtol=4 * gtol, atol=gtol * float(g[f"{tag}/grad_l2"]) * 1e-2)
+    for k in g.files:
+        if k.startswith(f"{tag}/grad/"):
+            name = k.split("/grad/")[1]
+            assert_close(params[name].grad.float().cpu(), g[k], gtol, name)
+
+
+def test_two_backward_calls_like_the_reference(net):
+    """scripts/train.py:366-367 calls backward twice on one forward (retain_graph=True); gradients must add up."""
+    import copy
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from oracle.loss_ref import scale_hyp
+    dsn, m = net
+    mt, *_ = _train_step(dsn, m, 2, 128, 21, torch.float32)
+    ref = {k: p.grad.clone() for k, p in mt.named_parameters() if p.grad is not None}
+    m2 = copy.deepcopy(m).train()
+    m2.hyp = dict(scale_hyp(6, 128), label_smoothing=0.0)
+    x = synth_images(2, 128, 21).cuda()
+    det_t, seg_t = synth_targets(2, 128, 21)
+    det_pred, seg_pred = m2(x)
+    det_loss, _ = ComputeLoss(m2)(det_pred, det_t.cuda())
+    seg_loss = SegmentationLosses()(seg_pred, seg_t.cuda())
+    (det_loss * 0.14).backward(retain_graph=True)
+    (seg_loss * 1.0).backward()
+    for k, p in m2.named_parameters():
+        if k in ref:
+            assert rel_err(p.grad.cpu(), ref[k].cpu()) < 1e-3, k
