@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- DeSeNet-s hot path on MI355X: images/sec (640x640).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|infer] [--dtype bf16|fp32] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+mode train (default; BASELINE.json config 3 / 4): one step = zero grads -> forward (HIP) -> det + seg loss -> backward (HIP) ->
+  [RCCL all-reduce of the flat gradient buffer] -> SGD-nesterov step, batch 8 per GPU, bf16 storage / fp32 accumulate,
+  synthetic 640x640 images + targets (seed 3 + rank), hash-filled weights.  Weak scaling: per-GPU work is fixed.
+mode infer (config 2): fused model, batch 16, fp32, forward + Detect decode + NMS (conf .25 / IoU .45 / max_det 1000).
+
+Prints ONE JSON line (rank 0).  `roofline` is the kernel with the largest share of device time in the timed region,
+measured live with HIP events recorded by the library on the launch stream (dsn_profile_*); `cpu_baseline` is the CPU
+oracle (oracle/, a PyTorch-CPU restatement of the reference graph) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"hbm_GBs": 8000.0, "mfma_bf16_TFs": 2500.0, "mfma_f32_TFs": 157.3}   # MI355X_MICROARCH.md chip-level table
+from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN  # noqa: E402  (scripts/train.py:285)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may actually use (cgroup/affinity), capped at the 16-core
+    share a one-GPU box grants."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, os.cpu_count() or n, 16))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 8 train / 16 infer)")
+    ap.add_argument("--img", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(device):
+    from desenet_amd.core.models.yolo import Model
+    from desenet_amd.synth import synthetic_checkpoint
+    m = Model("desenet_s.yaml", ch=3, nc=6)
+    sd = m.state_dict()
+    synthetic_checkpoint(sd)
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+def cpu_baseline_train(img, batch=2, budget_s=12.0):
+    """The oracle's training step (fwd + losses + bwd, fp32, NCHW, stock ATen CPU kernels) on the host cores."""
+    import yaml
+    from oracle import desenet_ref as R
+    from oracle import loss_ref
+    from desenet_amd.synth import synth_images, synth_targets, synthetic_checkpoint
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "desenet_amd", "cfg", "desenet_s.yaml")))
+    sd0 = R.make_state_dict(cfg)
+    synthetic_checkpoint(sd0)
+    is_p = lambda k: "running" not in k and "num_batches" not in k and "anchor" not in k
+    x = synth_images(batch, img, 3)
+    dt, st = synth_targets(batch, img, 3)
+
+    def step():
+        sd = {k: v.clone().requires_grad_(is_p(k)) for k, v in sd0.items()}
+        raws, seg, _ = R.forward(cfg, sd, x, training=True)
+        total, *_ = loss_ref.step_loss(raws, seg, dt, st, sd["model.25.anchors"], 6, img)
+        total.backward()
+
+    step()
+    t0 = time.perf_counter()
+    timed = 0
+    while timed < 2 or time.perf_counter() - t0 < budget_s:
+        step()
+        timed += 1
+    el = time.perf_counter() - t0
+    return {"value": batch * timed / el, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle train step (fwd+loss+bwd, fp32), batch {batch} x {timed} timed steps after 1 warm-up, "
+                      f"{img}x{img}, torch {torch.__version__} CPU, {threads} threads"}
+
+
+def cpu_baseline_infer(img, batch=2, budget_s=12.0):
+    import yaml
+    from oracle import desenet_ref as R
+    from oracle import nms_ref
+    from desenet_amd.synth import synth_images, synthetic_checkpoint
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "desenet_amd", "cfg", "desenet_s.yaml")))
+    sd = R.make_state_dict(cfg)
+    synthetic_checkpoint(sd)
+    sd = R.fold_bn(sd)
+    x = synth_images(batch, img, 2)
+
+    def step():
+        with torch.no_grad():
+            (pred, _), seg, _ = R.forward(cfg, sd, x, fused=True)
+        nms_ref.non_max_suppression(pred.numpy(), 0.25, 0.45, max_det=1000)
+
+    step()
+    t0 = time.perf_counter()
+    timed = 0
+    while timed < 2 or time.perf_counter() - t0 < budget_s:
+        step()
+        timed += 1
+    el = time.perf_counter() - t0
+    return {"value": batch * timed / el, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fused eval forward + NMS, batch {batch} x {timed} timed after 1 warm-up, {img}x{img}, "
+                      f"torch {torch.__version__} CPU, {threads} threads"}
+
+
+def roofline_from_profile(prof, steps, dtype):
+    if not prof:
+        return None, {}
+    table = {}
+    for name, r in prof.items():
+        table[name] = {"launches_per_step": r["launches"] / steps, "ms_per_step": r["ms"] / steps,
+                       "TFLOPs": (r["flops"] / (r["ms"] * 1e-3) / 1e12) if r["flops"] else None,
+                       "GBs": r["bytes"] / (r["ms"] * 1e-3) / 1e9}
+    name = max(prof, key=lambda k: prof[k]["ms"])
+    r = prof[name]
+    avg_ms = r["ms"] / r["launches"]
+    if r["flops"] > 0:
+        peak = PEAK["mfma_bf16_TFs"] if "bf16" in name else PEAK["mfma_f32_TFs"]
+        ach = r["flops"] / r["launches"] / (avg_ms * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+    else:
+        ach = r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK["hbm_GBs"], "unit": "GB/s",
+                "frac": ach / PEAK["hbm_GBs"]}
+    roof.update({"avg_launch_us": avg_ms * 1e3, "launches_per_step": r["launches"] / steps,
+                 "algorithmic_GBs": r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9, "traffic": None})
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            roof["traffic"] = json.load(open(tfile)).get(name)
+        except Exception:
+            pass
+    return roof, table
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.synth import synth_images, synth_targets
+
+    train = a.mode == "train"
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype or ("bf16" if train else "fp32")]
+    batch = a.batch or (8 if train else 16)
+    desenet_amd.set_compute_dtype(dtype)
+    model = build_model(dev)
+
+    if train:
+        from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+        from desenet_amd.parallel import FlatGradients, broadcast_parameters, sgd_param_groups
+        from desenet_amd.core.utils.hyp import scale_hyp
+        model.train()
+        model.hyp = scale_hyp(6, a.img)
+        broadcast_parameters(model)
+        flat = FlatGradients(model.parameters())
+        opt = torch.optim.SGD(sgd_param_groups(model), lr=0.01, momentum=0.937, nesterov=True)
+        compute_loss, compute_seg_loss = ComputeLoss(model), SegmentationLosses()
+        x = synth_images(batch, a.img, 3 + rank).to(dev)
+        det_t, seg_t = synth_targets(batch, a.img, 3 + rank)
+        det_t, seg_t = det_t.to(dev), seg_t.to(dev)
+
+        def step():
+            flat.zero()
+            det_pred, seg_pred = model(x)
+            det_loss, _ = compute_loss(det_pred, det_t)
+            seg_loss = compute_seg_loss(seg_pred, seg_t)
+            (det_loss * DETGAIN + seg_loss * SEGGAIN).backward()
+            flat.all_reduce()
+            opt.step()
+    else:
+        from desenet_amd.core.utils.general import non_max_suppression
+        model.eval().fuse()
+        x = synth_images(batch, a.img, 2 + rank).to(dev)
+
+        def step():
+            with torch.no_grad():
+                (pred, _), seg = model(x)
+                return non_max_suppression(pred, 0.25, 0.45, max_det=1000), seg
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}/{world}: model ready, mode={a.mode} dtype={dtype} batch={batch}; warm-up x{a.warmup}")
+    for i in range(a.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    sync()
+    log(f"timing {a.steps} steps")
+    if not a.no_profile:
+        ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = {}
+    if not a.no_profile:
+        prof = ops.profile_collect()
+        ops.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    log(f"timed region: {elapsed:.3f} s")
+    if rank == 0:
+        roof, table = roofline_from_profile(prof, a.steps, dtype)
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            log(f"CPU baseline on {host_threads()} threads ...")
+            cpu = cpu_baseline_train(a.img) if train else cpu_baseline_infer(a.img)
+        if train:
+            metric = "images/sec (640x640) train fwd+bwd"
+            workload = (f"config {'3' if world == 1 else '4'}: DeSeNet-s training step (fwd + det/seg loss + bwd + "
+                        f"{'RCCL flat all-reduce + ' if world > 1 else ''}SGD), batch {batch}/GPU, {a.img}x{a.img}")
+        else:
+            metric = "images/sec (640x640) inference fwd+NMS"
+            workload = f"config 2: DeSeNet-s fused inference (fwd + Detect decode + NMS), batch {batch}, {a.img}x{a.img}"
+        out = {
+            "metric": metric, "value": world * batch * a.steps / elapsed, "unit": "images/sec", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+            "data": "synthetic (seeded uniform images, seeded boxes/masks, hash-filled weights)",
+            "config": {"workload": workload, "batch_per_gpu": batch, "img": a.img, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": table,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

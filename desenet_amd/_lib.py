@@ -47,17 +47,22 @@ PROTOTYPES = {
     "dsn_upsample_nearest2x": (i32, [TP, TP, vp]),
     "dsn_upsample_nearest2x_bwd": (i32, [TP, TP, i32, vp]),
     "dsn_bilinear_ac": (i32, [TP, TP, i32, vp]),
-    "dsn_bilinear_ac_bwd": (i32, [TP, i32, TP, i32, vp]),
-    "dsn_adaptive_avgpool": (i32, [TP, TP, vp]),
+    "dsn_bilinear_ac_bwd": (i32, [TP, i32, TP, i32, vp, i64, vp]),
+    "dsn_window_reduce_workspace_bytes": (i64, [i32, i32, i32]),
+    "dsn_adaptive_avgpool": (i32, [TP, TP, vp, i64, vp]),
     "dsn_adaptive_avgpool_bwd": (i32, [TP, TP, i32, vp]),
     "dsn_copy": (i32, [TP, TP, i32, vp]),
     "dsn_ffm_scale": (i32, [TP, TP, TP, vp]),
-    "dsn_ffm_scale_bwd": (i32, [TP, TP, TP, TP, TP, i32, vp]),
+    "dsn_ffm_scale_bwd": (i32, [TP, TP, TP, TP, TP, i32, vp, i64, vp]),
     "dsn_detect_decode": (i32, [TP, vp, vp, i64, i64, i32, i32, f32, vp, vp]),
     "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, vp]),
     "dsn_nms_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "dsn_nms": (i32, [vp, i32, i32, i32, f32, f32, i32, i32, u64, i32, vp, vp, vp, i64, vp]),
     "dsn_cast": (i32, [vp, vp, i32, i64, vp]),
+    "dsn_profile_enable": (i32, [i32]),
+    "dsn_profile_collect": (i32, [vp, i32]),
+    "dsn_profile_kernel_count": (i32, []),
+    "dsn_profile_kernel_name": (C.c_char_p, [i32]),
 }
 
 _lib = None

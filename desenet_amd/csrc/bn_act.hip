@@ -110,18 +110,34 @@ __global__ __launch_bounds__(RED_THREADS) void reduce2_kernel(const T* __restric
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_o, float* __restrict__ rstd_o) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+// One wave per channel: the 64 lanes stride over the per-block partial rows and fold in fp64 with shuffles (fixed order ->
+// deterministic).  256-thread blocks = 4 channels per block.
+__device__ __forceinline__ void fold_rows(const float* __restrict__ partial, int nblocks, int C, int c, int lane,
+                                          double& s, double& ss) {
+    s = 0.0; ss = 0.0;
+    for (int b = lane; b < nblocks; b += 64) {
         s += (double)partial[(int64_t)b * 2 * C + c];
         ss += (double)partial[(int64_t)b * 2 * C + C + c];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        ss += __shfl_down(ss, off);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s, ss;
+    fold_rows(partial, nblocks, C, c, lane, s, ss);
+    if (lane != 0) return;
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -140,16 +156,15 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblock
 }
 
 // sums -> dgamma/dbeta (+=) and the two means the apply pass needs (written after the partial rows)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double count,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                       float* __restrict__ means) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                              double count, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ means) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s += (double)partial[(int64_t)b * 2 * C + c];
-        ss += (double)partial[(int64_t)b * 2 * C + C + c];
-    }
+    double s, ss;
+    fold_rows(partial, nblocks, C, c, lane, s, ss);
+    if (lane != 0) return;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)ss : (float)ss;
     means[c] = (float)(s / count);
@@ -216,8 +231,8 @@ inline int ew_grid(int64_t total) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 inline int red_blocks(int64_t P) {
-    int64_t b = (P + 127) / 128;
-    return (int)(b < 1 ? 1 : (b > MAX_RED_BLOCKS ? MAX_RED_BLOCKS : b));
+    int64_t b = (P + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 inline bool vec4_ok(const dsn_tensor* t) {
     const int es = t->dtype == DSN_F32 ? 4 : 2;
@@ -243,6 +258,9 @@ extern "C" int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float
     hipStream_t st = (hipStream_t)stream;
     const bool v4 = vec4_ok(y);
     DSN_CHECK_ARG(v4 || y->c <= RED_THREADS, "bn_stats: C=%d needs C%%4==0 or C<=256", y->c);
+    const double esz = y->dtype == DSN_F32 ? 4.0 : 2.0;
+    {
+    ProfScope prof(KID_BN_STATS, 0.0, (double)P * y->c * esz, st);
     DSN_DISPATCH_DTYPE(y->dtype, T, {
         if (v4)
             hipLaunchKernelGGL((reduce2_kernel<T, 4, false, StatsF>), dim3(nb), dim3(RED_THREADS), 0, st,
@@ -251,8 +269,9 @@ extern "C" int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float
             hipLaunchKernelGGL((reduce2_kernel<T, 1, false, StatsF>), dim3(nb), dim3(RED_THREADS), 0, st,
                                (const T*)y->ptr, y->ldc, (const T*)nullptr, (int64_t)0, P, y->c, partial, StatsF{});
     });
+    }
     DSN_LAUNCH_CHECK("bn_stats reduce");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(y->c, 128)), dim3(128), 0, st, partial, nb, y->c, (double)P, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(y->c, 4)), dim3(256), 0, st, partial, nb, y->c, (double)P, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
     DSN_LAUNCH_CHECK("bn_stats finalize");
     return DSN_OK;
@@ -266,6 +285,7 @@ extern "C" int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const flo
     const int64_t P = npix(y);
     const bool v4 = vec4_ok(y) && vec4_ok(z) && (!residual || vec4_ok(residual));
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(KID_BN_ACT_FWD, 0.0, (double)P * y->c * (y->dtype == DSN_F32 ? 4.0 : 2.0) * (residual ? 3 : 2), st);
     DSN_DISPATCH_DTYPE(y->dtype, T, {
         const T* r = residual ? (const T*)residual->ptr : nullptr;
         const int64_t rld = residual ? residual->ldc : 0;
@@ -296,6 +316,9 @@ extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const f
     const bool v4 = vec4_ok(y) && vec4_ok(dz) && vec4_ok(dy);
     DSN_CHECK_ARG(v4 || y->c <= RED_THREADS, "bn_act_bwd: C=%d needs C%%4==0 or C<=256", y->c);
     BwdF f{scale, shift, mean, rstd, act};
+    const double esz = y->dtype == DSN_F32 ? 4.0 : 2.0;
+    {
+    ProfScope prof(KID_BN_BWD_REDUCE, 0.0, 2.0 * P * y->c * esz, st);
     DSN_DISPATCH_DTYPE(y->dtype, T, {
         if (v4)
             hipLaunchKernelGGL((reduce2_kernel<T, 4, true, BwdF>), dim3(nb), dim3(RED_THREADS), 0, st, (const T*)y->ptr,
@@ -304,10 +327,12 @@ extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const f
             hipLaunchKernelGGL((reduce2_kernel<T, 1, true, BwdF>), dim3(nb), dim3(RED_THREADS), 0, st, (const T*)y->ptr,
                                y->ldc, (const T*)dz->ptr, dz->ldc, P, y->c, partial, f);
     });
+    }
     DSN_LAUNCH_CHECK("bn_act_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(y->c, 128)), dim3(128), 0, st, partial, nb, y->c, (double)P,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(y->c, 4)), dim3(256), 0, st, partial, nb, y->c, (double)P,
                        dgamma, dbeta, accumulate, means);
     DSN_LAUNCH_CHECK("bn_act_bwd finalize");
+    ProfScope prof2(KID_BN_BWD_APPLY, 0.0, 3.0 * P * y->c * esz, st);
     DSN_DISPATCH_DTYPE(y->dtype, T, {
         if (v4)
             hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 4>), dim3(ew_grid(P * (y->c / 4))), dim3(256), 0, st,

@@ -83,3 +83,21 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
             __VA_ARGS__;                               \
         }                                              \
     } while (0)
+
+// ---- optional live profiler: HIP events recorded on the launch stream around the hot kernels (bench.py roofline) ----
+enum {
+    KID_IGEMM = 0,            // + dtype*20 + cfg*2 + is_dgrad   (cfg 0..4 -> 128x128, 128x64, 64x64, 128x32, 64x16)
+    KID_WGRAD = 40,           // + dtype
+    KID_WGRAD_REDUCE = 42,
+    KID_BN_STATS = 43,
+    KID_BN_ACT_FWD = 44,
+    KID_BN_BWD_REDUCE = 45,
+    KID_BN_BWD_APPLY = 46,
+    KID_COUNT = 47
+};
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(int kid, double flops, double bytes, hipStream_t stream);
+    ~ProfScope();
+};

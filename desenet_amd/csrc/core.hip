@@ -10,6 +10,73 @@ void dsn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- live profiler -------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfEntry { hipEvent_t a, b; int kid; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;
+size_t g_prof_used = 0;
+}
+ProfScope::ProfScope(int kid, double flops, double bytes, hipStream_t stream) : slot(-1), st(stream) {
+    if (!g_prof_on) return;
+    if (g_prof_used == g_prof.size()) {
+        ProfEntry e{};
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        g_prof.push_back(e);
+    }
+    slot = (int)g_prof_used++;
+    g_prof[slot].kid = kid; g_prof[slot].flops = flops; g_prof[slot].bytes = bytes;
+    (void)hipEventRecord(g_prof[slot].a, st);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+
+extern "C" int dsn_profile_enable(int32_t on) {
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return DSN_OK;
+}
+
+// Aggregates per kernel id since dsn_profile_enable(1): out[kid] = {launches, total_ms, total_flops, total_bytes}.
+extern "C" int dsn_profile_collect(double* out /* [KID_COUNT][4] */, int32_t n_kids) {
+    DSN_CHECK_ARG(out && n_kids >= KID_COUNT, "profile_collect: need room for %d kernel ids", KID_COUNT);
+    for (int i = 0; i < n_kids * 4; ++i) out[i] = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_prof[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b);
+        if (e != hipSuccess) DSN_FAIL((int)e, "profile_collect: %s", hipGetErrorString(e));
+        double* o = out + 4 * g_prof[i].kid;
+        o[0] += 1.0; o[1] += ms; o[2] += g_prof[i].flops; o[3] += g_prof[i].bytes;
+    }
+    g_prof_used = 0;
+    return DSN_OK;
+}
+
+extern "C" int32_t dsn_profile_kernel_count(void) { return KID_COUNT; }
+
+extern "C" const char* dsn_profile_kernel_name(int32_t kid) {
+    static thread_local char buf[64];
+    static const char* cfg[5] = {"128x128", "128x64", "64x64", "128x32", "64x16"};
+    if (kid >= KID_IGEMM && kid < KID_WGRAD) {
+        const int dt = kid / 20, c = (kid % 20) / 2, dg = kid & 1;
+        snprintf(buf, sizeof(buf), "igemm_%s_%s_%s", dt ? "bf16" : "f32", c < 5 ? cfg[c] : "?", dg ? "dgrad" : "fwd");
+        return buf;
+    }
+    switch (kid) {
+        case KID_WGRAD: return "wgrad_f32";
+        case KID_WGRAD + 1: return "wgrad_bf16";
+        case KID_WGRAD_REDUCE: return "wgrad_reduce";
+        case KID_BN_STATS: return "bn_stats_reduce";
+        case KID_BN_ACT_FWD: return "bn_act_fwd";
+        case KID_BN_BWD_REDUCE: return "bn_act_bwd_reduce";
+        case KID_BN_BWD_APPLY: return "bn_act_bwd_apply";
+    }
+    return "?";
+}
+
 extern "C" int dsn_version(void) { return DSN_VERSION; }
 extern "C" const char* dsn_last_error(void) { return g_err; }
 

@@ -31,6 +31,7 @@ struct Geom {
     int32_t act, accumulate;
     int64_t sld, dld, rld;
     int32_t tiles_m, tiles_n;
+    int32_t is_dgrad;
 };
 
 template <typename T> struct Mma;
@@ -228,9 +229,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 template <typename T, int MI, int NI, int WGM, int WGN>
 int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, Geom g, bool vec, hipStream_t st) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
+                        : (BM == 128 && BN == 32) ? 3 : 4;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.Cd + BN - 1) / BN;
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    // algorithmic work of this launch: every source/destination element and every weight touched once
+    const double K = (double)g.KH * g.KW * g.Cs;
+    const double src_elems = (double)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws * g.Cs;
+    const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd;
+    ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0),
+                   2.0 * g.M * g.Cd * K, elems * sizeof(T), st);
     if (vec)
         hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true>), grid, block, 0, st, src, w, bias, res, dst, g);
     else
@@ -304,7 +313,7 @@ extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_t
     g.Hs = dy->h; g.Ws = dy->w; g.Cs = dy->c; g.Cd = dx->c;
     g.KH = p->kh; g.KW = p->kw;
     g.a = 1; g.b = p->pad; g.d = -p->dil; g.q = p->stride;
-    g.act = DSN_ACT_NONE; g.accumulate = p->accumulate;
+    g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
     if (dy->dtype == DSN_F32) return launch<float>(dy, w, nullptr, nullptr, dx, g, (hipStream_t)stream);
     return launch<bf16_t>(dy, w, nullptr, nullptr, dx, g, (hipStream_t)stream);

@@ -225,36 +225,6 @@ __global__ void bilinear_bwd_kernel(const void* __restrict__ dyv, int64_t yld, T
 __device__ __forceinline__ int bin_lo(int o, int in, int k) { return (o * in) / k; }
 __device__ __forceinline__ int bin_hi(int o, int in, int k) { return ((o + 1) * in + k - 1) / k; }
 
-// one block per (n, oh, ow); thread (ty, tx): tx = channel, ty strides the window's pixels; LDS fold.
-template <typename T>
-__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y,
-                                                               int64_t yld, int H, int W, int C, int KH, int KW) {
-    __shared__ float red[256];
-    const int b = blockIdx.x;
-    const int ow = b % KW, oh = (b / KW) % KH, n = b / (KW * KH);
-    const int h0 = bin_lo(oh, H, KH), h1 = bin_hi(oh, H, KH), w0 = bin_lo(ow, W, KW), w1 = bin_hi(ow, W, KW);
-    const int ww = w1 - w0, cnt = (h1 - h0) * ww;
-    const int TX = C < 256 ? C : 256, TY = 256 / TX;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    for (int c0 = 0; c0 < C; c0 += TX) {
-        const int c = c0 + tx;
-        float s = 0.f;
-        if (ty < TY && c < C)
-            for (int q = ty; q < cnt; q += TY) {
-                const int hh = h0 + q / ww, wq = w0 + q % ww;
-                s += to_f32<T>(x[(((int64_t)n * H + hh) * W + wq) * xld + c]);
-            }
-        __syncthreads();
-        if (ty < TY) red[ty * TX + tx] = s;
-        __syncthreads();
-        if (ty == 0 && c < C) {
-            float tot = 0.f;
-            for (int t = 0; t < TY; ++t) tot += red[t * TX + tx];
-            y[(((int64_t)n * KH + oh) * KW + ow) * yld + c] = from_f32<T>(tot / (float)cnt);
-        }
-    }
-}
-
 template <typename T>
 __global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld,
                                             int N, int H, int W, int C, int KH, int KW, int accumulate) {
@@ -310,32 +280,103 @@ __global__ void ffm_scale_bwd_feat_kernel(const T* __restrict__ dout, int64_t dl
         *o = from_f32<T>(s);
     }
 }
-// datt[n][c] = sum_hw dout*feat : one block per image, same (ty, tx) fold as the pools
-template <typename T>
-__global__ __launch_bounds__(256) void ffm_scale_bwd_att_kernel(const T* __restrict__ dout, int64_t dld,
-                                                                const T* __restrict__ f, int64_t fld,
-                                                                T* __restrict__ datt, int64_t ald, int64_t HW, int C) {
+// ---- split window reductions ----------------------------------------------------------------------------------------------
+// out[seg][c] = sum over a 2-D pixel window of  w(pixel) * x[pixel][c] (* y[pixel][c])  for a handful of segments (pyramid
+// bins, whole images, the few source pixels of a tiny bilinear input).  A segment is far too much work for one block and
+// there are far too few segments to fill 256 CUs, so every segment is split over S blocks by window rows; each block folds
+// its share through LDS ((ty, tx) layout: tx = channel, coalesced) and writes one fp32 partial row; a second tiny kernel
+// adds the S rows in order (deterministic, no atomics).
+enum { WR_AVGPOOL = 0, WR_FFM_ATT = 1, WR_BILINEAR_BWD = 2 };
+struct WRGeom {
+    int32_t N, H, W, C;       // the big map (pool input / feat / dy of the bilinear)
+    int32_t KH, KW;           // the small map (pool output / 1x1 / dx of the bilinear)
+    int32_t S;
+    float sh, sw;             // bilinear scales
+    int64_t xld, yld;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                            float* __restrict__ partial, const WRGeom g) {
     __shared__ float red[256];
-    const int n = blockIdx.x;
-    const int TX = C < 256 ? C : 256, TY = 256 / TX;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    for (int c0 = 0; c0 < C; c0 += TX) {
-        const int c = c0 + tx;
-        float s = 0.f;
-        if (ty < TY && c < C)
-            for (int64_t q = ty; q < HW; q += TY) {
-                const int64_t p = (int64_t)n * HW + q;
-                s += to_f32<T>(dout[p * dld + c]) * to_f32<T>(f[p * fld + c]);
-            }
-        __syncthreads();
-        if (ty < TY) red[ty * TX + tx] = s;
-        __syncthreads();
-        if (ty == 0 && c < C) {
-            float tot = 0.f;
-            for (int t = 0; t < TY; ++t) tot += red[t * TX + tx];
-            datt[(int64_t)n * ald + c] = from_f32<T>(tot);
+    const int s = blockIdx.x % g.S;
+    const int seg = blockIdx.x / g.S;
+    const int kw = seg % g.KW, kh = (seg / g.KW) % g.KH, n = seg / (g.KW * g.KH);
+    int h0 = 0, h1 = g.H, w0 = 0, w1 = g.W;
+    float inv = 1.f;
+    if (MODE == WR_AVGPOOL) {
+        h0 = bin_lo(kh, g.H, g.KH); h1 = bin_hi(kh, g.H, g.KH);
+        w0 = bin_lo(kw, g.W, g.KW); w1 = bin_hi(kw, g.W, g.KW);
+        inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+    } else if (MODE == WR_BILINEAR_BWD) {
+        if (g.sh > 0.f) {
+            h0 = (int)floorf((float)(kh - 1) / g.sh) - 1; h1 = (int)ceilf((float)(kh + 1) / g.sh) + 2;
+            h0 = h0 < 0 ? 0 : h0; h1 = h1 > g.H ? g.H : h1;
+        }
+        if (g.sw > 0.f) {
+            w0 = (int)floorf((float)(kw - 1) / g.sw) - 1; w1 = (int)ceilf((float)(kw + 1) / g.sw) + 2;
+            w0 = w0 < 0 ? 0 : w0; w1 = w1 > g.W ? g.W : w1;
         }
     }
+    const int ww = w1 - w0;
+    const int TX = g.C < 256 ? g.C : 256, TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    float* out = partial + (int64_t)blockIdx.x * g.C;
+    for (int c0 = 0; c0 < g.C; c0 += TX) {
+        const int c = c0 + tx;
+        float acc = 0.f;
+        if (ty < TY && c < g.C) {
+            for (int hh = h0 + s; hh < h1; hh += g.S) {
+                float wh = 1.f;
+                if (MODE == WR_BILINEAR_BWD) {
+                    const Lerp a = lerp_coord(hh, g.sh, g.KH);
+                    wh = (a.i0 == kh ? a.l0 : 0.f) + (a.i1 == kh ? a.l1 : 0.f);
+                    if (wh == 0.f) continue;
+                }
+                for (int q = ty; q < ww; q += TY) {
+                    const int wq = w0 + q;
+                    float wgt = wh;
+                    if (MODE == WR_BILINEAR_BWD) {
+                        const Lerp b = lerp_coord(wq, g.sw, g.KW);
+                        wgt *= (b.i0 == kw ? b.l0 : 0.f) + (b.i1 == kw ? b.l1 : 0.f);
+                    }
+                    const int64_t p = ((int64_t)n * g.H + hh) * g.W + wq;
+                    float v = to_f32<T>(x[p * g.xld + c]);
+                    if (MODE == WR_FFM_ATT) v *= to_f32<T>(y[p * g.yld + c]);
+                    acc += wgt * v;
+                }
+            }
+        }
+        __syncthreads();
+        if (ty < TY) red[ty * TX + tx] = acc;
+        __syncthreads();
+        if (ty == 0 && c < g.C) {
+            float tot = 0.f;
+            for (int t = 0; t < TY; ++t) tot += red[t * TX + tx];
+            out[c] = tot * inv;
+        }
+    }
+}
+
+template <typename T>
+__global__ void window_finalize_kernel(const float* __restrict__ partial, int S, int64_t nseg, int C, T* __restrict__ out,
+                                       int64_t old_, int accumulate) {
+    const int64_t total = nseg * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t seg = i / C;
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += partial[(seg * S + k) * C + c];
+        T* o = out + seg * old_ + c;
+        if (accumulate) v += to_f32<T>(*o);
+        *o = from_f32<T>(v);
+    }
+}
+
+inline int wr_splits(int64_t nseg, int rows) {
+    int64_t s = (768 + nseg - 1) / nseg;
+    if (s > rows) s = rows;
+    return (int)(s < 1 ? 1 : s);
 }
 
 inline bool same_nhwc(const dsn_tensor* a, const dsn_tensor* b) {
@@ -427,7 +468,7 @@ extern "C" int dsn_bilinear_ac(const dsn_tensor* x, const dsn_tensor* y, int32_t
 }
 
 extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const dsn_tensor* dx, int32_t accumulate,
-                                   void* stream) {
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     DSN_CHECK_ARG(tensor_ok(dx) && dy && dy->ptr && dy->n == dx->n && dy->c == dx->c && dy->h > 0 && dy->w > 0,
                   "bilinear_ac_bwd: invalid arguments");
     DSN_CHECK_ARG(dy_nchw ? (dy->dtype == DSN_F32) : (dy->dtype == dx->dtype),
@@ -435,6 +476,22 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
     const float sh = ac_scale(dx->h, dy->h), sw = ac_scale(dx->w, dy->w);
     const int64_t total = npix(dx) * dx->c;
     hipStream_t st = (hipStream_t)stream;
+    // tiny source maps (PyramidPooling: 1..6 pixels a side feeding 80x80): every source pixel gathers a large window ->
+    // split reduction instead of one thread per element
+    const int64_t nseg = npix(dx);
+    if (!dy_nchw && (int64_t)dx->h * dx->w <= 64 && workspace) {
+        WRGeom g{dy->n, dy->h, dy->w, dy->c, dx->h, dx->w, wr_splits(nseg, dy->h), sh, sw, dy->ldc, 0};
+        if (workspace_bytes < nseg * g.S * dx->c * (int64_t)sizeof(float))
+            DSN_FAIL(DSN_EWORKSPACE, "bilinear_ac_bwd: workspace too small");
+        DSN_DISPATCH_DTYPE(dx->dtype, T, {
+            hipLaunchKernelGGL((window_reduce_kernel<T, WR_BILINEAR_BWD>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                               (const T*)dy->ptr, (const T*)nullptr, (float*)workspace, g);
+            hipLaunchKernelGGL(window_finalize_kernel<T>, dim3(ew_grid(nseg * dx->c)), dim3(256), 0, st,
+                               (const float*)workspace, g.S, nseg, dx->c, (T*)dx->ptr, dx->ldc, accumulate);
+        });
+        DSN_LAUNCH_CHECK("bilinear_ac_bwd (split)");
+        return DSN_OK;
+    }
     DSN_DISPATCH_DTYPE(dx->dtype, T, {
         if (dy_nchw)
             hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, st, dy->ptr, dy->ldc,
@@ -448,13 +505,25 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
     return DSN_OK;
 }
 
-extern "C" int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* stream) {
+extern "C" int64_t dsn_window_reduce_workspace_bytes(int32_t n_segments, int32_t rows, int32_t c) {
+    return (int64_t)n_segments * wr_splits(n_segments, rows) * c * (int64_t)sizeof(float);
+}
+
+extern "C" int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
     DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(y) && x->dtype == y->dtype && x->n == y->n && x->c == y->c,
                   "adaptive_avgpool: invalid arguments");
-    DSN_DISPATCH_DTYPE(x->dtype, T,
-                       hipLaunchKernelGGL(adaptive_avgpool_kernel<T>, dim3(y->n * y->h * y->w), dim3(256), 0,
-                                          (hipStream_t)stream, (const T*)x->ptr, x->ldc, (T*)y->ptr, y->ldc, x->h, x->w,
-                                          x->c, y->h, y->w));
+    const int64_t nseg = (int64_t)y->n * y->h * y->w;
+    WRGeom g{x->n, x->h, x->w, x->c, y->h, y->w, wr_splits(nseg, x->h), 0.f, 0.f, x->ldc, 0};
+    if (!workspace || workspace_bytes < nseg * g.S * x->c * (int64_t)sizeof(float))
+        DSN_FAIL(DSN_EWORKSPACE, "adaptive_avgpool: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    DSN_DISPATCH_DTYPE(x->dtype, T, {
+        hipLaunchKernelGGL((window_reduce_kernel<T, WR_AVGPOOL>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                           (const T*)x->ptr, (const T*)nullptr, (float*)workspace, g);
+        hipLaunchKernelGGL(window_finalize_kernel<T>, dim3(ew_grid(nseg * x->c)), dim3(256), 0, st,
+                           (const float*)workspace, g.S, nseg, x->c, (T*)y->ptr, y->ldc, 0);
+    });
     DSN_LAUNCH_CHECK("adaptive_avgpool");
     return DSN_OK;
 }
@@ -485,16 +554,23 @@ extern "C" int dsn_ffm_scale(const dsn_tensor* feat, const dsn_tensor* att, cons
 }
 
 extern "C" int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat, const dsn_tensor* att,
-                                 const dsn_tensor* dfeat, const dsn_tensor* datt, int32_t accumulate, void* stream) {
+                                 const dsn_tensor* dfeat, const dsn_tensor* datt, int32_t accumulate, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
     DSN_CHECK_ARG(tensor_ok(dout) && tensor_ok(feat) && tensor_ok(att) && tensor_ok(dfeat) && tensor_ok(datt) &&
                       same_nhwc(dout, feat) && same_nhwc(dfeat, feat) && same_nhwc(att, datt) && att->n == feat->n &&
                       att->h == 1 && att->w == 1 && att->c == feat->c && att->dtype == feat->dtype,
                   "ffm_scale_bwd: invalid arguments");
     const int64_t P = npix(feat), HW = (int64_t)feat->h * feat->w;
     hipStream_t st = (hipStream_t)stream;
+    const int64_t nseg = feat->n;
+    WRGeom g{feat->n, feat->h, feat->w, feat->c, 1, 1, wr_splits(nseg, feat->h), 0.f, 0.f, dout->ldc, feat->ldc};
+    if (!workspace || workspace_bytes < nseg * g.S * feat->c * (int64_t)sizeof(float))
+        DSN_FAIL(DSN_EWORKSPACE, "ffm_scale_bwd: workspace too small");
     DSN_DISPATCH_DTYPE(feat->dtype, T, {
-        hipLaunchKernelGGL(ffm_scale_bwd_att_kernel<T>, dim3(feat->n), dim3(256), 0, st, (const T*)dout->ptr, dout->ldc,
-                           (const T*)feat->ptr, feat->ldc, (T*)datt->ptr, datt->ldc, HW, feat->c);
+        hipLaunchKernelGGL((window_reduce_kernel<T, WR_FFM_ATT>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                           (const T*)dout->ptr, (const T*)feat->ptr, (float*)workspace, g);
+        hipLaunchKernelGGL(window_finalize_kernel<T>, dim3(ew_grid(nseg * feat->c)), dim3(256), 0, st,
+                           (const float*)workspace, g.S, nseg, feat->c, (T*)datt->ptr, datt->ldc, 0);
         hipLaunchKernelGGL(ffm_scale_bwd_feat_kernel<T>, dim3(ew_grid(P * feat->c)), dim3(256), 0, st,
                            (const T*)dout->ptr, dout->ldc, (const T*)att->ptr, att->ldc, (T*)dfeat->ptr, dfeat->ldc, HW,
                            P, feat->c, accumulate);

@@ -256,14 +256,19 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     const bool vl = (g.Co % vec == 0) && (g.Ci % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
                     ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
     dim3 grid(g.tiles_ci * g.tiles_co * g.KH * g.KW * g.S), block(256);
+    {
+    ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), 2.0 * g.P * g.Co * g.Ci * g.KH * g.KW,
+                   ((double)npix(x) * g.Ci + (double)g.P * g.Co) * es + (double)n_out * 4, st);
     DSN_DISPATCH_DTYPE(x->dtype, T, {
         if (vl)
             hipLaunchKernelGGL((wgrad_kernel<T, true>), grid, block, 0, st, (const T*)x->ptr, (const T*)dy->ptr, out, g);
         else
             hipLaunchKernelGGL((wgrad_kernel<T, false>), grid, block, 0, st, (const T*)x->ptr, (const T*)dy->ptr, out, g);
     });
+    }
     DSN_LAUNCH_CHECK("conv wgrad");
     if (g.S > 1) {
+        ProfScope prof(KID_WGRAD_REDUCE, 0.0, (double)(g.S + 1) * n_out * 4, st);
         int64_t b = (n_out + 255) / 256;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(b > 2048 ? 2048 : b)), dim3(256), 0, st, out, dw, n_out, g.S,
                            p->accumulate);

@@ -259,17 +259,27 @@ def bilinear_ac(x, y, out_nchw=False):
     return y
 
 
+def _wr_ws(nseg, rows, c, device):
+    nbytes = _lib.lib().dsn_window_reduce_workspace_bytes(nseg, rows, c)
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
+
+
 def bilinear_ac_bwd(dy, dx, dy_nchw=False, accumulate=False):
     a = _desc_nchw(dy) if dy_nchw else desc(dy)
     b = desc(dx)
-    _lib.check(_lib.lib().dsn_bilinear_ac_bwd(C.byref(a), int(dy_nchw), C.byref(b), int(accumulate), stream_ptr()),
-               "bilinear_ac_bwd")
+    ws, nbytes = None, 0
+    if not dy_nchw and dx.shape[2] * dx.shape[3] <= 64:
+        ws, nbytes = _wr_ws(dx.shape[0] * dx.shape[2] * dx.shape[3], dy.shape[2], dx.shape[1], dx.device)
+    _lib.check(_lib.lib().dsn_bilinear_ac_bwd(C.byref(a), int(dy_nchw), C.byref(b), int(accumulate), _p(ws), nbytes,
+                                              stream_ptr()), "bilinear_ac_bwd")
     return dx
 
 
 def adaptive_avgpool(x, y):
     a, b = desc(x), desc(y)
-    _lib.check(_lib.lib().dsn_adaptive_avgpool(C.byref(a), C.byref(b), stream_ptr()), "adaptive_avgpool")
+    ws, nbytes = _wr_ws(y.shape[0] * y.shape[2] * y.shape[3], x.shape[2], x.shape[1], x.device)
+    _lib.check(_lib.lib().dsn_adaptive_avgpool(C.byref(a), C.byref(b), ws.data_ptr(), nbytes, stream_ptr()),
+               "adaptive_avgpool")
     return y
 
 
@@ -294,8 +304,9 @@ def ffm_scale(feat, att, out):
 
 def ffm_scale_bwd(dout, feat, att, dfeat, datt, accumulate=False):
     a, b, c, d, e = desc(dout), desc(feat), desc(att), desc(dfeat), desc(datt)
+    ws, nbytes = _wr_ws(feat.shape[0], feat.shape[2], feat.shape[1], feat.device)
     _lib.check(_lib.lib().dsn_ffm_scale_bwd(C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), int(accumulate),
-                                            stream_ptr()), "ffm_scale_bwd")
+                                            ws.data_ptr(), nbytes, stream_ptr()), "ffm_scale_bwd")
     return dfeat, datt
 
 
@@ -342,4 +353,23 @@ def cast(src: torch.Tensor, dtype) -> torch.Tensor:
         s = s.float().contiguous()
     out = torch.empty(s.shape, dtype=dtype, device=s.device)
     _lib.check(_lib.lib().dsn_cast(s.data_ptr(), out.data_ptr(), _DT[dtype], s.numel(), stream_ptr()), "cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ live profiler
+def profile_enable(on: bool):
+    _lib.check(_lib.lib().dsn_profile_enable(int(on)), "profile_enable")
+
+
+def profile_collect():
+    """{kernel name: dict(launches, ms, flops, bytes)} for every kernel launched since profile_enable(True)."""
+    L = _lib.lib()
+    n = L.dsn_profile_kernel_count()
+    buf = (C.c_double * (4 * n))()
+    _lib.check(L.dsn_profile_collect(C.cast(buf, C.c_void_p), n), "profile_collect")
+    out = {}
+    for k in range(n):
+        if buf[4 * k] > 0:
+            out[L.dsn_profile_kernel_name(k).decode()] = dict(launches=int(buf[4 * k]), ms=buf[4 * k + 1],
+                                                               flops=buf[4 * k + 2], bytes=buf[4 * k + 3])
     return out

@@ -130,8 +130,11 @@ int dsn_upsample_nearest2x(const dsn_tensor* x, const dsn_tensor* y, void* strea
 int dsn_upsample_nearest2x_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream);
 int dsn_bilinear_ac(const dsn_tensor* x, const dsn_tensor* y, int32_t out_nchw, void* stream);
 int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const dsn_tensor* dx, int32_t accumulate,
-                        void* stream);
-int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* stream);
+                        void* workspace, int64_t workspace_bytes, void* stream);
+/* split reductions (few segments, large windows): workspace = dsn_window_reduce_workspace_bytes(segments, window rows, C);
+ * segments = N*k*k (avgpool), N*Hi*Wi (bilinear bwd from a <= 64-pixel source; workspace may be NULL otherwise), N (FFM) */
+int64_t dsn_window_reduce_workspace_bytes(int32_t n_segments, int32_t rows, int32_t c);
+int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* workspace, int64_t workspace_bytes, void* stream);
 int dsn_adaptive_avgpool_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream);
 int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumulate, void* stream);
 
@@ -139,7 +142,8 @@ int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumulate, void*
 int dsn_ffm_scale(const dsn_tensor* feat, const dsn_tensor* att, const dsn_tensor* out, void* stream);
 /* dfeat (+)= dout*(1+att);  datt[n,c] = sum_hw dout*feat */
 int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat, const dsn_tensor* att,
-                      const dsn_tensor* dfeat, const dsn_tensor* datt, int32_t accumulate, void* stream);
+                      const dsn_tensor* dfeat, const dsn_tensor* datt, int32_t accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* ---- Detect head (yolo.py:255-277) ------------------------------------------------------------------------------
  * t: conv output of level i, NHWC [N,ny,nx,na*no].  raw: contiguous fp32 [N,na,ny,nx,no] (the training output and
@@ -167,6 +171,14 @@ int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, float conf_thr
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 /* dst[i] = (dtype) src[i]  (flat fp32 master -> bf16 copy) */
 int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream);
+
+/* ---- live profiler (bench.py roofline): HIP events recorded on the launch stream around the hot kernels ------------
+ * dsn_profile_enable(1) starts recording, (0) stops; dsn_profile_collect waits for the recorded events and returns, per
+ * kernel id, {launches, total_ms, total_algorithmic_flops, total_algorithmic_bytes}. */
+int         dsn_profile_enable(int32_t on);
+int         dsn_profile_collect(double* out /* [kernel_count][4] */, int32_t kernel_count);
+int32_t     dsn_profile_kernel_count(void);
+const char* dsn_profile_kernel_name(int32_t kid);
 
 #ifdef __cplusplus
 }
