@@ -21,6 +21,11 @@ class dsn_conv_params(C.Structure):
                 ("act", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class dsn_pack_desc(C.Structure):
+    _fields_ = [("w_oihw", C.c_void_p), ("out_fwd", C.c_void_p), ("out_dgrad", C.c_void_p), ("co", C.c_int32),
+                ("ci", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("ci_pad", C.c_int32), ("reserved", C.c_int32)]
+
+
 TP = C.POINTER(dsn_tensor)
 CP = C.POINTER(dsn_conv_params)
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
@@ -32,9 +37,11 @@ PROTOTYPES = {
     "dsn_conv2d_fwd": (i32, [TP, vp, vp, TP, TP, CP, vp]),
     "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
     "dsn_conv2d_wgrad_workspace_bytes": (i64, [TP, TP, CP, i32]),
-    "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, CP, vp, i64, vp]),
+    "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
     "dsn_pack_weight_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dsn_pack_chunk": (i32, []),
+    "dsn_pack_weights_multi": (i32, [vp, vp, i32, i32, vp]),
     "dsn_unpack_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_bn_workspace_bytes": (i64, [i32]),
     "dsn_bn_stats": (i32, [TP, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i64, vp]),

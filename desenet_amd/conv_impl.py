@@ -117,8 +117,8 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     elif train_bn:
         scale, shift, mean, rstd = ops.bn_stats(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                                 bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
+            bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
         ops.bn_act_fwd(y, scale, shift, act, residual, out)
         rec.update(scale=scale, shift=shift, mean=mean, rstd=rstd, frozen=False)
     else:
@@ -132,6 +132,16 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     if tape is not None:
         tape.push(rec)
     return out
+
+
+def _grad_slot(p):
+    """The parameter's existing fp32 contiguous .grad (kernels then accumulate into it directly), else None."""
+    if p is None or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g
 
 
 def _channel_sum(t):
@@ -155,19 +165,28 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
         raise NotImplementedError("backward through eval-mode BatchNorm is not part of the DeSeNet training path")
     else:
         dy = ops.new_act(*y.shape, dtype, y.device)
-        dg = torch.empty_like(rec["scale"])
-        db = torch.empty_like(rec["scale"])
-        ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, dg, db)
-        tape.add_grad(bn.weight, dg)
-        tape.add_grad(bn.bias, db)
+        # gradient accumulation straight into existing .grad storage (FlatGradients views): no temporaries, no add kernels
+        gw, gb = _grad_slot(bn.weight), _grad_slot(bn.bias)
+        direct = gw is not None and gb is not None
+        dg = gw if direct else torch.empty_like(rec["scale"])
+        db = gb if direct else torch.empty_like(rec["scale"])
+        ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, dg, db, accumulate=direct)
+        if not direct:
+            tape.add_grad(bn.weight, dg)
+            tape.add_grad(bn.bias, db)
     if conv.weight.requires_grad:
         co, ci, kh, kw = conv.weight.shape
-        cip = rec["ci_pad"] or ci
-        dwp = torch.zeros((co, kh, kw, cip), dtype=torch.float32, device=x.device)
-        ops.conv2d_wgrad(x, dy, dwp, cip, ops.conv_params(k, s, p, d))
-        tape.add_grad(conv.weight, ops.unpack_wgrad(dwp, (co, ci, kh, kw), cip))
+        slot = _grad_slot(conv.weight)
+        g = slot if slot is not None else torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device)
+        ops.conv2d_wgrad(x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None), oihw=True)
+        if slot is None:
+            tape.add_grad(conv.weight, g)
     if conv.bias is not None and conv.bias.requires_grad:
-        tape.add_grad(conv.bias, _channel_sum(dy))
+        slot = _grad_slot(conv.bias)
+        if slot is not None:
+            slot.add_(_channel_sum(dy))
+        else:
+            tape.add_grad(conv.bias, _channel_sum(dy))
     if not need_dx:
         return None
     if dx is None:

@@ -308,7 +308,51 @@ class Model(HipModule):
             raise NotImplementedError("augment / profile / visualize are outside the hot path (SURVEY.md 2 row 5)")
         return run_module(self, x)
 
+    # ---- per-step, whole-model preparation (training): one pack launch, one BN-counter increment --------------------------
+    def _prepare_training_step(self, dtype, device):
+        from ...conv_impl import _cache, _ver
+        convs = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
+        bank = self.__dict__.get("_dsn_bank")
+        if bank is None or not bank.valid_for(dtype) or len(bank.convs) != len(convs):
+            vec = 4 if dtype == torch.float32 else 8
+            focus_convs = {m.conv.conv for m in self.modules() if isinstance(m, Focus)}
+            pads = [((c.in_channels + vec - 1) // vec * vec) if c in focus_convs else c.in_channels for c in convs]
+            bank = self.__dict__["_dsn_bank"] = ops.WeightBank(convs, pads, dtype, device)
+            self.__dict__["_dsn_bank_pads"] = pads
+            self.__dict__["_dsn_bank_version"] = None
+        version = tuple(c.weight._version for c in convs)
+        if version != self.__dict__.get("_dsn_bank_version"):
+            bank.pack()
+            self.__dict__["_dsn_bank_version"] = version
+            for c, cp, f, d in zip(convs, self.__dict__["_dsn_bank_pads"], bank.fwd, bank.dgrad):
+                bias = c.bias.detach() if c.bias is not None else None
+                cache = _cache(c)
+                cache[("fwd", dtype, cp, False)] = (_ver(c.weight, c.bias), f, bias)
+                if cp == c.in_channels:
+                    cache[("fwd", dtype, None, False)] = cache[("fwd", dtype, cp, False)]
+                cache[("dgrad", dtype)] = (_ver(c.weight), d)
+        # BatchNorm `num_batches_tracked`: every counter is a view of one int64 vector -> a single add per step
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None
+               and not getattr(m, "_dsn_never_runs", False)]
+        flat = self.__dict__.get("_dsn_bn_counters")
+        if (flat is None or flat.device != device or flat.numel() != len(bns)
+                or any(b.num_batches_tracked.data_ptr() != flat[i].data_ptr() for i, b in enumerate(bns))):
+            flat = torch.stack([b.num_batches_tracked.detach().to(device) for b in bns]) if bns else None
+            for i, b in enumerate(bns):
+                b._buffers["num_batches_tracked"] = flat[i]
+                b.__dict__["_dsn_shared_counter"] = True
+            self.__dict__["_dsn_bn_counters"] = flat
+        if flat is not None:
+            flat.add_(1)
+
     def fwd(self, x, tape=None, out=None):
+        if self.training:
+            for pp in (m for m in self.modules() if isinstance(m, PyramidPooling)):
+                for pool, conv in pp._branches():      # quirk Q1: a BN behind a 1x1 pool never runs un-fused
+                    sz = pool.output_size if isinstance(pool.output_size, int) else pool.output_size[0]
+                    if sz == 1 and hasattr(conv, "bn"):
+                        conv.bn.__dict__["_dsn_never_runs"] = True
+            self._prepare_training_step(self._dtype_of(x), self._device_of(x))
         y = []
         cats = {}
         for m in self.model:

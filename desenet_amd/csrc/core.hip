@@ -150,6 +150,33 @@ __global__ void copy_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t 
     }
 }
 
+// ---- multi-tensor weight pack: ONE launch packs every conv weight of the model (forward + dgrad layouts) -------------------
+// work[b] = {tensor id, first element}; each block converts up to PACK_CHUNK elements of one tensor.
+constexpr int PACK_CHUNK = 2048;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const dsn_pack_desc* __restrict__ descs,
+                                                         const int2* __restrict__ work) {
+    const int2 wk = work[blockIdx.x];
+    const dsn_pack_desc d = descs[wk.x];
+    const float* __restrict__ w = (const float*)d.w_oihw;
+    T* __restrict__ of = (T*)d.out_fwd;
+    T* __restrict__ od = (T*)d.out_dgrad;
+    const int taps = d.kh * d.kw;
+    const int64_t n_fwd = (int64_t)d.co * taps * d.ci_pad;
+    const int64_t end = (wk.y + PACK_CHUNK < n_fwd) ? wk.y + PACK_CHUNK : n_fwd;
+    for (int64_t i = wk.y + threadIdx.x; i < end; i += 256) {
+        // i indexes the forward layout [co][tap][ci_pad]
+        const int c = (int)(i % d.ci_pad);
+        const int64_t t = i / d.ci_pad;
+        const int tap = (int)(t % taps);
+        const int o = (int)(t / taps);
+        float v = 0.f;
+        if (c < d.ci) v = w[((int64_t)o * d.ci + c) * taps + tap];
+        if (of) of[i] = from_f32<T>(v);
+        if (od && c < d.ci) od[((int64_t)c * taps + tap) * d.co + o] = from_f32<T>(v);
+    }
+}
+
 inline int grid_for(int64_t total, int threads = 256) {
     int64_t b = (total + threads - 1) / threads;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -176,6 +203,18 @@ extern "C" int dsn_pack_weight_dgrad(const float* w, void* out, int32_t dtype, i
                        hipLaunchKernelGGL(pack_dgrad_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
                                           (hipStream_t)stream, w, (T*)out, co, ci, kh, kw));
     DSN_LAUNCH_CHECK("pack_weight_dgrad");
+    return DSN_OK;
+}
+
+extern "C" int32_t dsn_pack_chunk(void) { return PACK_CHUNK; }
+
+extern "C" int dsn_pack_weights_multi(const dsn_pack_desc* descs_dev, const int32_t* work_dev, int32_t n_work,
+                                      int32_t dtype, void* stream) {
+    DSN_CHECK_ARG(descs_dev && work_dev && n_work > 0, "pack_weights_multi: bad args");
+    DSN_DISPATCH_DTYPE(dtype, T,
+                       hipLaunchKernelGGL(pack_multi_kernel<T>, dim3(n_work), dim3(256), 0, (hipStream_t)stream, descs_dev,
+                                          (const int2*)work_dev));
+    DSN_LAUNCH_CHECK("pack_weights_multi");
     return DSN_OK;
 }
 

@@ -16,6 +16,7 @@ struct WGeom {
     int64_t yld, xld;
     int32_t S, ppb, tiles_co, tiles_ci;
     int32_t accumulate;
+    int32_t oihw;         // final output layout: 0 = packed [Co][tap][Cip], 1 = OIHW [Co][Ci][tap]
 };
 
 constexpr int PK = 32;    // pixels per chunk
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
                 const int co = co0 + (wm * 2 + i) * 16 + fg * 4 + e;
                 const int ci = ci0 + (wn * 2 + j) * 16 + fr;
                 if (co < g.Co && ci < g.Ci) {
-                    float* d = o + ((int64_t)co * taps + tap) * g.Cip + ci;
+                    float* d = (g.S == 1 && g.oihw) ? o + ((int64_t)co * g.Ci + ci) * taps + tap
+                                                    : o + ((int64_t)co * taps + tap) * g.Cip + ci;
                     float v = acc[i][j][e];
                     if (g.S == 1 && g.accumulate) v += *d;
                     *d = v;
@@ -187,12 +189,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int64_t n, int S,
-                                    int accumulate) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = accumulate ? dw[i] : 0.f;
-        for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
-        dw[i] = s;
+// dw (+)= sum_s slab[s]: a 256-thread block owns 64 consecutive packed elements; its 4 waves each add every 4th slab
+// (coalesced 256-byte reads), then the 4 partial sums are combined in a fixed order -> deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                           int64_t n, int S, int accumulate, int oihw, int Ci, int Cip,
+                                                           int taps) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+        const int64_t j = base + lane;
+        float s = 0.f;
+        if (j < n)
+            for (int k = grp; k < S; k += 4) s += slabs[(int64_t)k * n + j];
+        part[grp][lane] = s;
+        __syncthreads();
+        if (grp == 0 && j < n) {
+            float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            int64_t dst = j;
+            bool ok = true;
+            if (oihw) {
+                const int ci = (int)(j % Cip);
+                const int64_t t = j / Cip;
+                const int tap = (int)(t % taps);
+                const int64_t co = t / taps;
+                ok = ci < Ci;
+                dst = (co * Ci + ci) * taps + tap;
+            }
+            if (ok) {
+                if (accumulate) v += dw[dst];
+                dw[dst] = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -216,13 +244,15 @@ extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const d
     g.tiles_ci = (x->c + TB - 1) / TB;
     g.KH = p->kh; g.KW = p->kw;
     const int S = choose_split(g);
-    return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * ci_pad * sizeof(float) : 0;
+    const int64_t row = ci_pad > x->c ? ci_pad : x->c;
+    return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * row * sizeof(float) : 0;
 }
 
-extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad,
+extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
                                 const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream) {
     DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(dy) && dw && p, "conv wgrad: null/invalid argument");
-    DSN_CHECK_ARG(x->dtype == dy->dtype && x->n == dy->n && ci_pad >= x->c, "conv wgrad: dtype/batch mismatch");
+    DSN_CHECK_ARG(x->dtype == dy->dtype && x->n == dy->n && ci_pad > 0 && (oihw ? ci_pad <= x->c : ci_pad >= x->c),
+                  "conv wgrad: dtype/batch/channel mismatch");
     const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     DSN_CHECK_ARG(ho == dy->h && wo == dy->w, "conv wgrad: dy is %dx%d, expected %dx%d", dy->h, dy->w, ho, wo);
@@ -237,6 +267,8 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
     g.accumulate = p->accumulate;
+    g.oihw = oihw ? 1 : 0;
+    if (oihw) g.Ci = (x->c < ci_pad) ? x->c : ci_pad, g.Cip = x->c;   // OIHW: ci_pad = REAL Ci, x may carry zero-padded channels
     const int64_t n_out = (int64_t)g.Co * g.KH * g.KW * g.Cip;
     float* out = dw;
     hipStream_t st = (hipStream_t)stream;
@@ -246,9 +278,8 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
                      (long long)((int64_t)g.S * n_out * sizeof(float)));
         out = (float*)workspace;
     }
-    // every slab element a block does not own must read as zero in the reduction: tiles cover co<Co, ci<Ci only, the
-    // ci_pad tail is never written -> clear it when padding exists.
-    if (g.S > 1 && g.Cip != g.Ci) {
+    // packed layout with a padded channel axis: the reduction also visits the padding lanes, which no tile writes
+    if (g.S > 1 && !g.oihw && g.Cip != g.Ci) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)g.S * n_out * sizeof(float), st);
         if (e != hipSuccess) DSN_FAIL((int)e, "conv wgrad: memset failed");
     }
@@ -269,9 +300,9 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     DSN_LAUNCH_CHECK("conv wgrad");
     if (g.S > 1) {
         ProfScope prof(KID_WGRAD_REDUCE, 0.0, (double)(g.S + 1) * n_out * 4, st);
-        int64_t b = (n_out + 255) / 256;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(b > 2048 ? 2048 : b)), dim3(256), 0, st, out, dw, n_out, g.S,
-                           p->accumulate);
+        int64_t b = (n_out + 63) / 64;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(b > 4096 ? 4096 : b)), dim3(256), 0, st, out, dw, n_out, g.S,
+                           p->accumulate, g.oihw, g.Ci, g.Cip, g.KH * g.KW);
         DSN_LAUNCH_CHECK("conv wgrad reduce");
     } else if (g.Cip != g.Ci && !p->accumulate) {
         // direct write leaves the padding lanes of dw untouched: they are defined to be zero

@@ -116,14 +116,72 @@ def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params):
     return dx
 
 
-def conv2d_wgrad(x, dy, dw_packed, ci_pad, p: dsn_conv_params):
+_scratch = {}
+
+
+def scratch(nbytes: int, device) -> torch.Tensor:
+    """A persistent, growing workspace per (device, stream): kernels on one stream run in order, so every workspace user
+    on that stream can share it (no allocator round-trip per call, stable pointers for hipGraph capture)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _scratch[key] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+    return buf
+
+
+def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False):
+    """oihw=False: dw packed [Co][KH][KW][ci] (ci >= x channels).  oihw=True: dw is the OIHW fp32 gradient itself
+    (ci = real input channels <= x channels); p.accumulate adds into it."""
     L = _lib.lib()
     a, b = desc(x), desc(dy)
-    nbytes = L.dsn_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(b), C.byref(p), ci_pad)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-    _lib.check(L.dsn_conv2d_wgrad(C.byref(a), C.byref(b), dw_packed.data_ptr(), ci_pad, C.byref(p), ws.data_ptr(),
-                                  nbytes, stream_ptr()), "conv2d_wgrad")
-    return dw_packed
+    nbytes = L.dsn_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(b), C.byref(p), ci)
+    ws = scratch(nbytes, x.device) if nbytes else None
+    _lib.check(L.dsn_conv2d_wgrad(C.byref(a), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p), _p(ws), nbytes,
+                                  stream_ptr()), "conv2d_wgrad")
+    return dw
+
+
+class WeightBank:
+    """All conv weights of a model packed by ONE kernel launch per optimizer step (forward + dgrad layouts)."""
+
+    def __init__(self, convs, ci_pads, dtype, device, need_dgrad=True):
+        L = _lib.lib()
+        chunk = L.dsn_pack_chunk()
+        es = 2 if dtype == torch.bfloat16 else 4
+        self.dtype, self.convs = dtype, list(convs)
+        sizes_f = [c.out_channels * c.kernel_size[0] * c.kernel_size[1] * cp for c, cp in zip(self.convs, ci_pads)]
+        sizes_d = [c.weight.numel() for c in self.convs]
+        al = lambda n: (n + 63) // 64 * 64
+        self.fwd_buf = torch.empty(sum(al(n) for n in sizes_f), dtype=dtype, device=device)
+        self.dg_buf = torch.empty(sum(al(n) for n in sizes_d), dtype=dtype, device=device) if need_dgrad else None
+        descs = (_lib.dsn_pack_desc * len(self.convs))()
+        work, self.fwd, self.dgrad = [], [], []
+        of = od = 0
+        for i, (c, cp) in enumerate(zip(self.convs, ci_pads)):
+            co, ci, kh, kw = c.weight.shape
+            fv = self.fwd_buf[of:of + sizes_f[i]].view(co, kh, kw, cp)
+            dv = self.dg_buf[od:od + sizes_d[i]].view(ci, kh, kw, co) if need_dgrad else None
+            self.fwd.append(fv)
+            self.dgrad.append(dv)
+            w = c.weight
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dv.data_ptr() if need_dgrad else None, co, ci, kh,
+                                          kw, cp, 0)
+            work += [(i, s0) for s0 in range(0, sizes_f[i], chunk)]
+            of += al(sizes_f[i])
+            od += al(sizes_d[i])
+        raw = bytes(descs)
+        self.descs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.work_dev = torch.tensor(work, dtype=torch.int32).to(device)
+        self.n_work = len(work)
+        self.ptrs = tuple(c.weight.data_ptr() for c in self.convs)
+
+    def valid_for(self, dtype):
+        return dtype == self.dtype and self.ptrs == tuple(c.weight.data_ptr() for c in self.convs)
+
+    def pack(self):
+        _lib.check(_lib.lib().dsn_pack_weights_multi(self.descs_dev.data_ptr(), self.work_dev.data_ptr(), self.n_work,
+                                                     _DT[self.dtype], stream_ptr()), "pack_weights_multi")
 
 
 def pack_weight_fwd(w_oihw: torch.Tensor, dtype, scale: Optional[torch.Tensor] = None, ci_pad: Optional[int] = None):
@@ -261,7 +319,7 @@ def bilinear_ac(x, y, out_nchw=False):
 
 def _wr_ws(nseg, rows, c, device):
     nbytes = _lib.lib().dsn_window_reduce_workspace_bytes(nseg, rows, c)
-    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
+    return scratch(max(nbytes, 16), device), nbytes
 
 
 def bilinear_ac_bwd(dy, dx, dy_nchw=False, accumulate=False):

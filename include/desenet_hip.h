@@ -74,8 +74,11 @@ int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w_packed, const dsn_tenso
                      void* stream);
 int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p,
                                          int32_t ci_pad);
-int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, const dsn_conv_params* p,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+/* oihw = 0: dw is packed [Co][KH][KW][ci_pad] (ci_pad >= x->c).
+ * oihw = 1: dw is the parameter-gradient layout [Co][Ci][KH][KW] with Ci = ci_pad <= x->c (x may carry zero-padded
+ *           channels); with p->accumulate the result is ADDED to dw (gradient accumulation straight into .grad). */
+int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
+                     const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* weight packing: OIHW fp32 master weights (the state_dict layout, `...conv.weight [c2,c1,k,k]`) -> kernel layouts.
  * ci_pad >= ci zero-pads the input-channel axis (Focus: 12 -> 16 for 16-byte bf16 loads).
@@ -84,6 +87,17 @@ int dsn_pack_weight_fwd(const float* w_oihw, const float* scale, void* out, int3
                         int32_t kh, int32_t kw, int32_t ci_pad, void* stream);
 int dsn_pack_weight_dgrad(const float* w_oihw, void* out, int32_t dtype, int32_t co, int32_t ci, int32_t kh,
                           int32_t kw, void* stream);
+/* One launch for ALL conv weights of a model (per optimizer step): descs/work live in device memory.
+ * work = int32 pairs {tensor id, first element of a dsn_pack_chunk()-sized piece of that tensor's forward layout}. */
+typedef struct {
+    const void* w_oihw;   /* fp32 [co][ci][kh][kw] */
+    void*       out_fwd;  /* [co][kh][kw][ci_pad] or NULL */
+    void*       out_dgrad;/* [ci][kh][kw][co]     or NULL */
+    int32_t     co, ci, kh, kw, ci_pad, reserved;
+} dsn_pack_desc;
+int32_t dsn_pack_chunk(void);
+int dsn_pack_weights_multi(const dsn_pack_desc* descs_dev, const int32_t* work_dev, int32_t n_work, int32_t dtype,
+                           void* stream);
 /* dw (packed [Co][KH][KW][Ci_pad] fp32) -> OIHW fp32 gradient, grad (+)= dw */
 int dsn_unpack_wgrad(const float* dw_packed, float* grad_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
                      int32_t ci_pad, int32_t accumulate, void* stream);

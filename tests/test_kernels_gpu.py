@@ -110,6 +110,10 @@ def test_conv_dgrad_wgrad(ops, case, dtype):
     ops.conv2d_wgrad(to_dev(ops, x.detach(), dtype), gd, dwp, ci, p)
     dw = ops.unpack_wgrad(dwp, (co, ci, k, k), ci)
     assert_close(dw.cpu(), wq.grad, TOL[dtype], f"wgrad {case}")
+    # straight into an OIHW gradient, accumulating on top of an existing value
+    g = torch.ones((co, ci, k, k), device="cuda")
+    ops.conv2d_wgrad(to_dev(ops, x.detach(), dtype), gd, g, ci, ops.conv_params(k, s, pad, dil, accumulate=True), oihw=True)
+    assert_close(g.cpu() - 1.0, wq.grad, 2 * TOL[dtype], f"wgrad oihw+accumulate {case}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -125,6 +129,9 @@ def test_wgrad_large_reduction_and_padding(ops, dtype):
     dw = ops.unpack_wgrad(dwp, (co, ci, 3, 3), 16)
     assert_close(dw.cpu(), wq.grad, TOL[dtype], "wgrad split-K")
     assert float(dwp[..., 12:].abs().max()) == 0
+    g = torch.zeros((co, ci, 3, 3), device="cuda")
+    ops.conv2d_wgrad(to_dev(ops, xpad, dtype), to_dev(ops, gy, dtype), g, ci, ops.conv_params(3), oihw=True)
+    assert_close(g.cpu(), wq.grad, TOL[dtype], "wgrad split-K, OIHW out, padded x")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -136,6 +143,14 @@ def test_pack_weights(ops, dtype):
     assert_close(wp.float().cpu(), ref, 1e-6 if dtype == torch.float32 else 8e-3)
     wd = ops.pack_weight_dgrad(wt.cuda(), dtype)
     assert_close(wd.float().cpu(), q(wt, dtype).permute(1, 2, 3, 0), 0)
+    # multi-tensor bank: one launch for several convs, identical bytes to the single-tensor packers
+    convs = [torch.nn.Conv2d(12, 24, 3, bias=False), torch.nn.Conv2d(40, 8, 1, bias=False), torch.nn.Conv2d(8, 300, 3, bias=False)]
+    convs = [c.cuda() for c in convs]
+    bank = ops.WeightBank(convs, [16, 40, 8], dtype, "cuda")
+    bank.pack()
+    for c, cp, f, d in zip(convs, [16, 40, 8], bank.fwd, bank.dgrad):
+        assert torch.equal(f, ops.pack_weight_fwd(c.weight, dtype, None, cp))
+        assert torch.equal(d, ops.pack_weight_dgrad(c.weight, dtype))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

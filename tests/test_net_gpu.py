@@ -194,3 +194,37 @@ def test_two_backward_calls_like_the_reference(net):
     assert sorted(one) == sorted(two)
     for k in one:
         assert rel_err(two[k].cpu(), one[k].cpu()) < 1e-3, k
+
+
+def test_direct_accumulation_into_flat_gradients(net):
+    """With FlatGradients every .grad is a view of one buffer and the kernels accumulate into it directly (no autograd
+    temporaries): same numbers as the plain autograd path, and a second step after zero() is identical (deterministic)."""
+    import copy
+    from desenet_amd.parallel import FlatGradients
+    _, m = net
+    x = synth_images(2, 128, 21).cuda()
+
+    def upstream(raws, seg):
+        g = torch.Generator(device="cuda").manual_seed(5)
+        return [torch.rand(r.shape, device="cuda", generator=g) - 0.5 for r in raws] + \
+               [torch.rand(seg.shape, device="cuda", generator=g) - 0.5]
+
+    plain = copy.deepcopy(m).train()
+    raws, seg = plain(x)
+    torch.autograd.backward(list(raws) + [seg], upstream(raws, seg))
+    ref = {k: p.grad.clone() for k, p in plain.named_parameters() if p.grad is not None}
+
+    direct = copy.deepcopy(m).train()
+    flat = FlatGradients(direct.parameters())
+    for rep in range(2):
+        flat.zero()
+        direct.load_state_dict(m.state_dict())          # undo the BN running-stat update of the previous repetition
+        raws, seg = direct(x)
+        torch.autograd.backward(list(raws) + [seg], upstream(raws, seg))
+        for k, p in direct.named_parameters():
+            assert p.grad.untyped_storage().data_ptr() == flat.flat.untyped_storage().data_ptr()
+            if k in ref:
+                assert rel_err(p.grad.cpu(), ref[k].cpu()) < 1e-5, (rep, k)
+            else:
+                assert float(p.grad.abs().max()) == 0.0, k
+    assert int(direct.state_dict()["model.0.conv.bn.num_batches_tracked"]) == 1
