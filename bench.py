@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--img", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="train: launch every kernel from Python instead of hipGraph replay")
     return ap.parse_args()
 
 
@@ -200,14 +201,27 @@ def main():
         det_t, seg_t = synth_targets(batch, a.img, 3 + rank)
         det_t, seg_t = det_t.to(dev), seg_t.to(dev)
 
-        def step():
+        def loss_fn(det_pred, seg_pred):
+            det_loss, _ = compute_loss(det_pred, det_t)
+            return det_loss * DETGAIN + compute_seg_loss(seg_pred, seg_t) * SEGGAIN
+
+        def eager_step():
             flat.zero()
             det_pred, seg_pred = model(x)
-            det_loss, _ = compute_loss(det_pred, det_t)
-            seg_loss = compute_seg_loss(seg_pred, seg_t)
-            (det_loss * DETGAIN + seg_loss * SEGGAIN).backward()
+            loss_fn(det_pred, seg_pred).backward()
             flat.all_reduce()
             opt.step()
+
+        step = eager_step
+        mode_note = "eager launches"
+        if not a.eager:
+            try:
+                from desenet_amd.graph import GraphedTrainStep
+                graphed = GraphedTrainStep(model, loss_fn, flat, opt, x)
+                step = lambda: graphed()
+                mode_note = "hipGraph replay (fwd | bwd | optimizer), eager loss"
+            except Exception as e:   # keep the bench alive, but say so loudly
+                log(f"hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
     else:
         from desenet_amd.core.utils.general import non_max_suppression
         model.eval().fuse()
@@ -231,7 +245,8 @@ def main():
             log("first step done")
     sync()
     log(f"timing {a.steps} steps")
-    if not a.no_profile:
+    graphed_run = train and not a.eager and step is not eager_step
+    if not a.no_profile and not graphed_run:
         ops.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -239,7 +254,17 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof = {}
+    prof_steps = a.steps
     if not a.no_profile:
+        if graphed_run:
+            ops.profile_enable(True)
+            # graph replay cannot carry the library's event pairs: time the SAME launches (same kernels, shapes, stream)
+            # on eager steps right after the timed region
+            prof_steps = min(a.steps, 5)
+            ops.profile_collect()
+            for _ in range(prof_steps):
+                eager_step()
+            torch.cuda.synchronize()
         prof = ops.profile_collect()
         ops.profile_enable(False)
     if world > 1:
@@ -249,7 +274,7 @@ def main():
 
     log(f"timed region: {elapsed:.3f} s")
     if rank == 0:
-        roof, table = roofline_from_profile(prof, a.steps, dtype)
+        roof, table = roofline_from_profile(prof, prof_steps, dtype)
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} threads ...")
@@ -257,7 +282,8 @@ def main():
         if train:
             metric = "images/sec (640x640) train fwd+bwd"
             workload = (f"config {'3' if world == 1 else '4'}: DeSeNet-s training step (fwd + det/seg loss + bwd + "
-                        f"{'RCCL flat all-reduce + ' if world > 1 else ''}SGD), batch {batch}/GPU, {a.img}x{a.img}")
+                        f"{'RCCL flat all-reduce + ' if world > 1 else ''}SGD), batch {batch}/GPU, {a.img}x{a.img}, "
+                        f"{mode_note}")
         else:
             metric = "images/sec (640x640) inference fwd+NMS"
             workload = f"config 2: DeSeNet-s fused inference (fwd + Detect decode + NMS), batch {batch}, {a.img}x{a.img}"

@@ -16,6 +16,7 @@ struct WGeom {
     int64_t yld, xld;
     int32_t S, ppb, tiles_co, tiles_ci;
     int32_t accumulate;
+    int32_t CiLoad;       // channels x actually holds (>= Ci: zero-padded tail may be loaded, never stored)
     int32_t oihw;         // final output layout: 0 = packed [Co][tap][Cip], 1 = OIHW [Co][Ci][tap]
 };
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             ra[i] = u32x4{0u, 0u, 0u, 0u};
             rb[i] = u32x4{0u, 0u, 0u, 0u};
             if (pok) ra[i] = load_vec(dy + (int64_t)p * g.yld + co0 + vc, co0 + vc, g.Co);
-            if (xok) rb[i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.Ci);
+            if (xok) rb[i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.CiLoad);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -268,6 +269,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     g.S = (g.P + g.ppb - 1) / g.ppb;
     g.accumulate = p->accumulate;
     g.oihw = oihw ? 1 : 0;
+    g.CiLoad = x->c;
     if (oihw) g.Ci = (x->c < ci_pad) ? x->c : ci_pad, g.Cip = x->c;   // OIHW: ci_pad = REAL Ci, x may carry zero-padded channels
     const int64_t n_out = (int64_t)g.Co * g.KH * g.KW * g.Cip;
     float* out = dw;
@@ -284,7 +286,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
         if (e != hipSuccess) DSN_FAIL((int)e, "conv wgrad: memset failed");
     }
     const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
-    const bool vl = (g.Co % vec == 0) && (g.Ci % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
+    const bool vl = (g.Co % vec == 0) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
                     ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
     dim3 grid(g.tiles_ci * g.tiles_co * g.KH * g.KW * g.S), block(256);
     {
