@@ -36,6 +36,9 @@ PROTOTYPES = {
     "dsn_last_error": (C.c_char_p, []),
     "dsn_conv2d_fwd": (i32, [TP, vp, vp, TP, TP, CP, vp]),
     "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
+    "dsn_conv2d_stats_rows": (i32, [i64]),
+    "dsn_conv2d_fwd_stats": (i32, [TP, vp, TP, CP, vp, vp, vp]),
+    "dsn_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
     "dsn_conv2d_wgrad_workspace_bytes": (i64, [TP, TP, CP, i32]),
     "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
     "dsn_pack_weight_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

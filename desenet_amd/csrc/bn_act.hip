@@ -360,6 +360,18 @@ extern "C" int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float
     return DSN_OK;
 }
 
+// Finalize from partial rows produced elsewhere (the convolution epilogue: dsn_conv2d_fwd_stats).
+extern "C" int dsn_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    DSN_CHECK_ARG(partial && rows > 0 && c > 0 && count > 0 && scale && shift && mean && rstd, "bn_finalize: bad args");
+    DSN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
+                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    DSN_LAUNCH_CHECK("bn_finalize");
+    return DSN_OK;
+}
+
 extern "C" int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const float* shift, int32_t act,
                               const dsn_tensor* residual, const dsn_tensor* z, void* stream) {
     DSN_CHECK_ARG(tensor_ok(y) && tensor_ok(z) && same_shape(y, z), "bn_act_fwd: invalid tensors");

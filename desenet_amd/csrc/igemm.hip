@@ -1,22 +1,25 @@
 // Implicit-GEMM convolution on MFMA for gfx950 (CDNA4): forward and data-gradient share one gather-GEMM kernel.
 //
-//   C[m][n] = sum_{tap, c}  A[m][tap, c] * B[n][tap, c]
+//   C[m][n] = sum_k  A[m][k] * B[n][k],   k = (tap, c) linearised as tap*Cs + c
 //     m   : destination pixel (n, y, x) of an NHWC tensor (dense in N,H,W; channel stride ldc)
 //     n   : destination channel
-//     A   : gathered source pixel vectors, src = (dst*a + b + k*d) / q per axis, zero outside the map
+//     A   : gathered source pixel vectors, src = (dst*a + b + tap*d) / q per axis, zero outside the map
 //           forward : a = stride, b = -pad, d = dil,  q = 1       (src = input x,  dst = output y)
 //           dgrad   : a = 1,      b = +pad, d = -dil, q = stride  (src = dy,       dst = dx; needs divisibility)
 //     B   : packed weights [n][tap][c]   (K-contiguous per destination channel)
 //
-// Tiling: 256 threads = 4 waves (64-wide); block tile BM x BN = (WGM*MI*16) x (WGN*NI*16); K advances in 64-byte
-// chunks (16 fp32 / 32 bf16 channels of one tap), double-buffered in LDS with register-staged prefetch
-// (global loads for chunk i+1 are in flight while chunk i is on the matrix cores).
+// Tiling: 256 threads = 4 waves (64-wide); block tile BM x BN = (WGM*MI*16) x (WGN*NI*16).  K advances in 128-byte chunks
+// (32 fp32 / 64 bf16 consecutive k: a chunk may span several taps, so thin layers -- Focus' 12 channels, the 32-channel
+// stem -- waste nothing), double-buffered in LDS with register-staged prefetch: the 16-byte global loads of chunk i+1
+// (6-8 per thread) are in flight while chunk i is on the matrix cores, one barrier per chunk.
 // MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, config 2) / v_mfma_f32_16x16x32_bf16 (configs 3-5), fp32 accumulate.
 // One 16-byte LDS fragment per lane feeds 4 fp32 MFMAs or 1 bf16 MFMA: lane l holds row (l & 15), 16-byte K-group
-// (l >> 4) -- for fp32 the K order inside a chunk is permuted identically for A and B, which a dot product ignores.
-// LDS rows are 64 B; the 16-byte slot of K-group g in row r is g ^ ((r >> 2) & 3) so that the 16 lanes of a
-// ds_read_b128 group hit 16 distinct slots of the 256-byte bank row.
-// Epilogue (fused, in registers): + bias[n] -> activation (SiLU / sigmoid) -> + residual -> (+= dst) -> store.
+// (l >> 4) of a 64-byte half-chunk -- for fp32 the k order inside a 16-k group is permuted identically for A and B.
+// LDS rows are 128 B = 8 slots of 16 B; slot s of row r lives at s ^ ((r >> 1) & 7): the 16 lanes of every ds_read_b128
+// service group then hit 16 distinct slots of the 256-byte bank row, and an 8-lane ds_write_b128 group writes one whole row.
+// Epilogue: accumulators (+bias, activation) are staged through LDS as fp32, optional BatchNorm partial sums (per-channel
+// sum / sum of squares over the tile's rows, from the un-rounded fp32 values) are written for the finalize kernel, and the
+// tile leaves with 16-byte stores (+ residual, += destination) -- instead of 2-byte stores per lane.
 #include "common.h"
 
 namespace {
@@ -26,7 +29,7 @@ struct Geom {
     int32_t Hd, Wd;       // destination map
     int32_t Hs, Ws, Cs;   // source map, source channels (K per tap)
     int32_t Cd;           // destination channels
-    int32_t KH, KW;
+    int32_t KH, KW, Ktot;
     int32_t a, b, d, q;
     int32_t act, accumulate;
     int64_t sld, dld, rld;
@@ -36,7 +39,6 @@ struct Geom {
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {
-    static constexpr int KC = 16;   // elements per 64-byte chunk
     static constexpr int VEC = 4;   // elements per 16-byte vector
     __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
         // bit-cast the whole vector first: indexing the u32 vector inside __builtin_bit_cast(float, a[s]) made hipcc
@@ -49,7 +51,6 @@ template <> struct Mma<float> {
     }
 };
 template <> struct Mma<bf16_t> {
-    static constexpr int KC = 32;
     static constexpr int VEC = 8;
     __device__ static __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
@@ -57,23 +58,33 @@ template <> struct Mma<bf16_t> {
     }
 };
 
+constexpr int ROWB = 128;           // bytes per LDS row = one K chunk
+constexpr int CPAD = 4;             // fp32 staging row = BN + 4 floats (half-waves land 16 banks apart)
+
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8 equal) get a contiguous range of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+template <int BM, int BN> constexpr int smem_bytes() {
+    constexpr int loop = 2 * (BM + BN) * ROWB;
+    constexpr int epi = BM * (BN + CPAD) * 4 + 2 * 256 * 4;
+    return loop > epi ? loop : epi;
+}
+
 template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
-                                                    T* __restrict__ dst, const Geom g) {
+                                                    T* __restrict__ dst, float* __restrict__ stats, const Geom g) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
-    constexpr int KC = Mma<T>::KC, VEC = Mma<T>::VEC;
-    constexpr int AR = (BM + 63) / 64, BR = (BN + 63) / 64;   // staged rows per thread
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 64];
+    constexpr int VEC = Mma<T>::VEC;
+    constexpr int KC = ROWB / (int)sizeof(T);                  // k per chunk: 32 fp32 / 64 bf16
+    constexpr int AR = (BM + 31) / 32, BR = (BN + 31) / 32;    // staged rows per thread (8 threads per row)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[smem_bytes<BM, BN>()];
     unsigned char* sA = smem;
-    unsigned char* sB = smem + 2 * BM * 64;
+    unsigned char* sB = smem + 2 * BM * ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -82,14 +93,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-thread staging rows -----------------------------------------------------------------------------
-    const int v = tid & 3;          // 16-byte vector within the 64-byte chunk
-    const int r0 = tid >> 2;        // row 0..63 (+64*i)
+    const int v = tid & 7;          // 16-byte vector within the 128-byte chunk
+    const int r0 = tid >> 3;        // row 0..31 (+32*i)
     int32_t py[AR], px[AR];
     int64_t nbase[AR];
     bool rowok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int r = r0 + 64 * i;
+        const int r = r0 + 32 * i;
         const int m = m0 + r;
         rowok[i] = (r < BM) && (m < g.M);
         const int mm = rowok[i] ? m : 0;
@@ -99,70 +110,82 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         px[i] = x * g.a + g.b;
         nbase[i] = (int64_t)n * g.Hs * g.Ws;
     }
-    const int Ktot = g.KH * g.KW * g.Cs;
-    const int cpt = (g.Cs + KC - 1) / KC;        // chunks per tap
-    const int nchunks = g.KH * g.KW * cpt;
+    const int nchunks = (g.Ktot + KC - 1) / KC;
 
     u32x4 ra[AR], rb[BR];
-    int tap = 0, cc = 0;  // chunk counters for the NEXT load
 
-    auto load_chunk = [&]() {
-        const int ky = tap / g.KW, kx = tap - ky * g.KW;
-        const int c = cc * KC + v * VEC;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            u32x4 val = {0u, 0u, 0u, 0u};
-            int sy = py[i] + ky * g.d, sx = px[i] + kx * g.d;
-            bool ok = rowok[i] && sy >= 0 && sx >= 0;
-            if (g.q > 1) {
-                ok = ok && (sy % g.q == 0) && (sx % g.q == 0);
-                sy /= g.q;
-                sx /= g.q;
-            }
-            ok = ok && sy < g.Hs && sx < g.Ws;
-            if (ok) {
-                const T* p = src + (nbase[i] + (int64_t)sy * g.Ws + sx) * g.sld + c;
-                if (VECLOAD) {
-                    if (c < g.Cs) val = *reinterpret_cast<const u32x4*>(p);
-                } else {
-                    T tmp[VEC];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < g.Cs) ? p[e] : from_f32<T>(0.f);
-                    val = *reinterpret_cast<u32x4*>(tmp);
-                }
-            }
-            ra[i] = val;
+    // source address of destination row i for tap (ky, kx); nullptr when the tap falls outside the map
+    auto src_row = [&](int i, int ky, int kx) -> const T* {
+        int sy = py[i] + ky * g.d, sx = px[i] + kx * g.d;
+        bool ok = rowok[i] && sy >= 0 && sx >= 0;
+        if (g.q > 1) {
+            ok = ok && (sy % g.q == 0) && (sx % g.q == 0);
+            sy /= g.q;
+            sx /= g.q;
         }
+        ok = ok && sy < g.Hs && sx < g.Ws;
+        return ok ? src + (nbase[i] + (int64_t)sy * g.Ws + sx) * g.sld : nullptr;
+    };
+
+    auto load_chunk = [&](int ch) {
+        const int k0 = ch * KC + v * VEC;
+        if (VECLOAD) {
+            const bool kok = k0 < g.Ktot;
+            const int tap = k0 / g.Cs, c = k0 - tap * g.Cs;
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            u32x4 val = {0u, 0u, 0u, 0u};
-            const int r = r0 + 64 * i;
-            const int n = n0 + r;
-            if (r < BN && n < g.Cd) {
-                const T* p = wpk + (int64_t)n * Ktot + tap * g.Cs + c;
-                if (VECLOAD) {
-                    if (c < g.Cs) val = *reinterpret_cast<const u32x4*>(p);
-                } else {
-                    T tmp[VEC];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < g.Cs) ? p[e] : from_f32<T>(0.f);
-                    val = *reinterpret_cast<u32x4*>(tmp);
-                }
+            for (int i = 0; i < AR; ++i) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                const T* p = kok ? src_row(i, ky, kx) : nullptr;
+                if (p) val = *reinterpret_cast<const u32x4*>(p + c);
+                ra[i] = val;
             }
-            rb[i] = val;
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                const int r = r0 + 32 * i, n = n0 + r;
+                if (kok && r < BN && n < g.Cd) val = *reinterpret_cast<const u32x4*>(wpk + (int64_t)n * g.Ktot + k0);
+                rb[i] = val;
+            }
+        } else {   // generic path: per-element tap decode (channel counts that are not a multiple of the vector width)
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                T tmp[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int k = k0 + e;
+                    T val = from_f32<T>(0.f);
+                    if (k < g.Ktot) {
+                        const int tap = k / g.Cs, c = k - tap * g.Cs;
+                        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+                        const T* p = src_row(i, ky, kx);
+                        if (p) val = p[c];
+                    }
+                    tmp[e] = val;
+                }
+                ra[i] = *reinterpret_cast<u32x4*>(tmp);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                T tmp[VEC];
+                const int r = r0 + 32 * i, n = n0 + r;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    tmp[e] = (r < BN && n < g.Cd && k0 + e < g.Ktot) ? wpk[(int64_t)n * g.Ktot + k0 + e] : from_f32<T>(0.f);
+                rb[i] = *reinterpret_cast<u32x4*>(tmp);
+            }
         }
-        if (++cc == cpt) { cc = 0; ++tap; }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int r = r0 + 64 * i;
-            if (r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * 64 + ((v ^ ((r >> 2) & 3)) << 4)) = ra[i];
+            const int r = r0 + 32 * i;
+            if (r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int r = r0 + 64 * i;
-            if (r < BN) *reinterpret_cast<u32x4*>(sB + (buf * BN + r) * 64 + ((v ^ ((r >> 2) & 3)) << 4)) = rb[i];
+            const int r = r0 + 32 * i;
+            if (r < BN) *reinterpret_cast<u32x4*>(sB + (buf * BN + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = rb[i];
         }
     };
 
@@ -174,83 +197,161 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 
     const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int buf) {
-        u32x4 fa[MI], fb[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = (wm * MI + i) * 16 + fr;
-            fa[i] = *reinterpret_cast<const u32x4*>(sA + (buf * BM + r) * 64 + ((fg ^ ((r >> 2) & 3)) << 4));
+        for (int h = 0; h < 2; ++h) {      // two 64-byte half-chunks
+            u32x4 fa[MI], fb[NI];
+            const int slot = 4 * h + fg;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = (wm * MI + i) * 16 + fr;
+                fa[i] = *reinterpret_cast<const u32x4*>(sA + (buf * BM + r) * ROWB + ((slot ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int r = (wn * NI + j) * 16 + fr;
+                fb[j] = *reinterpret_cast<const u32x4*>(sB + (buf * BN + r) * ROWB + ((slot ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int r = (wn * NI + j) * 16 + fr;
-            fb[j] = *reinterpret_cast<const u32x4*>(sB + (buf * BN + r) * 64 + ((fg ^ ((r >> 2) & 3)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     };
 
     // ---- main loop: register-staged double buffering ------------------------------------------------------------
-    load_chunk();
+    load_chunk(0);
     store_chunk(0);
     __syncthreads();
     for (int it = 0; it < nchunks; ++it) {
         const int buf = it & 1;
         const bool more = it + 1 < nchunks;
-        if (more) load_chunk();
+        if (more) load_chunk(it + 1);
         compute(buf);
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- fused epilogue -----------------------------------------------------------------------------------------
+    // ---- epilogue: stage act(acc + bias) as fp32 [BM][BN + CPAD] ------------------------------------------------
+    constexpr int LDC = BN + CPAD;
+    float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int col = n0 + (wn * NI + j) * 16 + fr;
-        if (col >= g.Cd) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        const int cl = (wn * NI + j) * 16 + fr;
+        const int col = n0 + cl;
+        const float bv = (bias && col < g.Cd) ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = m0 + (wm * MI + i) * 16 + fg * 4 + e;
-                if (row >= g.M) continue;
-                float val = apply_act(acc[i][j][e] + bv, g.act);
-                if (res) val += to_f32<T>(res[(int64_t)row * g.rld + col]);
-                T* o = dst + (int64_t)row * g.dld + col;
-                if (g.accumulate) val += to_f32<T>(*o);
-                *o = from_f32<T>(val);
+                const int rl = (wm * MI + i) * 16 + fg * 4 + e;
+                sC[rl * LDC + cl] = apply_act(acc[i][j][e] + bv, g.act);
             }
+    }
+    __syncthreads();
+
+    // optional BatchNorm partial statistics of this tile (rows m0 .. m0+BM) -> stats[tm][0: sum, 1: sumsq][Cd]
+    if (stats) {
+        float* red = sC + BM * LDC;                 // 2 * 256 floats of scratch behind the staged tile
+        constexpr int TYS = 256 / BN > 0 ? 256 / BN : 1;
+        const int tx = tid % BN, ty = tid / BN;
+        float s = 0.f, ss = 0.f;
+        if (ty < TYS) {
+            const int rows = (g.M - m0 < BM) ? g.M - m0 : BM;
+            for (int r = ty; r < rows; r += TYS) {
+                const float val = sC[r * LDC + tx];
+                s += val;
+                ss += val * val;
+            }
+            red[ty * BN + tx] = s;
+            red[256 + ty * BN + tx] = ss;
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cd) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < TYS; ++t) {
+                t0 += red[t * BN + tid];
+                t1 += red[256 + t * BN + tid];
+            }
+            stats[((int64_t)tm * 2) * g.Cd + n0 + tid] = t0;
+            stats[((int64_t)tm * 2 + 1) * g.Cd + n0 + tid] = t1;
+        }
+    }
+
+    // ---- vectorised tile store (+ residual, += destination) -----------------------------------------------------
+    const bool vst = (g.Cd % VEC == 0) && (g.dld % VEC == 0) && (((uintptr_t)dst) % 16 == 0) &&
+                     (!res || ((g.rld % VEC == 0) && (((uintptr_t)res) % 16 == 0)));
+    if (vst) {
+        constexpr int VPR = BN / VEC;               // vectors per tile row
+        for (int idx = tid; idx < BM * VPR; idx += 256) {
+            const int rl = idx / VPR, cv = idx - rl * VPR;
+            const int row = m0 + rl, col = n0 + cv * VEC;
+            if (row >= g.M || col >= g.Cd) continue;
+            float vals[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(sC + rl * LDC + cv * VEC + e);
+                vals[e] = t[0]; vals[e + 1] = t[1]; vals[e + 2] = t[2]; vals[e + 3] = t[3];
+            }
+            T* o = dst + (int64_t)row * g.dld + col;
+            if (res) {
+                T rv[VEC];
+                *reinterpret_cast<u32x4*>(rv) = *reinterpret_cast<const u32x4*>(res + (int64_t)row * g.rld + col);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) vals[e] += to_f32<T>(rv[e]);
+            }
+            if (g.accumulate) {
+                T ov[VEC];
+                *reinterpret_cast<u32x4*>(ov) = *reinterpret_cast<const u32x4*>(o);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) vals[e] += to_f32<T>(ov[e]);
+            }
+            T outv[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(vals[e]);
+            *reinterpret_cast<u32x4*>(o) = *reinterpret_cast<u32x4*>(outv);
+        }
+    } else {
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int rl = idx / BN, cl = idx - rl * BN;
+            const int row = m0 + rl, col = n0 + cl;
+            if (row >= g.M || col >= g.Cd) continue;
+            float val = sC[rl * LDC + cl];
+            if (res) val += to_f32<T>(res[(int64_t)row * g.rld + col]);
+            T* o = dst + (int64_t)row * g.dld + col;
+            if (g.accumulate) val += to_f32<T>(*o);
+            *o = from_f32<T>(val);
         }
     }
 }
 
 template <typename T, int MI, int NI, int WGM, int WGN>
-int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, Geom g, bool vec, hipStream_t st) {
+int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, float* stats, Geom g, bool vec,
+               hipStream_t st, int* tiles_m_out) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
                         : (BM == 128 && BN == 32) ? 3 : 4;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.Cd + BN - 1) / BN;
+    if (tiles_m_out) *tiles_m_out = g.tiles_m;
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
     // algorithmic work of this launch: every source/destination element and every weight touched once
-    const double K = (double)g.KH * g.KW * g.Cs;
+    const double K = (double)g.Ktot;
     const double src_elems = (double)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws * g.Cs;
     const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd;
-    ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0),
-                   2.0 * g.M * g.Cd * K, elems * sizeof(T), st);
+    ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
+                   elems * sizeof(T), st);
     if (vec)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true>), grid, block, 0, st, src, w, bias, res, dst, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false>), grid, block, 0, st, src, w, bias, res, dst, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
     DSN_LAUNCH_CHECK("igemm");
     return DSN_OK;
 }
 
 template <typename T>
-int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, Geom g,
-           hipStream_t st) {
+int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, float* stats,
+           Geom g, hipStream_t st, int* tiles_m_out) {
     constexpr int VEC = Mma<T>::VEC;
     const T* src = (const T*)s->ptr;
     const T* res = r ? (const T*)r->ptr : nullptr;
@@ -260,12 +361,13 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     // tile choice: wide-N tiles for wide layers, tall-skinny for narrow ones; small M prefers smaller tiles so the
     // grid still covers the 256 CUs.
     const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.Cd + 127) / 128);
-    if (g.Cd > 64 && big >= 256) return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, g, vec, st);
+    if (g.Cd > 64 && big >= 256)
+        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
     if (g.Cd > 32 && (int64_t)((g.M + 127) / 128) * ((g.Cd + 63) / 64) >= 192)
-        return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, g, vec, st);
-    if (g.Cd > 32) return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, g, vec, st);
-    if (g.Cd > 16) return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, g, vec, st);
-    return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, g, vec, st);
+        return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
+    if (g.Cd > 32) return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
+    if (g.Cd > 16) return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
+    return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
 }
 
 int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const dsn_conv_params* p) {
@@ -277,10 +379,8 @@ int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const 
     return DSN_OK;
 }
 
-}  // namespace
-
-extern "C" int dsn_conv2d_fwd(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual,
-                              const dsn_tensor* y, const dsn_conv_params* p, void* stream) {
+int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual, const dsn_tensor* y,
+                  const dsn_conv_params* p, float* stats, int* tiles_m_out, void* stream) {
     int rc = check_common(x, w, y, p);
     if (rc) return rc;
     const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
@@ -293,12 +393,33 @@ extern "C" int dsn_conv2d_fwd(const dsn_tensor* x, const void* w, const float* b
     Geom g{};
     g.M = (int32_t)npix(y); g.Hd = y->h; g.Wd = y->w;
     g.Hs = x->h; g.Ws = x->w; g.Cs = x->c; g.Cd = y->c;
-    g.KH = p->kh; g.KW = p->kw;
+    g.KH = p->kh; g.KW = p->kw; g.Ktot = p->kh * p->kw * x->c;
     g.a = p->stride; g.b = -p->pad; g.d = p->dil; g.q = 1;
     g.act = p->act; g.accumulate = p->accumulate;
     g.sld = x->ldc; g.dld = y->ldc; g.rld = residual ? residual->ldc : 0;
-    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, g, (hipStream_t)stream);
-    return launch<bf16_t>(x, w, bias, residual, y, g, (hipStream_t)stream);
+    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, stats, g, (hipStream_t)stream, tiles_m_out);
+    return launch<bf16_t>(x, w, bias, residual, y, stats, g, (hipStream_t)stream, tiles_m_out);
+}
+
+}  // namespace
+
+extern "C" int dsn_conv2d_fwd(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual,
+                              const dsn_tensor* y, const dsn_conv_params* p, void* stream) {
+    return conv_fwd_impl(x, w, bias, residual, y, p, nullptr, nullptr, stream);
+}
+
+// conv (no bias / activation / residual) whose epilogue also emits per-tile BatchNorm partial sums: stats must hold
+// dsn_conv2d_stats_rows(M) * 2 * Co floats; *rows_out receives the number of rows actually written.
+extern "C" int32_t dsn_conv2d_stats_rows(int64_t out_pixels) { return (int32_t)((out_pixels + 63) / 64); }
+
+extern "C" int dsn_conv2d_fwd_stats(const dsn_tensor* x, const void* w, const dsn_tensor* y, const dsn_conv_params* p,
+                                    float* stats, int32_t* rows_out, void* stream) {
+    DSN_CHECK_ARG(stats && rows_out && p && p->act == DSN_ACT_NONE && !p->accumulate,
+                  "conv2d_fwd_stats: needs a stats buffer and a plain convolution");
+    int rows = 0;
+    int rc = conv_fwd_impl(x, w, nullptr, nullptr, y, p, stats, &rows, stream);
+    *rows_out = rows;
+    return rc;
 }
 
 extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
@@ -311,10 +432,11 @@ extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_t
     Geom g{};
     g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;
     g.Hs = dy->h; g.Ws = dy->w; g.Cs = dy->c; g.Cd = dx->c;
-    g.KH = p->kh; g.KW = p->kw;
+    g.KH = p->kh; g.KW = p->kw; g.Ktot = p->kh * p->kw * dy->c;
     g.a = 1; g.b = p->pad; g.d = -p->dil; g.q = p->stride;
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
-    if (dy->dtype == DSN_F32) return launch<float>(dy, w, nullptr, nullptr, dx, g, (hipStream_t)stream);
-    return launch<bf16_t>(dy, w, nullptr, nullptr, dx, g, (hipStream_t)stream);
+    if (dy->dtype == DSN_F32)
+        return launch<float>(dy, w, nullptr, nullptr, dx, nullptr, g, (hipStream_t)stream, nullptr);
+    return launch<bf16_t>(dy, w, nullptr, nullptr, dx, nullptr, g, (hipStream_t)stream, nullptr);
 }

@@ -108,6 +108,24 @@ def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params):
     return y
 
 
+def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_mean, running_var, momentum, eps):
+    """Training forward of a conv followed by BatchNorm: conv with statistics in its epilogue + finalize (2 launches, no
+    separate pass over y).  Returns (scale, shift, mean, rstd) fp32 [C]."""
+    L = _lib.lib()
+    dx, dy = desc(x), desc(y)
+    n, c, h, w = y.shape
+    rows = L.dsn_conv2d_stats_rows(n * h * w)
+    ws = scratch(rows * 2 * c * 4, x.device)
+    got = C.c_int32(0)
+    _lib.check(L.dsn_conv2d_fwd_stats(C.byref(dx), w_packed.data_ptr(), C.byref(dy), C.byref(p), ws.data_ptr(),
+                                      C.addressof(got), stream_ptr()), "conv2d_fwd_stats")
+    out = torch.empty((4, c), dtype=torch.float32, device=y.device)
+    _lib.check(L.dsn_bn_finalize(ws.data_ptr(), got.value, c, n * h * w, _p(gamma), _p(beta), _p(running_mean),
+                                 _p(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
+                                 out[2].data_ptr(), out[3].data_ptr(), stream_ptr()), "bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
 def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params):
     L = _lib.lib()
     a, b = desc(dy), desc(dx)

@@ -72,6 +72,12 @@ int dsn_conv2d_fwd(const dsn_tensor* x, const void* w_packed, const float* bias,
                    const dsn_tensor* y, const dsn_conv_params* p, void* stream);
 int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w_packed, const dsn_tensor* dx, const dsn_conv_params* p,
                      void* stream);
+/* Training forward: plain conv whose epilogue ALSO writes per-tile BatchNorm partial sums (sum, sum of squares per output
+ * channel, taken from the fp32 accumulators) -> no separate statistics pass over y.  stats: dsn_conv2d_stats_rows(N*Ho*Wo)
+ * * 2 * Co floats; *rows_out = rows written; feed both to dsn_bn_finalize. */
+int32_t dsn_conv2d_stats_rows(int64_t out_pixels);
+int dsn_conv2d_fwd_stats(const dsn_tensor* x, const void* w_packed, const dsn_tensor* y, const dsn_conv_params* p,
+                         float* stats, int32_t* rows_out, void* stream);
 int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p,
                                          int32_t ci_pad);
 /* oihw = 0: dw is packed [Co][KH][KW][ci_pad] (ci_pad >= x->c).
@@ -115,6 +121,9 @@ int64_t dsn_bn_workspace_bytes(int32_t c);
 int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                  float* rstd, void* workspace, int64_t workspace_bytes, void* stream);
+int dsn_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                    float* mean, float* rstd, void* stream);
 int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const float* shift, int32_t act,
                    const dsn_tensor* residual, const dsn_tensor* z, void* stream);
 int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
