@@ -68,6 +68,11 @@ PROTOTYPES = {
     "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, vp]),
     "dsn_nms_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "dsn_nms": (i32, [vp, i32, i32, i32, f32, f32, i32, i32, u64, i32, vp, vp, vp, i64, vp]),
+    "dsn_det_loss_workspace_bytes": (i64, [i32, i32, i32, i32, i64]),
+    "dsn_det_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, vp,
+                           vp, i64, vp]),
+    "dsn_seg_ce_workspace_bytes": (i64, []),
+    "dsn_seg_ce": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
     "dsn_cast": (i32, [vp, vp, i32, i64, vp]),
     "dsn_profile_enable": (i32, [i32]),
     "dsn_profile_collect": (i32, [vp, i32]),

@@ -1,0 +1,381 @@
+// Training losses of the hot path as HIP kernels (no host synchronisation, fixed launch shapes -> hipGraph-capturable):
+//   detection : ComputeLoss.__call__ + build_targets (core/utils/loss.py:117-223) with CIoU (core/utils/metrics.py:202-244)
+//   segmentation : nn.CrossEntropyLoss(ignore_index) over N x C x H x W logits (core/utils/loss.py:242-243)
+// Forward AND the gradient w.r.t. the network outputs are produced together (the training step always needs both).
+//
+// Detection, per pyramid level (one launch each, candidates = 5 offsets x na anchors x nt targets, id = o*(na*nt) + a*nt + t,
+// i.e. the reference's candidate order):
+//   det_match   : anchor-ratio test, neighbour-cell offsets, CIoU of the decoded box against the target with forward-mode
+//                 dual numbers (4 partials: the raw x, y, w, h logits), class BCE; per-candidate records; the objectness
+//                 target of a cell is owned by the LAST matching candidate in reference order (atomicMax on the id), which
+//                 is what the reference's sequential CPU scatter `tobj[b,a,gj,gi] = iou` leaves behind.
+//   det_obj     : BCE-with-logits of every cell's objectness against clamp(iou_owner, 0); writes the whole dense gradient
+//                 tensor (zeros + objectness term), block partial sums of the loss.
+//   det_scatter : adds the box / class gradients of the active candidates into the dense gradient (float atomics: the
+//                 only place -- a handful of adds per step, duplicates are rare).
+// det_finalize folds the three levels into (lbox + lobj + lcls) * bs and the three reported items.
+#include "common.h"
+
+namespace {
+
+constexpr int LT = 256;            // threads per loss block
+constexpr int MAX_NC = 32;
+
+// ---- forward-mode dual numbers over the 4 box logits ------------------------------------------------------------------------
+struct D4 {
+    float v, d[4];
+};
+__device__ __forceinline__ D4 dconst(float v) { return D4{v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 dvar(float v, int i) { D4 r = dconst(v); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ D4 operator+(const D4& a, const D4& b) { D4 r; r.v = a.v + b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D4 operator-(const D4& a, const D4& b) { D4 r; r.v = a.v - b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D4 operator*(const D4& a, const D4& b) { D4 r; r.v = a.v * b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D4 operator/(const D4& a, const D4& b) {
+    D4 r; const float inv = 1.f / b.v; r.v = a.v * inv;
+    for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+__device__ __forceinline__ D4 operator+(const D4& a, float b) { D4 r = a; r.v += b; return r; }
+__device__ __forceinline__ D4 operator-(const D4& a, float b) { D4 r = a; r.v -= b; return r; }
+__device__ __forceinline__ D4 operator*(const D4& a, float b) { D4 r; r.v = a.v * b; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b; return r; }
+__device__ __forceinline__ D4 dmin(const D4& a, float b) { return a.v < b ? a : dconst(b); }
+__device__ __forceinline__ D4 dmax(const D4& a, float b) { return a.v > b ? a : dconst(b); }
+__device__ __forceinline__ D4 dclamp0(const D4& a) { return a.v > 0.f ? a : dconst(0.f); }
+__device__ __forceinline__ D4 dsigmoid(const D4& a) {
+    const float s = 1.f / (1.f + expf(-a.v));
+    D4 r; r.v = s;
+    for (int i = 0; i < 4; ++i) r.d[i] = s * (1.f - s) * a.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 datan(const D4& a) {
+    D4 r; r.v = atanf(a.v);
+    const float g = 1.f / (1.f + a.v * a.v);
+    for (int i = 0; i < 4; ++i) r.d[i] = g * a.d[i];
+    return r;
+}
+
+// BCE with logits, pos_weight pw: loss = (1 - t)*x + (1 + (pw-1)*t) * softplus(-x);  dloss/dx = sigma*(1 + (pw-1) t) - pw t
+__device__ __forceinline__ float bce_logits(float x, float t, float pw, float* dx) {
+    const float lw = 1.f + (pw - 1.f) * t;
+    const float sp = fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));     // softplus(-x), stable
+    const float s = 1.f / (1.f + expf(-x));
+    *dx = (1.f - t) - lw * (1.f - s);
+    return (1.f - t) * x + lw * sp;
+}
+
+struct DetParams {
+    int32_t bs, na, no, nc, ny, nx, nt;
+    float anchor_t, cls_pw, obj_pw, cp, cn;
+    float anchors[6];              // this level, grid units, [na<=3][2]
+};
+
+struct Cand {                      // one (offset, anchor, target) candidate
+    int32_t cell;                  // ((b*na + a)*ny + gj)*nx + gi, or -1 when inactive
+    int32_t cls;
+    float iou;
+    float dbox[4];                 // d(1 - ciou)/d(raw x,y,w,h)
+};
+
+// per-level accumulators: [0] n active, [1] sum(1 - ciou), [2] sum class BCE, [3] sum objectness BCE
+__global__ __launch_bounds__(LT) void det_match_kernel(const float* __restrict__ p, const float* __restrict__ targets,
+                                                       DetParams q, Cand* __restrict__ cands, float* __restrict__ dcls,
+                                                       int32_t* __restrict__ owner, float* __restrict__ acc) {
+    __shared__ float red[3][LT];
+    const int ncand = 5 * q.na * q.nt;
+    float n_act = 0.f, s_box = 0.f, s_cls = 0.f;
+    for (int id = blockIdx.x * LT + threadIdx.x; id < ncand; id += gridDim.x * LT) {
+        const int o = id / (q.na * q.nt), rem = id - o * (q.na * q.nt);
+        const int a = rem / q.nt, t = rem - a * q.nt;
+        const float* tg = targets + (int64_t)t * 6;
+        const float gx = tg[2] * (float)q.nx, gy = tg[3] * (float)q.ny;
+        const float gw = tg[4] * (float)q.nx, gh = tg[5] * (float)q.ny;
+        const float aw = q.anchors[2 * a], ah = q.anchors[2 * a + 1];
+        const float rw = gw / aw, rh = gh / ah;
+        bool act = fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh)) < q.anchor_t;
+        float ox = 0.f, oy = 0.f;
+        if (o == 1) { act = act && (fmodf(gx, 1.f) < 0.5f) && (gx > 1.f); ox = 0.5f; }
+        else if (o == 2) { act = act && (fmodf(gy, 1.f) < 0.5f) && (gy > 1.f); oy = 0.5f; }
+        else if (o == 3) { const float ix = (float)q.nx - gx; act = act && (fmodf(ix, 1.f) < 0.5f) && (ix > 1.f); ox = -0.5f; }
+        else if (o == 4) { const float iy = (float)q.ny - gy; act = act && (fmodf(iy, 1.f) < 0.5f) && (iy > 1.f); oy = -0.5f; }
+        Cand c;
+        c.cell = -1; c.cls = 0; c.iou = 0.f;
+        c.dbox[0] = c.dbox[1] = c.dbox[2] = c.dbox[3] = 0.f;
+        if (act) {
+            const int b = (int)tg[0];
+            const int ci = (int)(gx - ox), cj = (int)(gy - oy);            // .long() truncation
+            const int gi = min(max(ci, 0), q.nx - 1), gj = min(max(cj, 0), q.ny - 1);
+            const float tx = gx - (float)ci, ty = gy - (float)cj;          // target box in cell units (un-clamped cell)
+            c.cell = ((b * q.na + a) * q.ny + gj) * q.nx + gi;
+            c.cls = (int)tg[1];
+            const float* ps = p + (int64_t)c.cell * q.no;
+            // predicted box: pxy = 2*sigmoid - 0.5, pwh = (2*sigmoid)^2 * anchor
+            const D4 sx = dsigmoid(dvar(ps[0], 0)), sy = dsigmoid(dvar(ps[1], 1));
+            const D4 sw = dsigmoid(dvar(ps[2], 2)), sh = dsigmoid(dvar(ps[3], 3));
+            const D4 px = sx * 2.f - 0.5f, py = sy * 2.f - 0.5f;
+            const D4 pw = (sw * 2.f) * (sw * 2.f) * aw, ph = (sh * 2.f) * (sh * 2.f) * ah;
+            // CIoU (metrics.py:202-244, x1y1x2y2=False), box1 = prediction, box2 = target
+            const float eps = 1e-7f;
+            const D4 b1x1 = px - pw * 0.5f, b1x2 = px + pw * 0.5f, b1y1 = py - ph * 0.5f, b1y2 = py + ph * 0.5f;
+            const float b2x1 = tx - gw / 2.f, b2x2 = tx + gw / 2.f, b2y1 = ty - gh / 2.f, b2y2 = ty + gh / 2.f;
+            const D4 iw = dclamp0(dmin(b1x2, b2x2) - dmax(b1x1, b2x1));
+            const D4 ih = dclamp0(dmin(b1y2, b2y2) - dmax(b1y1, b2y1));
+            const D4 inter = iw * ih;
+            const D4 w1 = b1x2 - b1x1, h1 = b1y2 - b1y1 + eps;
+            const float w2 = b2x2 - b2x1, h2 = b2y2 - b2y1 + eps;
+            const D4 uni = w1 * h1 + (w2 * h2) - inter + eps;
+            const D4 iou = inter / uni;
+            const D4 cw = dmax(b1x2, b2x2) - dmin(b1x1, b2x1);
+            const D4 chh = dmax(b1y2, b2y2) - dmin(b1y1, b2y1);
+            const D4 c2 = cw * cw + chh * chh + eps;
+            const D4 dxx = (b1x1 + b1x2) * -1.f + (b2x1 + b2x2), dyy = (b1y1 + b1y2) * -1.f + (b2y1 + b2y2);
+            const D4 rho2 = (dxx * dxx + dyy * dyy) * 0.25f;
+            const D4 at = datan(w1 / h1) * -1.f + atanf(w2 / h2);
+            const D4 v = at * at * 0.4052847345693511f;                   // 4 / pi^2
+            const float alpha = v.v / (v.v - iou.v + (1.f + eps));        // no_grad in the reference
+            const D4 ciou = iou - (rho2 / c2 + v * alpha);
+            c.iou = ciou.v;
+            for (int i = 0; i < 4; ++i) c.dbox[i] = -ciou.d[i];
+            n_act += 1.f;
+            s_box += 1.f - ciou.v;
+            // class BCE over nc logits (target cp at the class, cn elsewhere); gradient per candidate kept unscaled
+            if (q.nc > 1) {
+                for (int k = 0; k < q.nc; ++k) {
+                    float dx;
+                    s_cls += bce_logits(ps[5 + k], k == c.cls ? q.cp : q.cn, q.cls_pw, &dx);
+                    dcls[(int64_t)id * q.nc + k] = dx;
+                }
+            }
+            atomicMax(&owner[c.cell], id);
+        }
+        cands[id] = c;
+    }
+    red[0][threadIdx.x] = n_act; red[1][threadIdx.x] = s_box; red[2][threadIdx.x] = s_cls;
+    __syncthreads();
+    for (int s = LT / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { acc[0] = red[0][0]; acc[1] = red[1][0]; acc[2] = red[2][0]; }   // launched with ONE block
+}
+
+// objectness BCE over every cell + dense gradient initialisation; partial[blockIdx] = sum of the block's cells
+__global__ __launch_bounds__(LT) void det_obj_kernel(const float* __restrict__ p, DetParams q,
+                                                     const Cand* __restrict__ cands, const int32_t* __restrict__ owner,
+                                                     float* __restrict__ dp, float obj_coef, float* __restrict__ partial) {
+    __shared__ float red[LT];
+    const int64_t ncell = (int64_t)q.bs * q.na * q.ny * q.nx;
+    float s = 0.f;
+    for (int64_t cell = blockIdx.x * (int64_t)LT + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * LT) {
+        const int own = owner[cell];
+        const float tobj = own >= 0 ? fmaxf(cands[own].iou, 0.f) : 0.f;
+        float dx;
+        s += bce_logits(p[cell * q.no + 4], tobj, q.obj_pw, &dx);
+        float* d = dp + cell * q.no;
+        for (int k = 0; k < q.no; ++k) d[k] = 0.f;
+        d[4] = dx * obj_coef;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int t = LT / 2; t > 0; t >>= 1) {
+        if (threadIdx.x < t) red[threadIdx.x] += red[threadIdx.x + t];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// add the (scaled) box / class gradients of active candidates; also folds the objectness partial sums (block 0)
+__global__ __launch_bounds__(LT) void det_scatter_kernel(DetParams q, const Cand* __restrict__ cands,
+                                                         const float* __restrict__ dcls, float* __restrict__ dp,
+                                                         float box_coef, float cls_coef, float* __restrict__ acc,
+                                                         const float* __restrict__ partial, int npartial) {
+    const int ncand = 5 * q.na * q.nt;
+    const float n = acc[0];
+    const float kb = n > 0.f ? box_coef / n : 0.f;
+    const float kc = (n > 0.f && q.nc > 1) ? cls_coef / (n * (float)q.nc) : 0.f;
+    for (int id = blockIdx.x * LT + threadIdx.x; id < ncand; id += gridDim.x * LT) {
+        const Cand c = cands[id];
+        if (c.cell < 0) continue;
+        float* d = dp + (int64_t)c.cell * q.no;
+        for (int i = 0; i < 4; ++i) atomicAdd(&d[i], c.dbox[i] * kb);
+        if (q.nc > 1)
+            for (int k = 0; k < q.nc; ++k) atomicAdd(&d[5 + k], dcls[(int64_t)id * q.nc + k] * kc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < npartial; ++i) s += (double)partial[i];
+        acc[3] = (float)s;
+    }
+}
+
+// acc: [nl][4];  out[0] = (lbox + lobj + lcls) * bs, out[1..3] = lbox, lobj, lcls (already multiplied by their gains)
+struct DetMeta { float ncells[5], balance[5]; };
+__global__ void det_finalize_kernel(const float* __restrict__ acc, int nl, DetMeta meta, float h_box, float h_obj,
+                                    float h_cls, int nc, int bs, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lbox = 0.f, lobj = 0.f, lcls = 0.f;
+    for (int i = 0; i < nl; ++i) {
+        const float n = acc[i * 4];
+        if (n > 0.f) {
+            lbox += acc[i * 4 + 1] / n;
+            if (nc > 1) lcls += acc[i * 4 + 2] / (n * (float)nc);
+        }
+        lobj += acc[i * 4 + 3] / meta.ncells[i] * meta.balance[i];
+    }
+    lbox *= h_box; lobj *= h_obj; lcls *= h_cls;
+    out[0] = (lbox + lobj + lcls) * (float)bs;
+    out[1] = lbox; out[2] = lobj; out[3] = lcls;
+}
+
+// ---- segmentation cross entropy ---------------------------------------------------------------------------------------------
+// pass 1: per-block partial (sum of -log softmax[target], number of valid pixels)
+__global__ __launch_bounds__(LT) void seg_ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        int N, int C, int64_t HW, int ignore, float* __restrict__ partial) {
+    __shared__ float red[2][LT];
+    float s = 0.f, cnt = 0.f;
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)LT + threadIdx.x; i < total; i += (int64_t)gridDim.x * LT) {
+        const int64_t t = target[i];
+        if (t == ignore || t < 0 || t >= C) continue;
+        const int64_t n = i / HW, px = i - n * HW;
+        const float* l = logits + n * C * HW + px;
+        float m = l[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, l[c * HW]);
+        float z = 0.f;
+        for (int c = 0; c < C; ++c) z += expf(l[c * HW] - m);
+        s += logf(z) + m - l[t * HW];
+        cnt += 1.f;
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int t = LT / 2; t > 0; t >>= 1) {
+        if (threadIdx.x < t) { red[0][threadIdx.x] += red[0][threadIdx.x + t]; red[1][threadIdx.x] += red[1][threadIdx.x + t]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
+}
+// out[0] = mean loss, out[1] = 1 / valid count (0 when no pixel is valid)
+__global__ void seg_ce_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, c = 0.0;
+    for (int i = 0; i < n; ++i) { s += (double)partial[2 * i]; c += (double)partial[2 * i + 1]; }
+    out[0] = c > 0.0 ? (float)(s / c) : 0.f;      // torch returns nan for an all-ignored target; 0 keeps the step finite
+    out[1] = c > 0.0 ? (float)(1.0 / c) : 0.f;
+}
+// pass 2: dlogits = (softmax - onehot) / count   (0 for ignored pixels)
+__global__ __launch_bounds__(LT) void seg_ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        int N, int C, int64_t HW, int ignore, const float* __restrict__ fin,
+                                                        float* __restrict__ dlogits) {
+    const float inv = fin[1];
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)LT + threadIdx.x; i < total; i += (int64_t)gridDim.x * LT) {
+        const int64_t t = target[i];
+        const int64_t n = i / HW, px = i - n * HW;
+        const float* l = logits + n * C * HW + px;
+        float* d = dlogits + n * C * HW + px;
+        if (t == ignore || t < 0 || t >= C) {
+            for (int c = 0; c < C; ++c) d[c * HW] = 0.f;
+            continue;
+        }
+        float m = l[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, l[c * HW]);
+        float z = 0.f;
+        for (int c = 0; c < C; ++c) z += expf(l[c * HW] - m);
+        const float iz = 1.f / z;
+        for (int c = 0; c < C; ++c) d[c * HW] = (expf(l[c * HW] - m) * iz - (c == t ? 1.f : 0.f)) * inv;
+    }
+}
+
+inline int lgrid(int64_t total, int cap) {
+    int64_t b = (total + LT - 1) / LT;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int64_t dsn_det_loss_workspace_bytes(int32_t nl, int32_t na, int32_t nt, int32_t nc, int64_t max_cells) {
+    const int64_t ncand = (int64_t)5 * na * (nt > 0 ? nt : 1);
+    const int64_t per_level = ncand * (int64_t)sizeof(Cand) + ncand * nc * 4 + max_cells * 4 + 1024 * 4;
+    return nl * per_level + 256;
+}
+
+// p[i]: fp32 [bs, na, ny_i, nx_i, no] contiguous; dp[i]: same shape (gradient of out[0] w.r.t. p[i]); targets fp32 [nt,6]
+// (image, class, x, y, w, h normalised); anchors: [nl][na][2] HOST floats in grid units; balance: [nl] HOST floats.
+// out (device): [0] = (lbox + lobj + lcls) * bs, [1..3] = lbox, lobj, lcls.
+extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32_t* ny, const int32_t* nx, int32_t nl,
+                            int32_t bs, int32_t na, int32_t nc, const float* targets, int32_t nt, const float* anchors,
+                            const float* balance, float h_box, float h_obj, float h_cls, float cls_pw, float obj_pw,
+                            float anchor_t, float cp, float cn, float* out, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    DSN_CHECK_ARG(p && dp && ny && nx && out && workspace && anchors && balance && nl > 0 && nl <= 5 && na > 0 && na <= 3,
+                  "det_loss: bad arguments");
+    DSN_CHECK_ARG(nc >= 1 && nc <= MAX_NC && bs > 0 && nt >= 0 && (nt == 0 || targets), "det_loss: bad sizes");
+    int64_t max_cells = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int64_t c = (int64_t)bs * na * ny[i] * nx[i];
+        max_cells = c > max_cells ? c : max_cells;
+    }
+    if (workspace_bytes < dsn_det_loss_workspace_bytes(nl, na, nt, nc, max_cells))
+        DSN_FAIL(DSN_EWORKSPACE, "det_loss: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int no = nc + 5;
+    const int64_t ncand = (int64_t)5 * na * (nt > 0 ? nt : 1);
+    char* w = (char*)workspace;
+    float* acc = (float*)w;                 // [nl][4] + ncells[nl] + balance[nl]
+    w += 256;
+    hipError_t e = hipMemsetAsync(acc, 0, 256, st);
+    if (e != hipSuccess) DSN_FAIL((int)e, "det_loss: memset failed");
+    DetMeta meta{};
+    for (int i = 0; i < nl; ++i) {
+        meta.ncells[i] = (float)((int64_t)bs * na * ny[i] * nx[i]);
+        meta.balance[i] = balance[i];
+    }
+    // small constant tables go through kernel arguments of the finalize launch below (no H2D copy: capture-safe)
+    for (int i = 0; i < nl; ++i) {
+        DetParams q{};
+        q.bs = bs; q.na = na; q.no = no; q.nc = nc; q.ny = ny[i]; q.nx = nx[i]; q.nt = nt;
+        q.anchor_t = anchor_t; q.cls_pw = cls_pw; q.obj_pw = obj_pw; q.cp = cp; q.cn = cn;
+        for (int k = 0; k < 2 * na; ++k) q.anchors[k] = anchors[i * na * 2 + k];
+        Cand* cands = (Cand*)w;                          w += ncand * sizeof(Cand);
+        float* dcls = (float*)w;                         w += ncand * nc * 4;
+        int32_t* owner = (int32_t*)w;                    w += max_cells * 4;
+        float* partial = (float*)w;                      w += 1024 * 4;
+        const int64_t ncell = (int64_t)bs * na * ny[i] * nx[i];
+        e = hipMemsetAsync(owner, 0xFF, (size_t)ncell * 4, st);      // -1
+        if (e != hipSuccess) DSN_FAIL((int)e, "det_loss: memset failed");
+        if (nt > 0)
+            hipLaunchKernelGGL(det_match_kernel, dim3(1), dim3(LT), 0, st, p[i], targets, q, cands, dcls, owner, acc + i * 4);
+        const int ob = lgrid(ncell, 1024);
+        const float obj_coef = h_obj * balance[i] * (float)bs / (float)ncell;
+        hipLaunchKernelGGL(det_obj_kernel, dim3(ob), dim3(LT), 0, st, p[i], q, cands, owner, dp[i], obj_coef, partial);
+        hipLaunchKernelGGL(det_scatter_kernel, dim3(nt > 0 ? lgrid(ncand, 64) : 1), dim3(LT), 0, st, q, cands, dcls, dp[i],
+                           h_box * (float)bs, h_cls * (float)bs, acc + i * 4, partial, ob);
+        DSN_LAUNCH_CHECK("det_loss level");
+    }
+    hipLaunchKernelGGL(det_finalize_kernel, dim3(1), dim3(1), 0, st, acc, nl, meta, h_box, h_obj, h_cls, nc, bs, out);
+    DSN_LAUNCH_CHECK("det_loss finalize");
+    return DSN_OK;
+}
+
+extern "C" int64_t dsn_seg_ce_workspace_bytes(void) { return (int64_t)(2 * 1024 + 4) * sizeof(float); }
+
+// logits: contiguous NCHW fp32; target: int64 [N,H,W]; out (device) [0] = mean CE over valid pixels, [1] = 1/valid count;
+// dlogits (may be NULL): d(out[0]) / d(logits), same layout as logits.
+extern "C" int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
+                          int32_t ignore_index, float* out, float* dlogits, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+    DSN_CHECK_ARG(logits && target && out && workspace && n > 0 && c > 0 && c <= 1024 && h > 0 && w > 0,
+                  "seg_ce: bad arguments");
+    if (workspace_bytes < dsn_seg_ce_workspace_bytes()) DSN_FAIL(DSN_EWORKSPACE, "seg_ce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t HW = (int64_t)h * w;
+    const int nb = lgrid((int64_t)n * HW, 1024);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(nb), dim3(LT), 0, st, logits, target, n, c, HW, ignore_index, partial);
+    hipLaunchKernelGGL(seg_ce_finalize_kernel, dim3(1), dim3(1), 0, st, partial, nb, out);
+    if (dlogits)
+        hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(lgrid((int64_t)n * HW, 8192)), dim3(LT), 0, st, logits, target, n, c, HW,
+                           ignore_index, out, dlogits);
+    DSN_LAUNCH_CHECK("seg_ce");
+    return DSN_OK;
+}

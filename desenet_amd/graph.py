@@ -1,77 +1,70 @@
-"""hipGraph replay of the training step: the ~1300 kernel launches of one DeSeNet-s forward/backward are enqueued by ONE
-hipGraphLaunch instead of ~1300 Python->ctypes calls (host launch cost exceeded device time by 1.4x in eager mode).
+"""hipGraph replay of the training step: the ~1500 kernel launches of one DeSeNet-s step (weight pack, forward, losses,
+backward, optimizer) are enqueued by ONE hipGraphLaunch instead of ~1500 Python->ctypes calls (host launch cost exceeded
+device time by 1.4x in eager mode).  No tracing compiler is involved: capture records exactly the launches the eager path
+makes; every buffer the graph touches lives in its private memory pool and inputs are copied into static tensors.
 
-    G1 = [zero flat grads | pack weights | forward]          captured once, replayed per step
-         eager: losses on the (static) outputs -> d(raws), d(seg)      (PyTorch ops with data-dependent shapes; they become
-                                                                         HIP kernels and join the graph in a later round)
-    G2 = [backward through the model]                        captured once
-         eager: flat gradient all-reduce (RCCL), only when world_size > 1
-    G3 = [optimizer step]
-
-Everything the graphs touch lives in one private memory pool (tape buffers written by G1 are read by G2), inputs are
-copied into static tensors.  No tracing compiler is involved: capture records exactly the launches the eager path makes.
+    world_size == 1 : G = [zero flat grads | pack weights | forward | det + seg loss (HIP) | backward | optimizer step]
+    world_size  > 1 : G_a = [zero | pack | forward | losses | backward]  ->  eager RCCL all-reduce of the flat gradient
+                      buffer  ->  G_b = [optimizer step]
 """
 from __future__ import annotations
 
 from typing import Callable
 
 import torch
+import torch.distributed as dist
 
-from .runtime import Tape, flatten, unflatten
+from .runtime import Tape
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn: Callable, flat, optimizer, example_input: torch.Tensor, warmup: int = 3):
-        """loss_fn(det_out, seg_out) -> scalar loss tensor (eager).  `flat` is a parallel.FlatGradients."""
-        self.model, self.loss_fn, self.flat, self.opt = model, loss_fn, flat, optimizer
+    def __init__(self, model, loss_and_grads: Callable, flat, optimizer, example_input: torch.Tensor, warmup: int = 3):
+        """loss_and_grads(det_out, seg_out) -> (loss tensor, d_det, d_seg): HIP kernels only (capturable)."""
+        self.model, self.loss_and_grads, self.flat, self.opt = model, loss_and_grads, flat, optimizer
         self.x = example_input.clone()
         dev = self.x.device
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):          # populate caches / workspaces / optimizer state outside capture
-                self._eager_step()
+                self._body()
+                self.flat.all_reduce()
+                self.opt.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
 
         self.pool = torch.cuda.graph_pool_handle()
-        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        self.tape = Tape()
+        self.ga, self.gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.multi else None)
         with torch.no_grad():
-            with torch.cuda.graph(self.g1, pool=self.pool):
-                self.flat.zero()
-                self.outs = self.model.fwd(self.x, self.tape)
-        outs_flat, self.out_spec = flatten(self.outs)
-        self.d_outs = [torch.zeros_like(o) for o in outs_flat]
-        with torch.no_grad():
-            with torch.cuda.graph(self.g2, pool=self.pool):
-                self.tape.begin_backward()
-                self.model.bwd(self.tape, unflatten(self.out_spec, iter(self.d_outs)), need_dx=False)
-                for p, g in self.tape.grads.items():     # parameters without a pre-attached .grad slot (none with FlatGradients)
-                    p.grad.add_(g) if p.grad is not None else setattr(p, "grad", g)
-            with torch.cuda.graph(self.g3, pool=self.pool):
-                self.opt.step()
+            with torch.cuda.graph(self.ga, pool=self.pool):
+                self.loss = self._body()
+                if not self.multi:
+                    self.opt.step()
+            if self.multi:
+                with torch.cuda.graph(self.gb, pool=self.pool):
+                    self.opt.step()
         torch.cuda.synchronize(dev)
 
-    def _eager_step(self):
+    def _body(self):
         self.flat.zero()
-        det, seg = self.model(self.x)
-        self.loss_fn(det, seg).backward()
-        self.flat.all_reduce()
-        self.opt.step()
+        tape = Tape()
+        det, seg = self.model.fwd(self.x, tape)
+        loss, d_det, d_seg = self.loss_and_grads(det, seg)
+        tape.begin_backward()
+        self.model.bwd(tape, (d_det, d_seg), need_dx=False)
+        for p, g in tape.grads.items():          # parameters without a pre-attached .grad slot (none with FlatGradients)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return loss
 
     def __call__(self, x: torch.Tensor = None):
         if x is not None and x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x)
-        self.g1.replay()
-        outs_flat, _ = flatten(self.outs)
-        leaves = [o.detach().requires_grad_(True) for o in outs_flat]
-        det, seg = unflatten(self.out_spec, iter(leaves))
-        loss = self.loss_fn(det, seg)
-        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-        for d, g in zip(self.d_outs, grads):
-            d.zero_() if g is None else d.copy_(g)
-        self.g2.replay()
-        self.flat.all_reduce()
-        self.g3.replay()
-        return loss
+        self.ga.replay()
+        if self.multi:
+            self.flat.all_reduce()
+            self.gb.replay()
+        return self.loss

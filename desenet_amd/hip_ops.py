@@ -449,3 +449,49 @@ def profile_collect():
             out[L.dsn_profile_kernel_name(k).decode()] = dict(launches=int(buf[4 * k]), ms=buf[4 * k + 1],
                                                                flops=buf[4 * k + 2], bytes=buf[4 * k + 3])
     return out
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def det_loss(p, targets, anchors_host, balance, h_box, h_obj, h_cls, cls_pw, obj_pw, anchor_t, cp, cn, nc, gain=1.0):
+    """p: list of fp32 contiguous [bs,na,ny,nx,5+nc] raw Detect outputs.  Returns (out [4] = {gain*(lbox+lobj+lcls)*bs,
+    gain*lbox, gain*lobj, gain*lcls} on the device, [d out[0] / d p_i])."""
+    L = _lib.lib()
+    nl = len(p)
+    for t in p:
+        _require_gpu(t)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("det_loss expects contiguous fp32 [bs,na,ny,nx,no] tensors (Detect's raw outputs)")
+    bs, na, _, _, no = p[0].shape
+    nt = int(targets.shape[0])
+    tg = targets if (targets.dtype == torch.float32 and targets.is_contiguous()) else targets.float().contiguous()
+    dp = [torch.empty_like(t) for t in p]
+    ny = (C.c_int32 * nl)(*[t.shape[2] for t in p])
+    nx = (C.c_int32 * nl)(*[t.shape[3] for t in p])
+    pp = (C.c_void_p * nl)(*[t.data_ptr() for t in p])
+    dpp = (C.c_void_p * nl)(*[t.data_ptr() for t in dp])
+    anc = (C.c_float * (nl * na * 2))(*[float(v) for v in anchors_host])
+    bal = (C.c_float * nl)(*[float(v) for v in balance])
+    max_cells = max(t.numel() // no for t in p)
+    nbytes = L.dsn_det_loss_workspace_bytes(nl, na, nt, nc, max_cells)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=p[0].device)
+    out = torch.empty(4, dtype=torch.float32, device=p[0].device)
+    _lib.check(L.dsn_det_loss(pp, dpp, ny, nx, nl, bs, na, nc, tg.data_ptr() if nt else None, nt, anc, bal,
+                              h_box * gain, h_obj * gain, h_cls * gain, cls_pw, obj_pw, anchor_t, cp, cn, out.data_ptr(),
+                              ws.data_ptr(), nbytes, stream_ptr()), "det_loss")
+    return out, dp
+
+
+def seg_ce(logits, target, ignore_index=-1, want_grad=True):
+    """nn.CrossEntropyLoss(ignore_index) on contiguous NCHW fp32 logits.  Returns (out [2] = {loss, 1/valid}, dlogits|None)."""
+    _require_gpu(logits)
+    lg = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
+    tg = target if (target.dtype == torch.int64 and target.is_contiguous()) else target.long().contiguous()
+    n, c, h, w = lg.shape
+    L = _lib.lib()
+    nbytes = L.dsn_seg_ce_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=lg.device)
+    out = torch.empty(2, dtype=torch.float32, device=lg.device)
+    dl = torch.empty_like(lg) if want_grad else None
+    _lib.check(L.dsn_seg_ce(lg.data_ptr(), tg.data_ptr(), n, c, h, w, int(ignore_index), out.data_ptr(), _p(dl),
+                            ws.data_ptr(), nbytes, stream_ptr()), "seg_ce")
+    return out, dl

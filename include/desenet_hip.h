@@ -191,6 +191,22 @@ int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, float conf_thr
             int32_t multi_label, int32_t agnostic, uint64_t classes_mask, int32_t max_det, float* out,
             int32_t* out_count, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- training losses (core/utils/loss.py:91-243, core/utils/metrics.py:202-244); forward AND gradient w.r.t. the network
+ * outputs in one call, no host synchronisation (hipGraph-capturable) -------------------------------------------------------
+ * dsn_det_loss: ComputeLoss.__call__ + build_targets + CIoU.  p[i] / dp[i]: fp32 [bs,na,ny_i,nx_i,5+nc] (raw Detect outputs
+ *   and d(out[0])/d(p[i])); targets: device fp32 [nt,6] (image, class, x, y, w, h normalised); anchors: HOST [nl][na][2] in
+ *   grid units; balance: HOST [nl]; out: device [4] = {(lbox+lobj+lcls)*bs, lbox, lobj, lcls}.
+ * dsn_seg_ce: nn.CrossEntropyLoss(ignore_index), mean; logits contiguous NCHW fp32, target int64 [N,H,W];
+ *   out: device [2] = {loss, 1/valid}; dlogits (may be NULL) = d(loss)/d(logits). */
+int64_t dsn_det_loss_workspace_bytes(int32_t nl, int32_t na, int32_t nt, int32_t nc, int64_t max_cells);
+int dsn_det_loss(const float* const* p, float* const* dp, const int32_t* ny, const int32_t* nx, int32_t nl, int32_t bs,
+                 int32_t na, int32_t nc, const float* targets, int32_t nt, const float* anchors, const float* balance,
+                 float h_box, float h_obj, float h_cls, float cls_pw, float obj_pw, float anchor_t, float cp, float cn,
+                 float* out, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t dsn_seg_ce_workspace_bytes(void);
+int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
+               int32_t ignore_index, float* out, float* dlogits, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 /* dst[i] = (dtype) src[i]  (flat fp32 master -> bf16 copy) */
 int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream);

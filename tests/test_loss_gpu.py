@@ -1,0 +1,85 @@
+"""HIP loss kernels (rows a15 / a16) vs the CPU oracle (oracle/loss_ref.py = the reference's ComputeLoss /
+SegmentationLosses restated on ATen-CPU ops, pinned by tests/golden/train.npz): loss values and the gradient w.r.t. every
+network output.  fp32; tolerance 1e-4 on losses, 1e-3 on gradients (expf / atanf / log1pf device intrinsics)."""
+import pytest
+import torch
+
+from desenet_amd.synth import synth_targets
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+ANCHORS = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]).float().view(3, 3, 2) \
+    / torch.tensor([8., 16., 32.]).view(3, 1, 1)
+
+
+class _Det:
+    na, nc, nl, anchors = 3, 6, 3, ANCHORS
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, hyp):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.model = [_Det()]
+        self.hyp = hyp
+
+
+@pytest.mark.parametrize("bs,size,seed,nt", [(2, 128, 21, None), (4, 256, 5, None), (2, 128, 7, 0), (1, 64, 9, 3)])
+def test_det_loss_vs_oracle(bs, size, seed, nt):
+    from desenet_amd.core.utils.hyp import scale_hyp
+    from desenet_amd.core.utils.loss import ComputeLoss
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(seed)
+    p = [(torch.randn(bs, 3, size // s, size // s, 11, generator=g) * 2).requires_grad_(True) for s in (8, 16, 32)]
+    det_t, _ = synth_targets(bs, size, seed, boxes_per_image=16)
+    if nt is not None:
+        det_t = det_t[:nt]
+    hyp = scale_hyp(6, size)
+    ref, items = loss_ref.det_loss(p, det_t, ANCHORS, hyp, 6)
+    (ref * 0.5).sum().backward()
+    cl = ComputeLoss(_Model(hyp))
+    pd = [t.detach().cuda().requires_grad_(True) for t in p]
+    loss, it = cl(pd, det_t.cuda())
+    (loss * 0.5).sum().backward()
+    assert loss.shape == (1,) and it.shape == (3,)
+    assert_close(loss.cpu(), ref.detach(), 1e-4, "det loss")
+    assert_close(it.cpu(), items, 1e-4, "loss items")
+    for a, b in zip(pd, p):
+        assert_close(a.grad.cpu(), b.grad, 1e-3, "d det_loss / d raw")
+
+
+def test_det_loss_duplicate_cells_take_last_candidate():
+    """Two targets in the same cell matched by the same anchor: the objectness target is the later candidate's IoU (what the
+    reference's sequential scatter leaves behind on the CPU)."""
+    from desenet_amd.core.utils.hyp import scale_hyp
+    from desenet_amd.core.utils.loss import ComputeLoss
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(3)
+    p = [torch.randn(1, 3, 64 // s, 64 // s, 11, generator=g).requires_grad_(True) for s in (8, 16, 32)]
+    det_t = torch.tensor([[0, 1, 0.52, 0.52, 0.30, 0.35], [0, 4, 0.53, 0.51, 0.32, 0.30], [0, 2, 0.2, 0.7, 0.1, 0.12]])
+    hyp = scale_hyp(6, 64)
+    ref, items = loss_ref.det_loss(p, det_t, ANCHORS, hyp, 6)
+    ref.sum().backward()
+    pd = [t.detach().cuda().requires_grad_(True) for t in p]
+    loss, it = ComputeLoss(_Model(hyp))(pd, det_t.cuda())
+    loss.sum().backward()
+    assert_close(loss.cpu(), ref.detach(), 1e-4)
+    for a, b in zip(pd, p):
+        assert_close(a.grad.cpu(), b.grad, 1e-3)
+
+
+@pytest.mark.parametrize("shape,ignore_frac", [((2, 2, 64, 96), 0.0), ((1, 5, 33, 17), 0.3), ((8, 2, 640, 640), 0.05)])
+def test_seg_ce_vs_aten(shape, ignore_frac):
+    from desenet_amd.core.utils.loss import SegmentationLosses
+    g = torch.Generator().manual_seed(1)
+    logits = (torch.randn(shape, generator=g) * 3).requires_grad_(True)
+    n, c, h, w = shape
+    target = torch.randint(0, c, (n, h, w), generator=g)
+    target[torch.rand(n, h, w, generator=g) < ignore_frac] = -1
+    ref = torch.nn.functional.cross_entropy(logits, target, ignore_index=-1)
+    (ref * 2.0).backward()
+    ld = logits.detach().cuda().requires_grad_(True)
+    loss = SegmentationLosses()(ld, target.cuda())
+    (loss * 2.0).backward()
+    assert_close(loss.cpu(), ref.detach(), 1e-5, "CE")
+    assert_close(ld.grad.cpu(), logits.grad, 1e-4, "dCE")

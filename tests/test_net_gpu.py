@@ -228,3 +228,49 @@ def test_direct_accumulation_into_flat_gradients(net):
             else:
                 assert float(p.grad.abs().max()) == 0.0, k
     assert int(direct.state_dict()["model.0.conv.bn.num_batches_tracked"]) == 1
+
+
+def test_graph_replay_equals_eager_training(net):
+    """desenet_amd.graph.GraphedTrainStep (one hipGraph per step: pack + forward + HIP losses + backward + SGD) must walk
+    the same trajectory as the eager autograd path: 3 SGD steps from the same initial weights, fp32."""
+    import copy
+    from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN, scale_hyp
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from desenet_amd.graph import GraphedTrainStep
+    from desenet_amd.parallel import FlatGradients, sgd_param_groups
+    _, m = net
+    x = synth_images(2, 128, 21).cuda()
+    det_t, seg_t = synth_targets(2, 128, 21)
+    det_t, seg_t = det_t.cuda(), seg_t.cuda()
+
+    def setup():
+        mm = copy.deepcopy(m).train()
+        mm.hyp = scale_hyp(6, 128)
+        flat = FlatGradients(mm.parameters())
+        opt = torch.optim.SGD(sgd_param_groups(mm), lr=0.01, momentum=0.937, nesterov=True)
+        return mm, flat, opt, ComputeLoss(mm), SegmentationLosses()
+
+    me, flat, opt, cl, sl = setup()
+    for _ in range(3 + 3):                       # GraphedTrainStep warms up with 3 real steps before capturing
+        flat.zero()
+        det, seg = me(x)
+        (cl(det, det_t)[0] * DETGAIN + sl(seg, seg_t) * SEGGAIN).backward()
+        opt.step()
+
+    mg, flat_g, opt_g, clg, slg = setup()
+
+    def loss_and_grads(det, seg):
+        out, d_det = clg.forward_backward(det, det_t, gain=DETGAIN)
+        sout, d_seg = slg.forward_backward(seg, seg_t)
+        return out[0] + sout[0] * SEGGAIN, d_det, d_seg
+
+    step = GraphedTrainStep(mg, loss_and_grads, flat_g, opt_g, x, warmup=3)
+    for _ in range(3):
+        loss = step()
+    assert torch.isfinite(loss).all()
+    sd_e, sd_g = me.state_dict(), mg.state_dict()
+    for k in sd_e:
+        if sd_e[k].dtype.is_floating_point:
+            assert rel_err(sd_g[k].cpu(), sd_e[k].cpu()) < 2e-3, k
+        else:
+            assert torch.equal(sd_g[k].cpu(), sd_e[k].cpu()), k
