@@ -201,10 +201,12 @@ __global__ __launch_bounds__(LT) void det_scatter_kernel(DetParams q, const Cand
         if (q.nc > 1)
             for (int k = 0; k < q.nc; ++k) atomicAdd(&d[5 + k], dcls[(int64_t)id * q.nc + k] * kc);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
         double s = 0.0;
-        for (int i = 0; i < npartial; ++i) s += (double)partial[i];
-        acc[3] = (float)s;
+        for (int i = threadIdx.x; i < npartial; i += 64) s += (double)partial[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (threadIdx.x == 0) acc[3] = (float)s;
     }
 }
 
@@ -254,13 +256,16 @@ __global__ __launch_bounds__(LT) void seg_ce_fwd_kernel(const float* __restrict_
     }
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
 }
-// out[0] = mean loss, out[1] = 1 / valid count (0 when no pixel is valid)
-__global__ void seg_ce_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = mean loss, out[1] = 1 / valid count (0 when no pixel is valid); one wave folds the block partials
+__global__ __launch_bounds__(64) void seg_ce_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
     double s = 0.0, c = 0.0;
-    for (int i = 0; i < n; ++i) { s += (double)partial[2 * i]; c += (double)partial[2 * i + 1]; }
-    out[0] = c > 0.0 ? (float)(s / c) : 0.f;      // torch returns nan for an all-ignored target; 0 keeps the step finite
-    out[1] = c > 0.0 ? (float)(1.0 / c) : 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) { s += (double)partial[2 * i]; c += (double)partial[2 * i + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); c += __shfl_down(c, off); }
+    if (threadIdx.x == 0) {
+        out[0] = c > 0.0 ? (float)(s / c) : 0.f;      // torch returns nan for an all-ignored target; 0 keeps the step finite
+        out[1] = c > 0.0 ? (float)(1.0 / c) : 0.f;
+    }
 }
 // pass 2: dlogits = (softmax - onehot) / count   (0 for ignored pixels)
 __global__ __launch_bounds__(LT) void seg_ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
@@ -372,7 +377,7 @@ extern "C" int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n,
     const int nb = lgrid((int64_t)n * HW, 1024);
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(nb), dim3(LT), 0, st, logits, target, n, c, HW, ignore_index, partial);
-    hipLaunchKernelGGL(seg_ce_finalize_kernel, dim3(1), dim3(1), 0, st, partial, nb, out);
+    hipLaunchKernelGGL(seg_ce_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nb, out);
     if (dlogits)
         hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(lgrid((int64_t)n * HW, 8192)), dim3(LT), 0, st, logits, target, n, c, HW,
                            ignore_index, out, dlogits);

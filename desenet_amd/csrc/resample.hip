@@ -235,11 +235,16 @@ __global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, int64_t yl
         const int w = (int)(t % W); t /= W;
         const int h = (int)(t % H);
         const int n = (int)(t / H);
+        // bins overlap by at most one pixel: only the bins around floor(h*K/H) can contain h
+        const int oh0 = (h * KH) / H, ow0 = (w * KW) / W;
         float s = 0.f;
-        for (int oh = 0; oh < KH; ++oh) {
+        // (maps smaller than the pool grid have bins overlapping further: scan them all)
+        const int oh_lo = H < KH ? 0 : (oh0 > 0 ? oh0 - 1 : 0), oh_hi = H < KH ? KH - 1 : (oh0 + 1 < KH ? oh0 + 1 : KH - 1);
+        const int ow_lo = W < KW ? 0 : (ow0 > 0 ? ow0 - 1 : 0), ow_hi = W < KW ? KW - 1 : (ow0 + 1 < KW ? ow0 + 1 : KW - 1);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
             const int h0 = bin_lo(oh, H, KH), h1 = bin_hi(oh, H, KH);
             if (h < h0 || h >= h1) continue;
-            for (int ow = 0; ow < KW; ++ow) {
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
                 const int w0 = bin_lo(ow, W, KW), w1 = bin_hi(ow, W, KW);
                 if (w < w0 || w >= w1) continue;
                 s += to_f32<T>(dy[(((int64_t)n * KH + oh) * KW + ow) * yld + c]) / (float)((h1 - h0) * (w1 - w0));

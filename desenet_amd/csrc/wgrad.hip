@@ -20,15 +20,16 @@ struct WGeom {
     int32_t oihw;         // final output layout: 0 = packed [Co][tap][Cip], 1 = OIHW [Co][Ci][tap]
 };
 
-constexpr int PK = 32;    // pixels per chunk
 constexpr int TB = 64;    // tile edge (co and ci)
 
 template <typename T> struct WTraits;
 template <> struct WTraits<float> {
     static constexpr int VEC = 4, ROW = TB + 16;   // padded row (floats): lanes l and l+16 land 16 banks apart
+    static constexpr int PK = 32;                  // pixels per chunk
 };
 template <> struct WTraits<bf16_t> {
     static constexpr int VEC = 8, ROW = TB;        // 128-byte rows for the transposing read
+    static constexpr int PK = 32;                  // pixels per chunk (128 measured slower: fewer, longer blocks)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -37,9 +38,10 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <typename T, bool VECLOAD>
 __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                     float* __restrict__ out, const WGeom g) {
-    constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW;
+    constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW, PK = WTraits<T>::PK;
     constexpr int VPR = TB / VEC;          // vectors per tile row
-    constexpr int NV = VPR / 8;            // vectors per thread per operand (8 threads per row)
+    constexpr int NV = VPR / 8;            // vectors per thread per row (8 threads per row)
+    constexpr int RG = PK / 32;            // row groups: thread (srow, sv) stages rows srow + 32*rg
     __shared__ __attribute__((aligned(16))) T sA[2][PK * ROW];
     __shared__ __attribute__((aligned(16))) T sB[2][PK * ROW];
 
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
 
     const int srow = tid >> 3;      // staged pixel row 0..31
     const int sv = tid & 7;         // first vector of the row
-    u32x4 ra[NV], rb[NV];
+    u32x4 ra[RG][NV], rb[RG][NV];
 
     auto load_vec = [&](const T* p, int c, int climit) -> u32x4 {
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -75,33 +77,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
         return v;
     };
     auto load_chunk = [&](int ch) {
-        const int p = p_begin + ch * PK + srow;
-        const bool pok = p < p_end;
-        int ox = 0, oy = 0, n = 0;
-        if (pok) {
-            ox = p % g.Wo;
-            const int t = p / g.Wo;
-            oy = t % g.Ho;
-            n = t / g.Ho;
-        }
-        const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
-        const bool xok = pok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vc = (sv + 8 * i) * VEC;
-            ra[i] = u32x4{0u, 0u, 0u, 0u};
-            rb[i] = u32x4{0u, 0u, 0u, 0u};
-            if (pok) ra[i] = load_vec(dy + (int64_t)p * g.yld + co0 + vc, co0 + vc, g.Co);
-            if (xok) rb[i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.CiLoad);
+        for (int rg = 0; rg < RG; ++rg) {
+            const int p = p_begin + ch * PK + srow + 32 * rg;
+            const bool pok = p < p_end;
+            int ox = 0, oy = 0, n = 0;
+            if (pok) {
+                ox = p % g.Wo;
+                const int t = p / g.Wo;
+                oy = t % g.Ho;
+                n = t / g.Ho;
+            }
+            const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
+            const bool xok = pok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int vc = (sv + 8 * i) * VEC;
+                ra[rg][i] = u32x4{0u, 0u, 0u, 0u};
+                rb[rg][i] = u32x4{0u, 0u, 0u, 0u};
+                if (pok) ra[rg][i] = load_vec(dy + (int64_t)p * g.yld + co0 + vc, co0 + vc, g.Co);
+                if (xok)
+                    rb[rg][i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.CiLoad);
+            }
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vc = (sv + 8 * i) * VEC;
-            *reinterpret_cast<u32x4*>(&sA[buf][srow * ROW + vc]) = ra[i];
-            *reinterpret_cast<u32x4*>(&sB[buf][srow * ROW + vc]) = rb[i];
-        }
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int vc = (sv + 8 * i) * VEC;
+                *reinterpret_cast<u32x4*>(&sA[buf][(srow + 32 * rg) * ROW + vc]) = ra[rg][i];
+                *reinterpret_cast<u32x4*>(&sB[buf][(srow + 32 * rg) * ROW + vc]) = rb[rg][i];
+            }
     };
 
     f32x4 acc[2][2];
@@ -131,28 +139,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block; it receives column (lane&15),
             // rows 0..3.  Block rows = pixels 8*fg + {0..3} then {4..7}; block columns = the fragment's 16 channels.
             const int q = fr >> 2, pp = fr & 3;
-            bf16x8 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bf16_t* base = &sA[buf][(8 * fg + q) * ROW + (wm * 2 + i) * 16 + 4 * pp];
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
-                const s16x4 hi =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
-                a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int ks = 0; ks < PK / 32; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16_t* base = &sA[buf][(32 * ks + 8 * fg + q) * ROW + (wm * 2 + i) * 16 + 4 * pp];
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+                    a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16_t* base = &sB[buf][(32 * ks + 8 * fg + q) * ROW + (wn * 2 + j) * 16 + 4 * pp];
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+                    b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bf16_t* base = &sB[buf][(8 * fg + q) * ROW + (wn * 2 + j) * 16 + 4 * pp];
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
-                const s16x4 hi =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
-                b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -265,6 +276,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     g.yld = dy->ldc; g.xld = x->ldc;
     g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
     g.S = choose_split(g);
+    const int PK = x->dtype == DSN_F32 ? WTraits<float>::PK : WTraits<bf16_t>::PK;
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
     g.accumulate = p->accumulate;
