@@ -141,6 +141,14 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     return out
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 def _grad_slot(p):
     """The parameter's existing fp32 contiguous .grad (kernels then accumulate into it directly), else None."""
     if p is None or not p.requires_grad:
@@ -181,19 +189,25 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
         if not direct:
             tape.add_grad(bn.weight, dg)
             tape.add_grad(bn.bias, db)
-    if conv.weight.requires_grad:
-        co, ci, kh, kw = conv.weight.shape
-        slot = _grad_slot(conv.weight)
-        g = slot if slot is not None else torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device)
-        ops.conv2d_wgrad(x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None), oihw=True)
-        if slot is None:
-            tape.add_grad(conv.weight, g)
-    if conv.bias is not None and conv.bias.requires_grad:
-        slot = _grad_slot(conv.bias)
-        if slot is not None:
-            slot.add_(_channel_sum(dy))
-        else:
-            tape.add_grad(conv.bias, _channel_sum(dy))
+    side = tape.fork(x.device) if (conv.weight.requires_grad or conv.bias is not None) else None
+    ctx_mgr = torch.cuda.stream(side) if side is not None else _NullCtx()
+    with ctx_mgr:
+        if conv.weight.requires_grad:
+            co, ci, kh, kw = conv.weight.shape
+            slot = _grad_slot(conv.weight)
+            g = slot if slot is not None else torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device)
+            ops.conv2d_wgrad(x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None), oihw=True)
+            if slot is None:
+                tape.add_grad(conv.weight, g)
+        if conv.bias is not None and conv.bias.requires_grad:
+            slot = _grad_slot(conv.bias)
+            if slot is not None:
+                slot.add_(_channel_sum(dy))
+            else:
+                tape.add_grad(conv.bias, _channel_sum(dy))
+    if side is not None:
+        dy.record_stream(side)     # dy is freed when this function returns; the side stream may still be reading it
+        x.record_stream(side)
     if not need_dx:
         return None
     if dx is None:

@@ -7,6 +7,8 @@
 // row-major [pixel][channel] in LDS with coalesced 16-byte loads and transposed on the way OUT of LDS:
 //   fp32 : v_mfma_f32_16x16x4_f32 takes one scalar per lane  -> plain ds_read_b32 from a padded image
 //   bf16 : v_mfma_f32_16x16x32_bf16 takes 8 K-contiguous bf16 -> two ds_read_b64_tr_b16 (hardware transpose) per fragment
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -35,10 +37,10 @@ template <> struct WTraits<bf16_t> {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <typename T, bool VECLOAD>
+template <typename T, bool VECLOAD, int PK>
 __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                     float* __restrict__ out, const WGeom g) {
-    constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW, PK = WTraits<T>::PK;
+    constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW;
     constexpr int VPR = TB / VEC;          // vectors per tile row
     constexpr int NV = VPR / 8;            // vectors per thread per row (8 threads per row)
     constexpr int RG = PK / 32;            // row groups: thread (srow, sv) stages rows srow + 32*rg
@@ -276,7 +278,8 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     g.yld = dy->ldc; g.xld = x->ldc;
     g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
     g.S = choose_split(g);
-    const int PK = x->dtype == DSN_F32 ? WTraits<float>::PK : WTraits<bf16_t>::PK;
+    static int pk_bf16 = [] { const char* e = getenv("DSN_WGRAD_PK"); int v = e ? atoi(e) : 32; return (v == 64 || v == 128) ? v : 32; }();
+    const int PK = x->dtype == DSN_F32 ? 32 : pk_bf16;
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
     g.accumulate = p->accumulate;
@@ -304,12 +307,18 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     {
     ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), 2.0 * g.P * g.Co * g.Ci * g.KH * g.KW,
                    ((double)npix(x) * g.Ci + (double)g.P * g.Co) * es + (double)n_out * 4, st);
-    DSN_DISPATCH_DTYPE(x->dtype, T, {
+    if (x->dtype == DSN_F32) {
         if (vl)
-            hipLaunchKernelGGL((wgrad_kernel<T, true>), grid, block, 0, st, (const T*)x->ptr, (const T*)dy->ptr, out, g);
+            hipLaunchKernelGGL((wgrad_kernel<float, true, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
         else
-            hipLaunchKernelGGL((wgrad_kernel<T, false>), grid, block, 0, st, (const T*)x->ptr, (const T*)dy->ptr, out, g);
-    });
+            hipLaunchKernelGGL((wgrad_kernel<float, false, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
+    } else {
+        const bf16_t *xp = (const bf16_t*)x->ptr, *yp = (const bf16_t*)dy->ptr;
+        if (!vl) hipLaunchKernelGGL((wgrad_kernel<bf16_t, false, 32>), grid, block, 0, st, xp, yp, out, g);
+        else if (PK == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 128>), grid, block, 0, st, xp, yp, out, g);
+        else if (PK == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 64>), grid, block, 0, st, xp, yp, out, g);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 32>), grid, block, 0, st, xp, yp, out, g);
+    }
     }
     DSN_LAUNCH_CHECK("conv wgrad");
     if (g.S > 1) {

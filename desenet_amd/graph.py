@@ -53,6 +53,7 @@ class GraphedTrainStep:
         loss, d_det, d_seg = self.loss_and_grads(det, seg)
         tape.begin_backward()
         self.model.bwd(tape, (d_det, d_seg), need_dx=False)
+        tape.join()                              # weight gradients run on a side stream (parallel graph branch)
         for p, g in tape.grads.items():          # parameters without a pre-attached .grad slot (none with FlatGradients)
             if p.grad is None:
                 p.grad = g

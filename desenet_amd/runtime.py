@@ -36,6 +36,28 @@ def compute_dtype():
     return _compute_dtype
 
 
+# ---- side stream for weight gradients --------------------------------------------------------------------------------------
+# dW = wgrad(x, dy) feeds nothing but the optimizer, so it is taken off the critical path of backward: it runs on a second
+# HIP stream, forked after dy is ready and joined once at the end of the backward pass.  Under hipGraph capture this
+# becomes a parallel branch of the graph (the layers are small: concurrent kernels fill CUs that would idle otherwise).
+_side_streams = {}
+_use_side_stream = False    # measured: no gain under hipGraph replay on ROCm 7.2 (branches are not overlapped); opt-in
+
+
+def set_wgrad_side_stream(on: bool):
+    global _use_side_stream
+    _use_side_stream = bool(on)
+
+
+def wgrad_stream(device):
+    if not _use_side_stream:
+        return None
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class Tape:
     """LIFO of forward records with a replayable cursor (two backward() calls on one forward, train.py:366-367)."""
 
@@ -50,6 +72,21 @@ class Tape:
     def begin_backward(self):
         self.cursor = len(self.stack)
         self.grads = {}
+        self.forked = set()
+
+    def fork(self, device):
+        """Side stream that may start once everything enqueued so far on the current stream is done (or None)."""
+        side = wgrad_stream(device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(device))
+            self.forked.add(side)
+        return side
+
+    def join(self):
+        """The current stream waits for every side stream used since begin_backward()."""
+        for side in getattr(self, "forked", ()):
+            torch.cuda.current_stream(side.device).wait_stream(side)
+        self.forked = set()
 
     def pop(self):
         self.cursor -= 1
@@ -120,6 +157,7 @@ class HipFunction(torch.autograd.Function):
         tape.begin_backward()
         with torch.no_grad():
             dx = ctx.module.bwd(tape, dy, need_dx=any(ctx.in_needs))
+            tape.join()
         dxs: List[Optional[torch.Tensor]] = []
         if dx is not None:
             dxs, _ = flatten(dx)

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single kernels on DeSeNet-s layer shapes (batch 8, 640x640, bf16): wgrad / conv fwd / dgrad.
+Times with torch.cuda events over many back-to-back launches (launch overhead amortised by a graph replay)."""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from desenet_amd import hip_ops as ops
+
+LAYERS = [  # name, N, Ci, H, W, Co, k, s
+    ("focus 16->32 k3 @320", 8, 16, 320, 320, 32, 3, 1),
+    ("l1 32->64 k3s2 @320", 8, 32, 320, 320, 64, 3, 2),
+    ("c3 cv1 64->32 k1 @160", 8, 64, 160, 160, 32, 1, 1),
+    ("bneck 32->32 k3 @160", 8, 32, 160, 160, 32, 3, 1),
+    ("c3 cv1 128->64 k1 @80", 8, 128, 80, 80, 64, 1, 1),
+    ("bneck 64->64 k3 @80", 8, 64, 80, 80, 64, 3, 1),
+    ("bneck 128->128 k3 @40", 8, 128, 40, 40, 128, 3, 1),
+    ("c3 cv3 256->256 k1 @40", 8, 256, 40, 40, 256, 1, 1),
+    ("l7 256->512 k3s2 @40", 8, 256, 40, 40, 512, 3, 2),
+    ("bneck 256->256 k3 @20", 8, 256, 20, 20, 256, 3, 1),
+    ("ffm 256->128 k3 @80", 8, 256, 80, 80, 128, 3, 1),
+]
+
+
+def timeit(fn, iters=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def main():
+    dt = torch.bfloat16
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for name, n, ci, h, w, co, k, s in LAYERS:
+        pad = k // 2
+        ho, wo = ops.conv_out_hw(h, w, k, s, pad, 1)
+        x = ops.new_act(n, ci, h, w, dt, "cuda"); x.normal_()
+        dy = ops.new_act(n, co, ho, wo, dt, "cuda"); dy.normal_()
+        wt = torch.randn(co, ci, k, k, device="cuda") * 0.05
+        wf, wd = ops.pack_weight_fwd(wt, dt), ops.pack_weight_dgrad(wt, dt)
+        y = ops.new_act(n, co, ho, wo, dt, "cuda")
+        dx = ops.new_act(n, ci, h, w, dt, "cuda")
+        g = torch.zeros(co, ci, k, k, device="cuda")
+        p = ops.conv_params(k, s, pad, 1)
+        flops = 2.0 * n * ho * wo * co * ci * k * k
+        byts = (x.numel() + dy.numel()) * 2
+        res = {}
+        if which in ("all", "fwd"):
+            res["fwd"] = timeit(lambda: ops.conv2d_fwd(x, wf, None, None, y, p))
+        if which in ("all", "dgrad"):
+            res["dgrad"] = timeit(lambda: ops.conv2d_dgrad(dy, wd, dx, p))
+        if which in ("all", "wgrad"):
+            res["wgrad"] = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ci, p, oihw=True))
+        print(f"{name:26s} GF {flops/1e9:6.2f} MB {byts/1e6:6.1f} | " +
+              " | ".join(f"{k_} {v:7.1f} us {flops/v/1e6:6.1f} TF/s {byts/v/1e3:6.0f} GB/s" for k_, v in res.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
