@@ -35,6 +35,12 @@ struct Geom {
     int64_t sld, dld, rld;
     int32_t tiles_m, tiles_n;
     int32_t is_dgrad;
+    // stride-2 dgrad by destination-pixel parity class (py, px): only the taps that can reach a class are visited
+    // (1 + 2 + 2 + 4 of the 9 taps of a 3x3 instead of 9 masked ones for every pixel).  Class c = py*2 + px.
+    int32_t cls_tile0[5];      // first M-tile of each class (cls_tile0[4] = tiles_m)
+    int32_t cls_h[4], cls_w[4];
+    int32_t cls_ntaps[4];
+    uint8_t cls_taps[4][12];   // tap index ky*KW + kx
 };
 
 template <typename T> struct Mma;
@@ -73,7 +79,7 @@ template <int BM, int BN> constexpr int smem_bytes() {
     return loop > epi ? loop : epi;
 }
 
-template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD>
+template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD, bool PAR>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
                                                     T* __restrict__ dst, float* __restrict__ stats, const Geom g) {
@@ -92,6 +98,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    // ---- destination rows of this tile -----------------------------------------------------------------------------
+    // plain: row r of tile tm is destination pixel m0 + r.  PAR: tile tm belongs to parity class cls and row r is the
+    // r-th pixel (n, yh, xh) of that class, i.e. destination pixel (n, 2*yh + py, 2*xh + px).
+    int cls = 0, cm0 = m0, cH = g.Hd, cW = g.Wd, cpy = 0, cpx = 0, cM = g.M;
+    if (PAR) {
+        while (cls < 3 && tm >= g.cls_tile0[cls + 1]) ++cls;
+        cm0 = (tm - g.cls_tile0[cls]) * BM;
+        cH = g.cls_h[cls]; cW = g.cls_w[cls];
+        cpy = cls >> 1; cpx = cls & 1;
+        cM = (g.M / (g.Hd * g.Wd)) * cH * cW;
+    }
+    auto dst_pixel = [&](int r, int& y, int& x, int& n) -> bool {     // r: row within the tile
+        const int m = cm0 + r;
+        if (r >= BM || m >= cM) return false;
+        x = m % cW;
+        const int t = m / cW;
+        y = t % cH;
+        n = t / cH;
+        if (PAR) { y = 2 * y + cpy; x = 2 * x + cpx; }
+        return true;
+    };
+
     // ---- per-thread staging rows -----------------------------------------------------------------------------
     const int v = tid & 7;          // 16-byte vector within the 128-byte chunk
     const int r0 = tid >> 3;        // row 0..31 (+32*i)
@@ -100,17 +128,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     bool rowok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int r = r0 + 32 * i;
-        const int m = m0 + r;
-        rowok[i] = (r < BM) && (m < g.M);
-        const int mm = rowok[i] ? m : 0;
-        const int x = mm % g.Wd, t = mm / g.Wd;
-        const int y = t % g.Hd, n = t / g.Hd;
+        int y = 0, x = 0, n = 0;
+        rowok[i] = dst_pixel(r0 + 32 * i, y, x, n);
         py[i] = y * g.a + g.b;
         px[i] = x * g.a + g.b;
         nbase[i] = (int64_t)n * g.Hs * g.Ws;
     }
-    const int nchunks = (g.Ktot + KC - 1) / KC;
+    const int Kc = PAR ? g.cls_ntaps[cls] * g.Cs : g.Ktot;      // K extent of this tile
+    const int nchunks = (Kc + KC - 1) / KC;
 
     u32x4 ra[AR], rb[BR];
 
@@ -130,9 +155,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     auto load_chunk = [&](int ch) {
         const int k0 = ch * KC + v * VEC;
         if (VECLOAD) {
-            const bool kok = k0 < g.Ktot;
-            const int tap = k0 / g.Cs, c = k0 - tap * g.Cs;
+            const bool kok = k0 < Kc;
+            int tap = k0 / g.Cs;
+            const int c = k0 - tap * g.Cs;
+            if (PAR) tap = kok ? g.cls_taps[cls][tap] : 0;
             const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            const int kb = PAR ? tap * g.Cs + c : k0;           // position of this vector in the packed weight row
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 u32x4 val = {0u, 0u, 0u, 0u};
@@ -144,7 +172,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
             for (int i = 0; i < BR; ++i) {
                 u32x4 val = {0u, 0u, 0u, 0u};
                 const int r = r0 + 32 * i, n = n0 + r;
-                if (kok && r < BN && n < g.Cd) val = *reinterpret_cast<const u32x4*>(wpk + (int64_t)n * g.Ktot + k0);
+                if (kok && r < BN && n < g.Cd) val = *reinterpret_cast<const u32x4*>(wpk + (int64_t)n * g.Ktot + kb);
                 rb[i] = val;
             }
         } else {   // generic path: per-element tap decode (channel counts that are not a multiple of the vector width)
@@ -219,8 +247,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     };
 
     // ---- main loop: register-staged double buffering ------------------------------------------------------------
-    load_chunk(0);
-    store_chunk(0);
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
     __syncthreads();
     for (int it = 0; it < nchunks; ++it) {
         const int buf = it & 1;
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         const int tx = tid % BN, ty = tid / BN;
         float s = 0.f, ss = 0.f;
         if (ty < TYS) {
-            const int rows = (g.M - m0 < BM) ? g.M - m0 : BM;
+            const int rows = (cM - cm0 < BM) ? cM - cm0 : BM;
             for (int r = ty; r < rows; r += TYS) {
                 const float val = sC[r * LDC + tx];
                 s += val;
@@ -285,7 +315,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         constexpr int VPR = BN / VEC;               // vectors per tile row
         for (int idx = tid; idx < BM * VPR; idx += 256) {
             const int rl = idx / VPR, cv = idx - rl * VPR;
-            const int row = m0 + rl, col = n0 + cv * VEC;
+            const int col = n0 + cv * VEC;
+            int row = m0 + rl;
+            if (PAR) {
+                int y, x, n;
+                if (!dst_pixel(rl, y, x, n)) continue;
+                row = (n * g.Hd + y) * g.Wd + x;
+            }
             if (row >= g.M || col >= g.Cd) continue;
             float vals[VEC];
 #pragma unroll
@@ -314,7 +350,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     } else {
         for (int idx = tid; idx < BM * BN; idx += 256) {
             const int rl = idx / BN, cl = idx - rl * BN;
-            const int row = m0 + rl, col = n0 + cl;
+            const int col = n0 + cl;
+            int row = m0 + rl;
+            if (PAR) {
+                int y, x, n;
+                if (!dst_pixel(rl, y, x, n)) continue;
+                row = (n * g.Hd + y) * g.Wd + x;
+            }
             if (row >= g.M || col >= g.Cd) continue;
             float val = sC[rl * LDC + cl];
             if (res) val += to_f32<T>(res[(int64_t)row * g.rld + col]);
@@ -331,7 +373,29 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
                         : (BM == 128 && BN == 32) ? 3 : 4;
-    g.tiles_m = (g.M + BM - 1) / BM;
+    const bool par = g.is_dgrad && g.q == 2 && vec;
+    if (par) {
+        const int nimg = g.M / (g.Hd * g.Wd);
+        int t = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int py = c >> 1, px = c & 1;
+            g.cls_h[c] = (g.Hd - py + 1) / 2;
+            g.cls_w[c] = (g.Wd - px + 1) / 2;
+            g.cls_tile0[c] = t;
+            t += (int)(((int64_t)nimg * g.cls_h[c] * g.cls_w[c] + BM - 1) / BM);
+            int nt = 0;
+            for (int ky = 0; ky < g.KH; ++ky)
+                for (int kx = 0; kx < g.KW; ++kx) {
+                    const int vy = py + g.b + ky * g.d, vx = px + g.b + kx * g.d;     // b = +pad, d = -dil
+                    if (((vy % 2) + 2) % 2 == 0 && ((vx % 2) + 2) % 2 == 0 && nt < 12) g.cls_taps[c][nt++] = (uint8_t)(ky * g.KW + kx);
+                }
+            g.cls_ntaps[c] = nt;
+        }
+        g.cls_tile0[4] = t;
+        g.tiles_m = t;
+    } else {
+        g.tiles_m = (g.M + BM - 1) / BM;
+    }
     g.tiles_n = (g.Cd + BN - 1) / BN;
     if (tiles_m_out) *tiles_m_out = g.tiles_m;
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
@@ -341,10 +405,12 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd;
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
                    elems * sizeof(T), st);
-    if (vec)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
+    if (par)
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, true>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
+    else if (vec)
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, false>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false, false>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
     DSN_LAUNCH_CHECK("igemm");
     return DSN_OK;
 }
