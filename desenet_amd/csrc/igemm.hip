@@ -35,6 +35,7 @@ struct Geom {
     int64_t sld, dld, rld;
     int32_t tiles_m, tiles_n;
     int32_t is_dgrad;
+    int32_t fits32;       // every source element offset fits a signed 32-bit integer
     // stride-2 dgrad by destination-pixel parity class (py, px): only the taps that can reach a class are visited
     // (1 + 2 + 2 + 4 of the 9 taps of a 3x3 instead of 9 masked ones for every pixel).  Class c = py*2 + px.
     int32_t cls_tile0[5];      // first M-tile of each class (cls_tile0[4] = tiles_m)
@@ -152,21 +153,59 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         return ok ? src + (nbase[i] + (int64_t)sy * g.Ws + sx) * g.sld : nullptr;
     };
 
+    // incremental (tap, channel) decode of this thread's 16-byte vector: chunks are visited in order, so k advances by
+    // KC per call -- no integer division in the loop (the address arithmetic, not memory, was the bottleneck: ~200 VALU
+    // instructions per chunk per thread before)
+    int kc_c = v * VEC, kc_tap = 0, kc_ky = 0, kc_kx = 0;
+    auto kc_norm = [&]() {
+        while (kc_c >= g.Cs) {
+            kc_c -= g.Cs;
+            ++kc_tap;
+            if (++kc_kx == g.KW) { kc_kx = 0; ++kc_ky; }
+        }
+    };
+    kc_norm();
+    // stride-1 gathers (every forward conv with q == 1): per-row element offset of (n, py, px), 32-bit when the tensor fits
+    const bool fast = !PAR && g.q == 1 && g.fits32;
+    int32_t base_off[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) base_off[i] = (int32_t)((nbase[i] + (int64_t)py[i] * g.Ws + px[i]) * g.sld);
+
     auto load_chunk = [&](int ch) {
         const int k0 = ch * KC + v * VEC;
         if (VECLOAD) {
             const bool kok = k0 < Kc;
-            int tap = k0 / g.Cs;
-            const int c = k0 - tap * g.Cs;
-            if (PAR) tap = kok ? g.cls_taps[cls][tap] : 0;
-            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            int tap, c, ky, kx;
+            if (PAR) {
+                tap = k0 / g.Cs;
+                c = k0 - tap * g.Cs;
+                tap = kok ? g.cls_taps[cls][tap] : 0;
+                ky = tap / g.KW; kx = tap - ky * g.KW;
+            } else {
+                tap = kc_tap; c = kc_c; ky = kc_ky; kx = kc_kx;
+                kc_c += KC;
+                kc_norm();
+            }
             const int kb = PAR ? tap * g.Cs + c : k0;           // position of this vector in the packed weight row
+            if (fast) {
+                const int dyo = ky * g.d, dxo = kx * g.d;
+                const int32_t off_tap = (dyo * g.Ws + dxo) * (int32_t)g.sld + c;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                u32x4 val = {0u, 0u, 0u, 0u};
-                const T* p = kok ? src_row(i, ky, kx) : nullptr;
-                if (p) val = *reinterpret_cast<const u32x4*>(p + c);
-                ra[i] = val;
+                for (int i = 0; i < AR; ++i) {
+                    u32x4 val = {0u, 0u, 0u, 0u};
+                    const bool ok = kok && rowok[i] && (unsigned)(py[i] + dyo) < (unsigned)g.Hs &&
+                                    (unsigned)(px[i] + dxo) < (unsigned)g.Ws;
+                    if (ok) val = *reinterpret_cast<const u32x4*>(src + (base_off[i] + off_tap));
+                    ra[i] = val;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    u32x4 val = {0u, 0u, 0u, 0u};
+                    const T* p = kok ? src_row(i, ky, kx) : nullptr;
+                    if (p) val = *reinterpret_cast<const u32x4*>(p + c);
+                    ra[i] = val;
+                }
             }
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
@@ -373,6 +412,7 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
                         : (BM == 128 && BN == 32) ? 3 : 4;
+    g.fits32 = ((int64_t)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws * g.sld) < ((1ll << 31) - (1ll << 22));
     const bool par = g.is_dgrad && g.q == 2 && vec;
     if (par) {
         const int nimg = g.M / (g.Hd * g.Wd);
