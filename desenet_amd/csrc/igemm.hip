@@ -36,6 +36,7 @@ struct Geom {
     int32_t tiles_m, tiles_n;
     int32_t is_dgrad;
     int32_t fits32;       // every source element offset fits a signed 32-bit integer
+    uint32_t src_bytes, w_bytes;   // buffer-descriptor ranges: out-of-range lanes of a buffer_load return 0 (free zero padding)
     // stride-2 dgrad by destination-pixel parity class (py, px): only the taps that can reach a class are visited
     // (1 + 2 + 2 + 4 of the 9 taps of a 3x3 instead of 9 masked ones for every pixel).  Class c = py*2 + px.
     int32_t cls_tile0[5];      // first M-tile of each class (cls_tile0[4] = tiles_m)
@@ -137,8 +138,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     }
     const int Kc = PAR ? g.cls_ntaps[cls] * g.Cs : g.Ktot;      // K extent of this tile
     const int nchunks = (Kc + KC - 1) / KC;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
 
-    u32x4 ra[AR], rb[BR];
+    // three register stages: chunks i+1, i+2, i+3 are in flight while chunk i is on the matrix cores (the loads of a
+    // chunk get two full iterations to land; one stage left every iteration waiting ~0.5 us for L2)
+    u32x4 ra0[AR], rb0[BR], ra1[AR], rb1[BR], ra2[AR], rb2[BR];
 
     // source address of destination row i for tap (ky, kx); nullptr when the tap falls outside the map
     auto src_row = [&](int i, int ky, int kx) -> const T* {
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 #pragma unroll
     for (int i = 0; i < AR; ++i) base_off[i] = (int32_t)((nbase[i] + (int64_t)py[i] * g.Ws + px[i]) * g.sld);
 
-    auto load_chunk = [&](int ch) {
+    auto load_chunk = [&](int ch, u32x4 (&ra)[AR], u32x4 (&rb)[BR]) {
         const int k0 = ch * KC + v * VEC;
         if (VECLOAD) {
             const bool kok = k0 < Kc;
@@ -187,32 +192,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
                 kc_norm();
             }
             const int kb = PAR ? tap * g.Cs + c : k0;           // position of this vector in the packed weight row
+            // buffer loads: an offset beyond the descriptor's range returns zeros, so padding / masked taps / tile
+            // overhang cost one v_cndmask on the OFFSET instead of a branch + four on the data
+            constexpr uint32_t OOB = 0xFFFFFFF0u;
             if (fast) {
                 const int dyo = ky * g.d, dxo = kx * g.d;
                 const int32_t off_tap = (dyo * g.Ws + dxo) * (int32_t)g.sld + c;
 #pragma unroll
                 for (int i = 0; i < AR; ++i) {
-                    u32x4 val = {0u, 0u, 0u, 0u};
                     const bool ok = kok && rowok[i] && (unsigned)(py[i] + dyo) < (unsigned)g.Hs &&
                                     (unsigned)(px[i] + dxo) < (unsigned)g.Ws;
-                    if (ok) val = *reinterpret_cast<const u32x4*>(src + (base_off[i] + off_tap));
-                    ra[i] = val;
+                    const uint32_t off = ok ? (uint32_t)(base_off[i] + off_tap) * (uint32_t)sizeof(T) : OOB;
+                    ra[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < AR; ++i) {
-                    u32x4 val = {0u, 0u, 0u, 0u};
                     const T* p = kok ? src_row(i, ky, kx) : nullptr;
-                    if (p) val = *reinterpret_cast<const u32x4*>(p + c);
-                    ra[i] = val;
+                    const uint32_t off = p ? (uint32_t)((p + c) - src) * (uint32_t)sizeof(T) : OOB;
+                    ra[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
                 }
             }
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
-                u32x4 val = {0u, 0u, 0u, 0u};
                 const int r = r0 + 32 * i, n = n0 + r;
-                if (kok && r < BN && n < g.Cd) val = *reinterpret_cast<const u32x4*>(wpk + (int64_t)n * g.Ktot + kb);
-                rb[i] = val;
+                const bool ok = kok && r < BN && n < g.Cd;
+                const uint32_t off = ok ? (uint32_t)(n * g.Ktot + kb) * (uint32_t)sizeof(T) : OOB;
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
             }
         } else {   // generic path: per-element tap decode (channel counts that are not a multiple of the vector width)
 #pragma unroll
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const u32x4 (&ra)[AR], const u32x4 (&rb)[BR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int r = r0 + 32 * i;
@@ -285,20 +291,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         }
     };
 
-    // ---- main loop: register-staged double buffering ------------------------------------------------------------
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
+    // ---- main loop: 3 register stages feeding 2 LDS buffers, one barrier per chunk ---------------------------------------
+#define DSN_STEP(RA_FREE, RB_FREE, RA_NEXT, RB_NEXT, IT)                                   \
+    if ((IT) < nchunks) {                                                                  \
+        if ((IT) + 3 < nchunks) load_chunk((IT) + 3, RA_FREE, RB_FREE);                    \
+        compute((IT) & 1);                                                                 \
+        if ((IT) + 1 < nchunks) store_chunk(((IT) + 1) & 1, RA_NEXT, RB_NEXT);             \
+        __syncthreads();                                                                   \
     }
+    if (nchunks > 0) load_chunk(0, ra0, rb0);
+    if (nchunks > 1) load_chunk(1, ra1, rb1);
+    if (nchunks > 2) load_chunk(2, ra2, rb2);
+    if (nchunks > 0) store_chunk(0, ra0, rb0);
     __syncthreads();
-    for (int it = 0; it < nchunks; ++it) {
-        const int buf = it & 1;
-        const bool more = it + 1 < nchunks;
-        if (more) load_chunk(it + 1);
-        compute(buf);
-        if (more) store_chunk(buf ^ 1);
-        __syncthreads();
+    for (int it = 0; it < nchunks; it += 3) {
+        DSN_STEP(ra0, rb0, ra1, rb1, it)
+        DSN_STEP(ra1, rb1, ra2, rb2, it + 1)
+        DSN_STEP(ra2, rb2, ra0, rb0, it + 2)
     }
+#undef DSN_STEP
 
     // ---- epilogue: stage act(acc + bias) as fp32 [BM][BN + CPAD] ------------------------------------------------
     constexpr int LDC = BN + CPAD;
@@ -412,7 +423,11 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
                         : (BM == 128 && BN == 32) ? 3 : 4;
-    g.fits32 = ((int64_t)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws * g.sld) < ((1ll << 31) - (1ll << 22));
+    const int64_t src_elems_ld = ((int64_t)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws - 1) * g.sld + g.Cs;
+    g.fits32 = (src_elems_ld < ((1ll << 30) - (1ll << 22))) && ((int64_t)g.Cd * g.Ktot < (1ll << 30));
+    g.src_bytes = (uint32_t)(src_elems_ld * sizeof(T));
+    g.w_bytes = (uint32_t)((int64_t)g.Cd * g.Ktot * sizeof(T));
+    vec = vec && g.fits32;     // the vector path addresses through 32-bit buffer offsets
     const bool par = g.is_dgrad && g.q == 2 && vec;
     if (par) {
         const int nimg = g.M / (g.Hd * g.Wd);

@@ -42,7 +42,10 @@ def timeit(fn, iters=30):
 def main():
     dt = torch.bfloat16
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     for name, n, ci, h, w, co, k, s in LAYERS:
+        if only and only not in name:
+            continue
         pad = k // 2
         ho, wo = ops.conv_out_hw(h, w, k, s, pad, 1)
         x = ops.new_act(n, ci, h, w, dt, "cuda"); x.normal_()
