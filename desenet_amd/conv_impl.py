@@ -109,10 +109,12 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     plain = skip_bn and act == ACT_NONE and residual is None
     y = out if plain else ops.new_act(n, co, ho, wo, dtype, x.device)
     stats = None
-    if train_bn and bias is None:
-        # BatchNorm statistics come out of the conv epilogue (fp32 accumulators): no extra pass over y
+    if train_bn and bias is None and co <= 1024:
+        # BatchNorm statistics come out of the conv epilogue (fp32 accumulators) and are folded in the prologue of the
+        # BN + act kernel: conv -> BN -> act is two launches, y is read once
         stats = ops.conv2d_fwd_bnstats(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), bn.weight, bn.bias, bn.running_mean,
-                                       bn.running_var, bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps)
+                                       bn.running_var, bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps,
+                                       act, residual, out)
     else:
         ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE))
     rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, y=y, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
@@ -121,12 +123,14 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     elif skip_bn:
         ops.bn_act_fwd(y, None, None, act, residual, out)
     elif train_bn:
-        scale, shift, mean, rstd = stats if stats is not None else ops.bn_stats(
-            y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-            bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps)
+        if stats is not None:
+            scale, shift, mean, rstd = stats        # z already written by the fused pair
+        else:
+            scale, shift, mean, rstd = ops.bn_stats(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                    bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps)
+            ops.bn_act_fwd(y, scale, shift, act, residual, out)
         if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
             bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
-        ops.bn_act_fwd(y, scale, shift, act, residual, out)
         rec.update(scale=scale, shift=shift, mean=mean, rstd=rstd, frozen=False)
     else:
         # eval-mode BN kept differentiable (running statistics are constants): z = act(y*scale + shift)

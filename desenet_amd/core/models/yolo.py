@@ -311,6 +311,7 @@ class Model(HipModule):
     # ---- per-step, whole-model preparation (training): one pack launch, one BN-counter increment --------------------------
     def _prepare_training_step(self, dtype, device):
         from ...conv_impl import _cache, _ver
+        ops.bn_arena_begin(device)        # one memset clears the BatchNorm accumulator slots of this step
         convs = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
         bank = self.__dict__.get("_dsn_bank")
         if bank is None or not bank.valid_for(dtype) or len(bank.convs) != len(convs):

@@ -6,8 +6,8 @@
 // parallelism: these tensors are 1-13 MB, the kernels live or die by latency).  Consecutive lanes read consecutive channel
 // vectors of one pixel, then the next pixel: fully coalesced whenever ldc == C, 16-byte segments otherwise (concat slices).
 //
-// Per-channel reductions fold the block's TY partials through LDS and write ONE row of per-block partials; a finalize
-// kernel (one wave per channel) reduces the rows in fp64 in a fixed order -> deterministic, no float atomics.
+// Per-channel reductions fold the block's TY partials through LDS and add them into fp64 accumulators (common.h: BnAcc);
+// the elementwise kernel that consumes the statistics folds the accumulators in its prologue (EwPro) -- no finalize launch.
 #include "common.h"
 
 namespace {
@@ -54,7 +54,7 @@ template <typename T> struct VW { static constexpr int N = 16 / sizeof(T); };
 // ---- functors ----------------------------------------------------------------------------------------------------------
 // Reductions: accumulate two per-channel quantities from (a = in0, b = in1).
 template <int V> struct StatsF {            // sum y, sum y^2
-    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void prepare(int, const float*) {}
     __device__ __forceinline__ void acc(const float (&a)[V], const float (&)[V], float (&q0)[V], float (&q1)[V]) const {
 #pragma unroll
         for (int k = 0; k < V; ++k) { q0[k] += a[k]; q1[k] += a[k] * a[k]; }
@@ -64,7 +64,7 @@ struct BnParams { const float *scale, *shift, *mean, *rstd, *means; int act, C; 
 template <int V> struct BwdRedF {           // sum g, sum g*yhat with g = dz * act'(y*scale+shift)
     BnParams p;
     float sc[V], sh[V], mu[V], rs[V];
-    __device__ __forceinline__ void prepare(int c0) {
+    __device__ __forceinline__ void prepare(int c0, const float*) {
 #pragma unroll
         for (int k = 0; k < V; ++k) { sc[k] = p.scale[c0 + k]; sh[k] = p.shift[c0 + k]; mu[k] = p.mean[c0 + k]; rs[k] = p.rstd[c0 + k]; }
     }
@@ -81,9 +81,12 @@ template <int V> struct BwdRedF {           // sum g, sum g*yhat with g = dz * a
 template <int V> struct FwdF {              // act(y*scale + shift) [+ res]
     BnParams p; bool has_res;
     float sc[V], sh[V];
-    __device__ __forceinline__ void prepare(int c0) {
+    __device__ __forceinline__ void prepare(int c0, const float* pro) {     // pro: (scale, shift) from the kernel prologue
 #pragma unroll
-        for (int k = 0; k < V; ++k) { sc[k] = p.scale ? p.scale[c0 + k] : 1.f; sh[k] = p.scale ? p.shift[c0 + k] : 0.f; }
+        for (int k = 0; k < V; ++k) {
+            sc[k] = pro ? pro[c0 + k] : (p.scale ? p.scale[c0 + k] : 1.f);
+            sh[k] = pro ? pro[p.C + c0 + k] : (p.scale ? p.shift[c0 + k] : 0.f);
+        }
     }
     __device__ __forceinline__ void apply(const float (&y)[V], const float (&r)[V], float (&o)[V]) const {
 #pragma unroll
@@ -96,12 +99,13 @@ template <int V> struct FwdF {              // act(y*scale + shift) [+ res]
 template <int V> struct BwdApplyF {         // BN: scale*(g - mean_g - yhat*mean_gyhat);  no BN: dz*act'(y)
     BnParams p;
     float sc[V], sh[V], mu[V], rs[V], m1[V], m2[V];
-    __device__ __forceinline__ void prepare(int c0) {
+    __device__ __forceinline__ void prepare(int c0, const float* pro) {     // pro: (mean g, mean g*yhat) from the prologue
         if (!p.scale) return;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             sc[k] = p.scale[c0 + k]; sh[k] = p.shift[c0 + k]; mu[k] = p.mean[c0 + k]; rs[k] = p.rstd[c0 + k];
-            m1[k] = p.means[c0 + k]; m2[k] = p.means[p.C + c0 + k];
+            m1[k] = pro ? pro[c0 + k] : p.means[c0 + k];
+            m2[k] = pro ? pro[p.C + c0 + k] : p.means[p.C + c0 + k];
         }
     }
     __device__ __forceinline__ void apply(const float (&y)[V], const float (&dz)[V], float (&o)[V]) const {
@@ -122,7 +126,7 @@ struct Strip { int64_t P; int C; int64_t per_block; };
 // ---- reduction kernel ---------------------------------------------------------------------------------------------------
 template <typename T, int V, bool HAS_B, typename F>
 __global__ __launch_bounds__(THREADS) void reduce2_kernel(const T* __restrict__ a, int64_t ald, const T* __restrict__ b,
-                                                          int64_t bld, Strip s, float* __restrict__ partial, F f) {
+                                                          int64_t bld, Strip s, const BnAcc fin, F f) {
     __shared__ float red[2 * THREADS * V];
     const int ncv = s.C / V;
     const int TX = ncv < THREADS ? ncv : THREADS;
@@ -130,14 +134,13 @@ __global__ __launch_bounds__(THREADS) void reduce2_kernel(const T* __restrict__ 
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int64_t p0 = blockIdx.x * s.per_block;
     const int64_t p1 = (p0 + s.per_block < s.P) ? p0 + s.per_block : s.P;
-    float* out = partial + (int64_t)blockIdx.x * 2 * s.C;
     for (int cv0 = 0; cv0 < ncv; cv0 += TX) {
         const int cv = cv0 + tx;
         float q0[V], q1[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) q0[k] = q1[k] = 0.f;
         if (ty < TY && cv < ncv) {
-            f.prepare(cv * V);
+            f.prepare(cv * V, nullptr);
             const T* ap = a + cv * V;
             const T* bp = HAS_B ? b + cv * V : nullptr;
             int64_t p = p0 + ty;
@@ -175,16 +178,67 @@ __global__ __launch_bounds__(THREADS) void reduce2_kernel(const T* __restrict__ 
                 s0 += red[(t * TX + ctx) * V + ck];
                 s1 += red[THREADS * V + (t * TX + ctx) * V + ck];
             }
-            out[cbase + c] = s0;
-            out[s.C + cbase + c] = s1;
+            bn_acc_add(fin, blockIdx.x, cbase + c, s0, s1);
         }
     }
 }
 
 // ---- elementwise kernel -------------------------------------------------------------------------------------------------
-template <typename T, int V, bool HAS_B, typename F>
+// Optional prologue: fold the fp64 accumulators the PREVIOUS kernel filled into the two per-channel constants this kernel
+// needs -- (scale, shift) of a training-mode BatchNorm forward, or (mean g, mean g*yhat) of its backward -- into LDS.  Every
+// block does it redundantly (2 channels per thread, 16 L2 hits each); block 0 also writes what later passes need.
+constexpr int PRO_MAXC = 1024;
+struct EwPro {
+    BnAcc a;                  // a.acc == nullptr: no prologue
+    int32_t mode;             // 0 forward statistics, 1 backward sums
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    float momentum, eps;
+    float *scale, *shift, *mean, *rstd;     // forward: saved for the backward pass
+    float *dgamma, *dbeta;                  // backward: parameter gradients
+    int32_t accumulate;
+};
+__device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
+    const int C = q.a.C;
+    const bool writer = blockIdx.x == 0;
+    for (int c = threadIdx.x; c < C; c += THREADS) {
+        double s, ss;
+        bn_acc_fold(q.a, c, s, ss);
+        if (q.mode == 0) {
+            const double mean = s / q.a.count;
+            double var = ss / q.a.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)q.eps));
+            const float g = q.gamma ? q.gamma[c] : 1.f, b = q.beta ? q.beta[c] : 0.f;
+            const float sc = g * rstd, sh = b - (float)mean * sc;
+            lds[c] = sc;
+            lds[C + c] = sh;
+            if (writer) {
+                q.scale[c] = sc; q.shift[c] = sh; q.mean[c] = (float)mean; q.rstd[c] = rstd;
+                if (q.running_mean) {
+                    const double unbiased = q.a.count > 1.0 ? var * q.a.count / (q.a.count - 1.0) : var;
+                    q.running_mean[c] = (1.f - q.momentum) * q.running_mean[c] + q.momentum * (float)mean;
+                    q.running_var[c] = (1.f - q.momentum) * q.running_var[c] + q.momentum * (float)unbiased;
+                }
+            }
+        } else {
+            lds[c] = (float)(s / q.a.count);
+            lds[C + c] = (float)(ss / q.a.count);
+            if (writer) {
+                if (q.dbeta) q.dbeta[c] = q.accumulate ? q.dbeta[c] + (float)s : (float)s;
+                if (q.dgamma) q.dgamma[c] = q.accumulate ? q.dgamma[c] + (float)ss : (float)ss;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, int V, bool HAS_B, bool PRO, typename F>
 __global__ __launch_bounds__(THREADS) void ew2_kernel(const T* __restrict__ a, int64_t ald, const T* __restrict__ b,
-                                                      int64_t bld, T* __restrict__ o, int64_t old_, Strip s, F f) {
+                                                      int64_t bld, T* __restrict__ o, int64_t old_, Strip s, const EwPro pro, F f) {
+    __shared__ float s_pro[PRO ? 2 * PRO_MAXC : 1];
+    if (PRO) ew_prologue(pro, s_pro);
+    const float* lds = PRO ? s_pro : nullptr;
     const int ncv = s.C / V;
     const int TX = ncv < THREADS ? ncv : THREADS;
     const int TY = THREADS / TX;
@@ -193,7 +247,7 @@ __global__ __launch_bounds__(THREADS) void ew2_kernel(const T* __restrict__ a, i
     const int64_t p0 = blockIdx.x * s.per_block;
     const int64_t p1 = (p0 + s.per_block < s.P) ? p0 + s.per_block : s.P;
     for (int cv = tx; cv < ncv; cv += TX) {
-        f.prepare(cv * V);
+        f.prepare(cv * V, lds);
         const T* ap = a + cv * V;
         const T* bp = HAS_B ? b + cv * V : nullptr;
         T* op = o + cv * V;
@@ -265,19 +319,36 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
-                                                              double count, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate,
-                                                              float* __restrict__ means) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
+// Standalone finalize of forward statistics from the accumulators (dsn_bn_stats: BN after a biased conv, channel sums);
+// restores the zeros, so that entry point keeps a "zero once" workspace.
+__global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const BnAcc a, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum, float eps,
+                                                              float* __restrict__ scale, float* __restrict__ shift,
+                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
     double s, ss;
-    fold_rows(partial, nblocks, C, c, lane, s, ss);
-    if (lane != 0) return;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)ss : (float)ss;
-    means[c] = (float)(s / count);
-    means[C + c] = (float)(ss / count);
+    bn_acc_fold(a, c, s, ss);
+    for (int r = 0; r < BN_NREP; ++r) {
+        a.acc[(size_t)r * 2 * a.C + c] = 0.0;
+        a.acc[(size_t)r * 2 * a.C + a.C + c] = 0.0;
+    }
+    const double mean = s / a.count;
+    double var = ss / a.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    if (running_mean) {
+        const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------------------------------
@@ -304,40 +375,54 @@ inline Strip make_strip(int64_t P, int C, int V, int max_blocks, int* nblocks) {
 }
 
 template <typename T, bool HAS_B, template <int> class F, typename... A>
-void launch_reduce(bool vec, const dsn_tensor* a, const dsn_tensor* b, float* partial, int* nblocks, hipStream_t st,
-                   A... args) {
+void launch_reduce(bool vec, const dsn_tensor* a, const dsn_tensor* b, const BnAcc& fin, hipStream_t st, A... args) {
+    int nb = 1;
+    int* nblocks = &nb;
     constexpr int VV = VW<T>::N;
     const int64_t P = npix(a);
     if (vec) {
         Strip s = make_strip(P, a->c, VV, MAX_RED_BLOCKS, nblocks);
         hipLaunchKernelGGL((reduce2_kernel<T, VV, HAS_B, F<VV>>), dim3(*nblocks), dim3(THREADS), 0, st, (const T*)a->ptr,
-                           a->ldc, b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, s, partial, F<VV>{args...});
+                           a->ldc, b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, s, fin, F<VV>{args...});
     } else {
         Strip s = make_strip(P, a->c, 1, MAX_RED_BLOCKS, nblocks);
         hipLaunchKernelGGL((reduce2_kernel<T, 1, HAS_B, F<1>>), dim3(*nblocks), dim3(THREADS), 0, st, (const T*)a->ptr,
-                           a->ldc, b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, s, partial, F<1>{args...});
+                           a->ldc, b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, s, fin, F<1>{args...});
     }
 }
 
 template <typename T, bool HAS_B, template <int> class F, typename... A>
-void launch_ew(bool vec, const dsn_tensor* a, const dsn_tensor* b, const dsn_tensor* o, hipStream_t st, A... args) {
+void launch_ew(bool vec, const dsn_tensor* a, const dsn_tensor* b, const dsn_tensor* o, const EwPro* pro, hipStream_t st,
+               A... args) {
     constexpr int VV = VW<T>::N;
     const int64_t P = npix(a);
+    const T* bp = b ? (const T*)b->ptr : nullptr;
+    const int64_t bld = b ? b->ldc : 0;
     int nb;
     if (vec) {
         Strip s = make_strip(P, a->c, VV, 16384, &nb);
-        hipLaunchKernelGGL((ew2_kernel<T, VV, HAS_B, F<VV>>), dim3(nb), dim3(THREADS), 0, st, (const T*)a->ptr, a->ldc,
-                           b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, (T*)o->ptr, o->ldc, s, F<VV>{args...});
+        if (pro)
+            hipLaunchKernelGGL((ew2_kernel<T, VV, HAS_B, true, F<VV>>), dim3(nb), dim3(THREADS), 0, st, (const T*)a->ptr, a->ldc,
+                               bp, bld, (T*)o->ptr, o->ldc, s, *pro, F<VV>{args...});
+        else
+            hipLaunchKernelGGL((ew2_kernel<T, VV, HAS_B, false, F<VV>>), dim3(nb), dim3(THREADS), 0, st, (const T*)a->ptr, a->ldc,
+                               bp, bld, (T*)o->ptr, o->ldc, s, EwPro{}, F<VV>{args...});
     } else {
         Strip s = make_strip(P, a->c, 1, 16384, &nb);
-        hipLaunchKernelGGL((ew2_kernel<T, 1, HAS_B, F<1>>), dim3(nb), dim3(THREADS), 0, st, (const T*)a->ptr, a->ldc,
-                           b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, (T*)o->ptr, o->ldc, s, F<1>{args...});
+        if (pro)
+            hipLaunchKernelGGL((ew2_kernel<T, 1, HAS_B, true, F<1>>), dim3(nb), dim3(THREADS), 0, st, (const T*)a->ptr, a->ldc,
+                               bp, bld, (T*)o->ptr, o->ldc, s, *pro, F<1>{args...});
+        else
+            hipLaunchKernelGGL((ew2_kernel<T, 1, HAS_B, false, F<1>>), dim3(nb), dim3(THREADS), 0, st, (const T*)a->ptr, a->ldc,
+                               bp, bld, (T*)o->ptr, o->ldc, s, EwPro{}, F<1>{args...});
     }
 }
 
 }  // namespace
 
-extern "C" int64_t dsn_bn_workspace_bytes(int32_t c) { return (int64_t)(MAX_RED_BLOCKS + 1) * 2 * c * sizeof(float); }
+// fp64 accumulators [BN_NREP][2][c] (common.h).  dsn_bn_stats wants them zero-filled ONCE (it restores the zeros);
+// dsn_conv2d_fwd_bnacc + dsn_bn_act_fwd_acc and dsn_bn_act_bwd want them ZERO ON ENTRY and leave them dirty.
+extern "C" int64_t dsn_bn_workspace_bytes(int32_t c) { return bn_acc_bytes(c); }
 
 extern "C" int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
@@ -346,16 +431,15 @@ extern "C" int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float
     DSN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats must come in pairs");
     if (workspace_bytes < dsn_bn_workspace_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "bn_stats: workspace too small");
     const int64_t P = npix(y);
-    float* partial = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    int nb = 1;
+    BnAcc f{(double*)workspace, y->c, (double)P};
     {
         ProfScope prof(KID_BN_STATS, 0.0, (double)P * y->c * (y->dtype == DSN_F32 ? 4.0 : 2.0), st);
-        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, false, StatsF>(vec_ok(y), y, nullptr, partial, &nb, st)));
+        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, false, StatsF>(vec_ok(y), y, nullptr, f, st)));
     }
     DSN_LAUNCH_CHECK("bn_stats reduce");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(y->c, 4)), dim3(256), 0, st, partial, nb, y->c, (double)P, gamma, beta,
-                       running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+    hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3(cdiv(y->c, 256)), dim3(256), 0, st, f, gamma, beta, running_mean,
+                       running_var, momentum, eps, scale, shift, mean, rstd);
     DSN_LAUNCH_CHECK("bn_stats finalize");
     return DSN_OK;
 }
@@ -384,11 +468,45 @@ extern "C" int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const flo
     BnParams bp{scale, shift, nullptr, nullptr, nullptr, act, y->c};
     DSN_DISPATCH_DTYPE(y->dtype, T, {
         if (residual)
-            launch_ew<T, true, FwdF>(v, y, residual, z, st, bp, true);
+            launch_ew<T, true, FwdF>(v, y, residual, z, nullptr, st, bp, true);
         else
-            launch_ew<T, false, FwdF>(v, y, nullptr, z, st, bp, false);
+            launch_ew<T, false, FwdF>(v, y, nullptr, z, nullptr, st, bp, false);
     });
     DSN_LAUNCH_CHECK("bn_act_fwd");
+    return DSN_OK;
+}
+
+// Training-mode BatchNorm + activation (+ shortcut) straight from the accumulators dsn_conv2d_fwd_bnacc filled: the kernel's
+// prologue turns the sums into scale/shift; block 0 also writes scale/shift/mean/rstd (saved for dsn_bn_act_bwd) and
+// updates the running statistics.
+extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  float* scale, float* shift, float* mean, float* rstd, int32_t act,
+                                  const dsn_tensor* residual, const dsn_tensor* z, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(y) && tensor_ok(z) && same_shape(y, z), "bn_act_fwd_acc: invalid tensors");
+    DSN_CHECK_ARG(acc && scale && shift && mean && rstd, "bn_act_fwd_acc: null argument");
+    DSN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_act_fwd_acc: running stats must come in pairs");
+    DSN_CHECK_ARG(y->c <= PRO_MAXC, "bn_act_fwd_acc: at most %d channels", PRO_MAXC);
+    if (acc_bytes < bn_acc_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "bn_act_fwd_acc: accumulator buffer too small");
+    if (residual) DSN_CHECK_ARG(tensor_ok(residual) && same_shape(y, residual), "bn_act_fwd_acc: residual mismatch");
+    const int64_t P = npix(y);
+    const bool v = vec_ok(y) && vec_ok(z) && (!residual || vec_ok(residual));
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(KID_BN_ACT_FWD, 0.0, (double)P * y->c * (y->dtype == DSN_F32 ? 4.0 : 2.0) * (residual ? 3 : 2), st);
+    BnParams bp{scale, shift, nullptr, nullptr, nullptr, act, y->c};
+    EwPro pro{};
+    pro.a = BnAcc{(double*)acc, y->c, (double)P};
+    pro.mode = 0;
+    pro.gamma = gamma; pro.beta = beta; pro.running_mean = running_mean; pro.running_var = running_var;
+    pro.momentum = momentum; pro.eps = eps;
+    pro.scale = scale; pro.shift = shift; pro.mean = mean; pro.rstd = rstd;
+    DSN_DISPATCH_DTYPE(y->dtype, T, {
+        if (residual)
+            launch_ew<T, true, FwdF>(v, y, residual, z, &pro, st, bp, true);
+        else
+            launch_ew<T, false, FwdF>(v, y, nullptr, z, &pro, st, bp, false);
+    });
+    DSN_LAUNCH_CHECK("bn_act_fwd_acc");
     return DSN_OK;
 }
 
@@ -401,24 +519,24 @@ extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const f
     DSN_CHECK_ARG(scale && shift && mean && rstd && workspace, "bn_act_bwd: null argument");
     if (workspace_bytes < dsn_bn_workspace_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "bn_act_bwd: workspace too small");
     const int64_t P = npix(y);
-    float* partial = (float*)workspace;
-    float* means = partial + (int64_t)MAX_RED_BLOCKS * 2 * y->c;
+    DSN_CHECK_ARG(y->c <= PRO_MAXC, "bn_act_bwd: at most %d channels", PRO_MAXC);
     hipStream_t st = (hipStream_t)stream;
     const bool v = vec_ok(y) && vec_ok(dz) && vec_ok(dy);
     const double esz = y->dtype == DSN_F32 ? 4.0 : 2.0;
-    BnParams bp{scale, shift, mean, rstd, means, act, y->c};
-    int nb = 1;
+    BnParams bp{scale, shift, mean, rstd, nullptr, act, y->c};
+    BnAcc f{(double*)workspace, y->c, (double)P};
     {
         ProfScope prof(KID_BN_BWD_REDUCE, 0.0, 2.0 * P * y->c * esz, st);
-        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, true, BwdRedF>(v, y, dz, partial, &nb, st, bp)));
+        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, true, BwdRedF>(v, y, dz, f, st, bp)));
     }
     DSN_LAUNCH_CHECK("bn_act_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(y->c, 4)), dim3(256), 0, st, partial, nb, y->c, (double)P, dgamma,
-                       dbeta, accumulate, means);
-    DSN_LAUNCH_CHECK("bn_act_bwd finalize");
+    EwPro pro{};
+    pro.a = f;
+    pro.mode = 1;
+    pro.dgamma = dgamma; pro.dbeta = dbeta; pro.accumulate = accumulate;
     {
         ProfScope prof(KID_BN_BWD_APPLY, 0.0, 3.0 * P * y->c * esz, st);
-        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, st, bp)));
+        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, &pro, st, bp)));
     }
     DSN_LAUNCH_CHECK("bn_act_bwd apply");
     return DSN_OK;
@@ -429,7 +547,7 @@ extern "C" int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t ac
                   "act_bwd: invalid tensors");
     const bool v = vec_ok(y) && vec_ok(dz) && vec_ok(dy);
     BnParams bp{nullptr, nullptr, nullptr, nullptr, nullptr, act, y->c};
-    DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, (hipStream_t)stream, bp)));
+    DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, nullptr, (hipStream_t)stream, bp)));
     DSN_LAUNCH_CHECK("act_bwd");
     return DSN_OK;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/desenet_hip.h"
 
@@ -70,6 +71,44 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     }
     return 1.0f;
 }
+
+
+// ---- per-channel reductions that cross blocks ---------------------------------------------------------------------------
+// BatchNorm needs per-channel sums over ALL pixels before anything downstream can run.  The producing kernel (conv epilogue
+// or a reduction sweep) adds each block's per-channel partials into fp64 accumulators with hardware atomics
+// (global_atomic_add_f64, no return value: measured free next to the kernel's own traffic), BN_NREP replicas picked by
+// block index keep same-address contention low.  The CONSUMING kernel folds the replicas in its prologue -- every block
+// redundantly, 2 channels per thread out of L2 -- so there is no finalize launch and no cross-block handshake at all.
+// (Measured alternatives on MI355X: a finalize launch costs ~6 us per layer; "last block finalizes" costs ~7 us of serial
+// device-scope round trips -- ticket, fold, store -- at the kernel's tail, and an agent-scope __threadfence() per block
+// ~19 us because it writes the XCD's L2 back.)
+// Contract: the accumulators are ZERO when the producer starts; nobody restores them (callers hand out slices of an arena
+// that is cleared once per step).  fp64 sums of fp32 partials: the addition order can only show up below 1e-13 relative.
+constexpr int BN_NREP = 8;
+struct BnAcc {
+    double* acc;          // [BN_NREP][2][C]
+    int32_t C;
+    double  count;        // pixels per channel
+};
+static inline int64_t bn_acc_bytes(int c) { return (int64_t)BN_NREP * 2 * c * sizeof(double); }
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void bn_acc_add(const BnAcc& f, int rep, int c, float s0, float s1) {
+    double* a = f.acc + (size_t)(rep & (BN_NREP - 1)) * 2 * f.C;
+    unsafeAtomicAdd(a + c, (double)s0);
+    unsafeAtomicAdd(a + f.C + c, (double)s1);
+}
+// fold the replicas of channel c (the producing kernel has completed: plain loads)
+__device__ __forceinline__ void bn_acc_fold(const BnAcc& f, int c, double& s, double& ss) {
+    s = 0.0; ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < BN_NREP; ++r) {
+        const double* a = f.acc + (size_t)r * 2 * f.C;
+        s += a[c];
+        ss += a[f.C + c];
+    }
+}
+#endif
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

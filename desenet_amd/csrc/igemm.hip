@@ -84,7 +84,7 @@ template <int BM, int BN> constexpr int smem_bytes() {
 template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD, bool PAR>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
-                                                    T* __restrict__ dst, float* __restrict__ stats, const Geom g) {
+                                                    T* __restrict__ dst, float* __restrict__ stats, const BnAcc fin, const Geom g) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int VEC = Mma<T>::VEC;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     __syncthreads();
 
     // optional BatchNorm partial statistics of this tile (rows m0 .. m0+BM) -> stats[tm][0: sum, 1: sumsq][Cd]
-    if (stats) {
+    if (stats || fin.acc) {
         float* red = sC + BM * LDC;                 // 2 * 256 floats of scratch behind the staged tile
         constexpr int TYS = 256 / BN > 0 ? 256 / BN : 1;
         const int tx = tid % BN, ty = tid / BN;
@@ -353,8 +353,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
                 t0 += red[t * BN + tid];
                 t1 += red[256 + t * BN + tid];
             }
-            stats[((int64_t)tm * 2) * g.Cd + n0 + tid] = t0;
-            stats[((int64_t)tm * 2 + 1) * g.Cd + n0 + tid] = t1;
+            if (fin.acc) {
+                bn_acc_add(fin, tm, n0 + tid, t0, t1);
+            } else {
+                stats[((int64_t)tm * 2) * g.Cd + n0 + tid] = t0;
+                stats[((int64_t)tm * 2 + 1) * g.Cd + n0 + tid] = t1;
+            }
         }
     }
 
@@ -418,8 +422,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 }
 
 template <typename T, int MI, int NI, int WGM, int WGN>
-int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, float* stats, Geom g, bool vec,
-               hipStream_t st, int* tiles_m_out) {
+int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, float* stats, const BnAcc& fin, Geom g,
+               bool vec, hipStream_t st, int* tiles_m_out) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
                         : (BM == 128 && BN == 32) ? 3 : 4;
@@ -461,18 +465,18 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
                    elems * sizeof(T), st);
     if (par)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, true>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
     else if (vec)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, false>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false, false>), grid, block, 0, st, src, w, bias, res, dst, stats, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
     DSN_LAUNCH_CHECK("igemm");
     return DSN_OK;
 }
 
 template <typename T>
 int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, float* stats,
-           Geom g, hipStream_t st, int* tiles_m_out) {
+           const BnAcc& fin, Geom g, hipStream_t st, int* tiles_m_out) {
     constexpr int VEC = Mma<T>::VEC;
     const T* src = (const T*)s->ptr;
     const T* res = r ? (const T*)r->ptr : nullptr;
@@ -483,12 +487,12 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     // grid still covers the 256 CUs.
     const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.Cd + 127) / 128);
     if (g.Cd > 64 && big >= 256)
-        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
+        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
     if (g.Cd > 32 && (int64_t)((g.M + 127) / 128) * ((g.Cd + 63) / 64) >= 192)
-        return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
-    if (g.Cd > 32) return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
-    if (g.Cd > 16) return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
-    return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, g, vec, st, tiles_m_out);
+        return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+    if (g.Cd > 32) return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+    if (g.Cd > 16) return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+    return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
 }
 
 int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const dsn_conv_params* p) {
@@ -501,7 +505,7 @@ int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const 
 }
 
 int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual, const dsn_tensor* y,
-                  const dsn_conv_params* p, float* stats, int* tiles_m_out, void* stream) {
+                  const dsn_conv_params* p, float* stats, int* tiles_m_out, void* stream, const BnAcc* finp = nullptr) {
     int rc = check_common(x, w, y, p);
     if (rc) return rc;
     const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
@@ -518,8 +522,10 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
     g.a = p->stride; g.b = -p->pad; g.d = p->dil; g.q = 1;
     g.act = p->act; g.accumulate = p->accumulate;
     g.sld = x->ldc; g.dld = y->ldc; g.rld = residual ? residual->ldc : 0;
-    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, stats, g, (hipStream_t)stream, tiles_m_out);
-    return launch<bf16_t>(x, w, bias, residual, y, stats, g, (hipStream_t)stream, tiles_m_out);
+    BnAcc fin{};
+    if (finp) fin = *finp;
+    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, stats, fin, g, (hipStream_t)stream, tiles_m_out);
+    return launch<bf16_t>(x, w, bias, residual, y, stats, fin, g, (hipStream_t)stream, tiles_m_out);
 }
 
 }  // namespace
@@ -543,6 +549,17 @@ extern "C" int dsn_conv2d_fwd_stats(const dsn_tensor* x, const void* w, const ds
     return rc;
 }
 
+// Training forward of conv + BatchNorm statistics in ONE launch: the epilogue reduces the fp32 accumulators per channel and
+// adds them into `acc` (dsn_bn_acc_bytes(Co) bytes, ZERO on entry); dsn_bn_act_fwd_acc folds them in its prologue.
+extern "C" int dsn_conv2d_fwd_bnacc(const dsn_tensor* x, const void* w, const dsn_tensor* y, const dsn_conv_params* p,
+                                    void* acc, int64_t acc_bytes, void* stream) {
+    DSN_CHECK_ARG(p && p->act == DSN_ACT_NONE && !p->accumulate, "conv2d_fwd_bnacc: needs a plain convolution");
+    DSN_CHECK_ARG(y && acc, "conv2d_fwd_bnacc: null argument");
+    if (acc_bytes < bn_acc_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "conv2d_fwd_bnacc: accumulator buffer too small");
+    BnAcc f{(double*)acc, y->c, (double)npix(y)};
+    return conv_fwd_impl(x, w, nullptr, nullptr, y, p, nullptr, nullptr, stream, &f);
+}
+
 extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
                                 void* stream) {
     int rc = check_common(dy, w, dx, p);
@@ -558,6 +575,6 @@ extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_t
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
     if (dy->dtype == DSN_F32)
-        return launch<float>(dy, w, nullptr, nullptr, dx, nullptr, g, (hipStream_t)stream, nullptr);
-    return launch<bf16_t>(dy, w, nullptr, nullptr, dx, nullptr, g, (hipStream_t)stream, nullptr);
+        return launch<float>(dy, w, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+    return launch<bf16_t>(dy, w, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
 }

@@ -27,12 +27,15 @@ constexpr int TB = 64;    // tile edge (co and ci)
 template <typename T> struct WTraits;
 template <> struct WTraits<float> {
     static constexpr int VEC = 4, ROW = TB + 16;   // padded row (floats): lanes l and l+16 land 16 banks apart
-    static constexpr int PK = 32;                  // pixels per chunk
 };
 template <> struct WTraits<bf16_t> {
     static constexpr int VEC = 8, ROW = TB;        // 128-byte rows for the transposing read
-    static constexpr int PK = 32;                  // pixels per chunk (128 measured slower: fewer, longer blocks)
 };
+
+// bf16 tiles are [pixel row][64 channels] = 128-byte rows.  A transposing read (ds_read_b64_tr_b16) touches, per 32-lane
+// half, 8 rows x 32 bytes; linear rows would put the 4 rows of equal parity on the same 8 banks (4-way conflict).  XOR-ing
+// the 32-byte column group with swz(row) spreads them over the four groups of the 256-byte bank row: conflict-free.
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int vc = (sv + 8 * i) * VEC;
+                int vc = (sv + 8 * i) * VEC;
+                if constexpr (sizeof(T) == 2) vc ^= swz(srow) << 4;
                 *reinterpret_cast<u32x4*>(&sA[buf][(srow + 32 * rg) * ROW + vc]) = ra[rg][i];
                 *reinterpret_cast<u32x4*>(&sB[buf][(srow + 32 * rg) * ROW + vc]) = rb[rg][i];
             }
@@ -141,12 +145,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block; it receives column (lane&15),
             // rows 0..3.  Block rows = pixels 8*fg + {0..3} then {4..7}; block columns = the fragment's 16 channels.
             const int q = fr >> 2, pp = fr & 3;
+            const int fz = swz(8 * fg + q);
 #pragma unroll
             for (int ks = 0; ks < PK / 32; ++ks) {
                 bf16x8 a[2], b[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const bf16_t* base = &sA[buf][(32 * ks + 8 * fg + q) * ROW + (wm * 2 + i) * 16 + 4 * pp];
+                    const bf16_t* base = &sA[buf][(32 * ks + 8 * fg + q) * ROW + (((wm * 2 + i) ^ fz) << 4) + 4 * pp];
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const bf16_t* base = &sB[buf][(32 * ks + 8 * fg + q) * ROW + (wn * 2 + j) * 16 + 4 * pp];
+                    const bf16_t* base = &sB[buf][(32 * ks + 8 * fg + q) * ROW + (((wn * 2 + j) ^ fz) << 4) + 4 * pp];
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
@@ -203,47 +208,221 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             }
 }
 
-// dw (+)= sum_s slab[s]: a 256-thread block owns 64 consecutive packed elements; its 4 waves each add every 4th slab
-// (coalesced 256-byte reads), then the 4 partial sums are combined in a fixed order -> deterministic.
+
+// ---- all-taps variant (bf16, 3x3): one block owns a 64(co) x 64(ci) tile of ALL nine taps over its pixel range ------------
+// The per-tap kernel above re-reads dy once per tap (9x: 472 MB instead of 52 MB for the Focus conv -- it ran at the HBM
+// rate of the re-reads).  Here dy is staged once per chunk and shared by the nine taps, the nine shifted x gathers hit the
+// same cache lines, 10 16-byte loads are in flight per thread, and every barrier is followed by 36 MFMAs per wave.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                 float* __restrict__ out, const WGeom g, uint32_t x_bytes,
+                                                                 uint32_t dy_bytes) {
+    constexpr int PKA = 32, ROW = TB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);                    // [2][PKA*ROW]
+    bf16_t* sB = sA + 2 * PKA * ROW;                                     // [2][NT][PKA*ROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    int bid = blockIdx.x;
+    const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
+    const int tco = bid % g.tiles_co;
+    const int split = bid / g.tiles_co;
+    const int co0 = tco * TB, ci0 = tci * TB;
+    const int p_begin = split * g.ppb;
+    const int p_end = (p_begin + g.ppb < g.P) ? p_begin + g.ppb : g.P;
+    const int nchunks = (p_end - p_begin + PKA - 1) / PKA;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+
+    const int srow = tid >> 3, sv = tid & 7;     // staged pixel row, 16-byte vector (8 channels) of the row
+    const int vc = sv * 8;
+    u32x4 ra, rb[NT];
+
+    auto load_chunk = [&](int ch) {
+        const int p = p_begin + ch * PKA + srow;
+        const bool pok = p < p_end;
+        int ox = 0, oy = 0, n = 0;
+        if (pok) {
+            ox = p % g.Wo;
+            const int t = p / g.Wo;
+            oy = t % g.Ho;
+            n = t / g.Ho;
+        }
+        const uint32_t aoff = (pok && co0 + vc < g.Co) ? (uint32_t)(p * (int)g.yld + co0 + vc) * 2u : OOB;
+        ra = __builtin_amdgcn_raw_buffer_load_b128(yr, aoff, 0, 0);
+        const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
+        const int nb = n * g.Hi;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;        // NT == KH*KW with KW == 3 (checked on the host)
+            const int iy = iy0 + ky * g.dil, ix = ix0 + kx * g.dil;
+            const bool ok = pok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi && ci0 + vc < g.CiLoad;
+            const uint32_t boff = ok ? (uint32_t)(((nb + iy) * g.Wi + ix) * (int)g.xld + ci0 + vc) * 2u : OOB;
+            rb[t] = __builtin_amdgcn_raw_buffer_load_b128(xr, boff, 0, 0);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        const int vs = vc ^ (swz(srow) << 4);
+        *reinterpret_cast<u32x4*>(&sA[(buf * PKA + srow) * ROW + vs]) = ra;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4*>(&sB[((buf * NT + t) * PKA + srow) * ROW + vs]) = rb[t];
+    };
+
+    f32x4 acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto tr_frag = [&](const bf16_t* base) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto compute = [&](int buf) {
+        const int q = fr >> 2, pp = fr & 3;
+        const int fz = swz(8 * fg + q);
+        bf16x8 a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = tr_frag(&sA[(buf * PKA + 8 * fg + q) * ROW + (((wm * 2 + i) ^ fz) << 4) + 4 * pp]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bf16x8 b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j] = tr_frag(&sB[((buf * NT + t) * PKA + 8 * fg + q) * ROW + (((wn * 2 + j) ^ fz) << 4) + 4 * pp]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nchunks;
+        if (more) load_chunk(it + 1);
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* o = out + (g.S > 1 ? (int64_t)split * g.Co * NT * g.Cip : 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + (wm * 2 + i) * 16 + fg * 4 + e;
+                    const int ci = ci0 + (wn * 2 + j) * 16 + fr;
+                    if (co < g.Co && ci < g.Ci) {
+                        float* d = (g.S == 1 && g.oihw) ? o + ((int64_t)co * g.Ci + ci) * NT + t
+                                                        : o + ((int64_t)co * NT + t) * g.Cip + ci;
+                        float v = acc[t][i][j][e];
+                        if (g.S == 1 && g.accumulate) v += *d;
+                        *d = v;
+                    }
+                }
+}
+
+// dw (+)= sum_s slab[s].  A 256-thread block owns 64 consecutive packed elements: 16 lanes x float4 cover them, and the 16
+// lane-groups each add every 16th slab with four 16-byte loads in flight (the old one-float-per-lane loop was pure load
+// latency: 64 dependent 256-byte reads per wave).  The 16 partial sums are combined in a fixed order -> deterministic.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                            int64_t n, int S, int accumulate, int oihw, int Ci, int Cip,
                                                            int taps) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    __shared__ float part[16][65];
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
-        const int64_t j = base + lane;
-        float s = 0.f;
-        if (j < n)
-            for (int k = grp; k < S; k += 4) s += slabs[(int64_t)k * n + j];
-        part[grp][lane] = s;
-        __syncthreads();
-        if (grp == 0 && j < n) {
-            float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-            int64_t dst = j;
-            bool ok = true;
-            if (oihw) {
-                const int ci = (int)(j % Cip);
-                const int64_t t = j / Cip;
-                const int tap = (int)(t % taps);
-                const int64_t co = t / taps;
-                ok = ci < Ci;
-                dst = (co * Ci + ci) * taps + tap;
+        const int64_t j = base + q * 4;
+        f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        if (VEC4) {
+            if (j < n) {
+                const float* src = slabs + j;
+                int k = grp;
+                for (; k + 48 < S; k += 64) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 16) * n);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 32) * n);
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 48) * n);
+                    s0 += a; s1 += b; s2 += c; s3 += d;
+                }
+                for (; k < S; k += 16) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
             }
-            if (ok) {
-                if (accumulate) v += dw[dst];
-                dw[dst] = v;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (j + e < n)
+                    for (int k = grp; k < S; k += 16) s0[e] += slabs[(int64_t)k * n + j + e];
+        }
+        const f32x4 sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[grp][q * 4 + e] = sum[e];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int t = threadIdx.x;
+            float v = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 16; ++g2) v += part[g2][t];
+            const int64_t jj = base + t;
+            if (jj < n) {
+                int64_t dst = jj;
+                bool ok = true;
+                if (oihw) {
+                    const int ci = (int)(jj % Cip);
+                    const int64_t tt = jj / Cip;
+                    const int tap = (int)(tt % taps);
+                    const int64_t co = tt / taps;
+                    ok = ci < Ci;
+                    dst = (co * Ci + ci) * taps + tap;
+                }
+                if (ok) {
+                    if (accumulate) v += dw[dst];
+                    dw[dst] = v;
+                }
             }
         }
         __syncthreads();
     }
 }
 
-inline int choose_split(const WGeom& g) {
-    const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * g.KH * g.KW;
-    int64_t s = (1024 + base - 1) / base;
-    const int64_t smax = (g.P + 255) / 256;
+inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p) {
+    if (x->dtype != DSN_BF16 || p->kh != 3 || p->kw != 3) return false;
+    static const int mode = [] { const char* e = getenv("DSN_WGRAD_ALLTAPS"); return e ? atoi(e) : -1; }();   // tuning knob
+    if (mode == 0) return false;
+    // measured (tools/sweep_wgrad.sh): sharing dy across the taps wins on the large maps (P >= 32k pixels: Focus, the stride-2
+    // stem, 160x160 bottlenecks, FFM); on the small maps the per-tap blocks' 9x higher block count matters more
+    if (mode < 0 && npix(dy) < 32768) return false;
+    const bool vl = (dy->c % 8 == 0) && (x->c % 8 == 0) && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) &&
+                    ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
+    const bool fits = (npix(x) * x->ldc < (1ll << 30)) && (npix(dy) * dy->ldc < (1ll << 30));
+    return vl && fits;
+}
+
+inline int choose_split(const WGeom& g, bool alltaps = false) {
+    const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
+    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    static const int scap = [] { const char* e = getenv("DSN_WGRAD_SCAP"); return e ? atoi(e) : 256; }();
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 256; }();
+    const int tgt = alltaps ? target / 2 : target, cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
+    int64_t s = (tgt + base - 1) / base;
+    const int64_t smax = (g.P + minpx - 1) / minpx;
     if (s > smax) s = smax;
-    if (s > 256) s = 256;
+    if (s > cap) s = cap;
     return (int)(s < 1 ? 1 : s);
 }
 
@@ -257,7 +436,7 @@ extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const d
     g.tiles_co = (dy->c + TB - 1) / TB;
     g.tiles_ci = (x->c + TB - 1) / TB;
     g.KH = p->kh; g.KW = p->kw;
-    const int S = choose_split(g);
+    const int S = choose_split(g, use_alltaps(x, dy, p));
     const int64_t row = ci_pad > x->c ? ci_pad : x->c;
     return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * row * sizeof(float) : 0;
 }
@@ -277,7 +456,8 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     g.KH = p->kh; g.KW = p->kw; g.stride = p->stride; g.pad = p->pad; g.dil = p->dil;
     g.yld = dy->ldc; g.xld = x->ldc;
     g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
-    g.S = choose_split(g);
+    const bool alltaps = use_alltaps(x, dy, p);
+    g.S = choose_split(g, alltaps);
     static int pk_bf16 = [] { const char* e = getenv("DSN_WGRAD_PK"); int v = e ? atoi(e) : 32; return (v == 64 || v == 128) ? v : 32; }();
     const int PK = x->dtype == DSN_F32 ? 32 : pk_bf16;
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
@@ -303,11 +483,23 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
     const bool vl = (g.Co % vec == 0) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
                     ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
-    dim3 grid(g.tiles_ci * g.tiles_co * g.KH * g.KW * g.S), block(256);
+    dim3 grid(g.tiles_ci * g.tiles_co * (alltaps ? 1 : g.KH * g.KW) * g.S), block(256);
     {
     ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), 2.0 * g.P * g.Co * g.Ci * g.KH * g.KW,
                    ((double)npix(x) * g.Ci + (double)g.P * g.Co) * es + (double)n_out * 4, st);
-    if (x->dtype == DSN_F32) {
+    if (alltaps) {
+        constexpr int NT = 9;
+        const size_t lds = (size_t)2 * 32 * TB * 2 * (1 + NT);          // A + 9 shifted B tiles, double buffered: 80 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)wgrad_alltaps_bf16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr_set = true;
+        }
+        const uint32_t xb = (uint32_t)(((npix(x) - 1) * x->ldc + x->c) * 2), yb = (uint32_t)(((npix(dy) - 1) * dy->ldc + dy->c) * 2);
+        hipLaunchKernelGGL(wgrad_alltaps_bf16_kernel<NT>, grid, block, lds, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out,
+                           g, xb, yb);
+    } else if (x->dtype == DSN_F32) {
         if (vl)
             hipLaunchKernelGGL((wgrad_kernel<float, true, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
         else
@@ -324,8 +516,13 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     if (g.S > 1) {
         ProfScope prof(KID_WGRAD_REDUCE, 0.0, (double)(g.S + 1) * n_out * 4, st);
         int64_t b = (n_out + 63) / 64;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(b > 4096 ? 4096 : b)), dim3(256), 0, st, out, dw, n_out, g.S,
-                           p->accumulate, g.oihw, g.Ci, g.Cip, g.KH * g.KW);
+        const dim3 rgrid((int)(b > 8192 ? 8192 : b));
+        if (n_out % 4 == 0 && (uintptr_t)out % 16 == 0)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, st, out, dw, n_out, g.S, p->accumulate, g.oihw,
+                               g.Ci, g.Cip, g.KH * g.KW);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, st, out, dw, n_out, g.S, p->accumulate, g.oihw,
+                               g.Ci, g.Cip, g.KH * g.KW);
         DSN_LAUNCH_CHECK("conv wgrad reduce");
     } else if (g.Cip != g.Ci && !p->accumulate) {
         // direct write leaves the padding lanes of dw untouched: they are defined to be zero

@@ -108,21 +108,23 @@ def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params):
     return y
 
 
-def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_mean, running_var, momentum, eps):
-    """Training forward of a conv followed by BatchNorm: conv with statistics in its epilogue + finalize (2 launches, no
-    separate pass over y).  Returns (scale, shift, mean, rstd) fp32 [C]."""
+def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_mean, running_var, momentum, eps, act,
+                       residual, z):
+    """Training forward of conv -> BatchNorm -> act (+ shortcut) in TWO launches: the conv epilogue adds the per-channel
+    sums into fp64 accumulators, the elementwise kernel folds them in its prologue (no statistics pass, no finalize
+    launch).  Writes z; returns (scale, shift, mean, rstd) fp32 [C] for the backward pass."""
     L = _lib.lib()
-    dx, dy = desc(x), desc(y)
-    n, c, h, w = y.shape
-    rows = L.dsn_conv2d_stats_rows(n * h * w)
-    ws = scratch(rows * 2 * c * 4, x.device)
-    got = C.c_int32(0)
-    _lib.check(L.dsn_conv2d_fwd_stats(C.byref(dx), w_packed.data_ptr(), C.byref(dy), C.byref(p), ws.data_ptr(),
-                                      C.addressof(got), stream_ptr()), "conv2d_fwd_stats")
+    dx, dy, dz = desc(x), desc(y), desc(z)
+    dr = desc(residual) if residual is not None else None
+    c = y.shape[1]
+    acc, nbytes = bn_acc(c, y.device)
+    _lib.check(L.dsn_conv2d_fwd_bnacc(C.byref(dx), w_packed.data_ptr(), C.byref(dy), C.byref(p), acc.data_ptr(), nbytes,
+                                      stream_ptr()), "conv2d_fwd_bnacc")
     out = torch.empty((4, c), dtype=torch.float32, device=y.device)
-    _lib.check(L.dsn_bn_finalize(ws.data_ptr(), got.value, c, n * h * w, _p(gamma), _p(beta), _p(running_mean),
-                                 _p(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
-                                 out[2].data_ptr(), out[3].data_ptr(), stream_ptr()), "bn_finalize")
+    _lib.check(L.dsn_bn_act_fwd_acc(C.byref(dy), acc.data_ptr(), nbytes, _p(gamma), _p(beta), _p(running_mean),
+                                    _p(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
+                                    out[2].data_ptr(), out[3].data_ptr(), act, _ref(dr), C.byref(dz), stream_ptr()),
+               "bn_act_fwd_acc")
     return out[0], out[1], out[2], out[3]
 
 
@@ -240,11 +242,59 @@ _ws_cache = {}
 
 
 def _bn_ws(c, device):
+    """dsn_bn_stats workspace: zero-filled ONCE (the finalize kernel restores the zeros)."""
     key = (c, device)
     if key not in _ws_cache:
         nbytes = _lib.lib().dsn_bn_workspace_bytes(c)
-        _ws_cache[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes)
+        _ws_cache[key] = (torch.zeros(nbytes, dtype=torch.uint8, device=device), nbytes)
     return _ws_cache[key]
+
+
+class _BnArena:
+    """Zeroed fp64 accumulator slots for the fused BatchNorm kernels (zero on entry, left dirty).  One buffer per device,
+    cleared by ONE memset at the start of a training step (`bn_arena_begin`, part of the captured graph) and handed out
+    slot by slot -- the same sequence of addresses every step, as hipGraph replay needs."""
+    BYTES = 32 << 20
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.BYTES, dtype=torch.uint8, device=device)
+        self.cursor = self.BYTES       # exhausted until the first begin()
+
+    def begin(self):
+        self.buf.zero_()
+        self.cursor = 0
+
+    def take(self, nbytes):
+        n = (nbytes + 255) // 256 * 256
+        if self.cursor + n > self.BYTES:
+            return None
+        t = self.buf[self.cursor:self.cursor + n]
+        self.cursor += n
+        return t
+
+
+_arenas = {}
+
+
+def bn_arena_begin(device):
+    """Call once at the start of a step (Model does): clears the accumulator arena with one memset."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    a = _arenas.get(device)
+    if a is None:
+        a = _arenas[device] = _BnArena(device)
+    a.begin()
+
+
+def bn_acc(c, device):
+    """A ZEROED accumulator slot for c channels: from the step arena when one is active, else a fresh zero-filled tensor."""
+    nbytes = _lib.lib().dsn_bn_workspace_bytes(c)
+    a = _arenas.get(device)
+    t = a.take(nbytes) if a is not None else None
+    if t is None:
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return t, nbytes
 
 
 def bn_stats(y, gamma, beta, running_mean, running_var, momentum, eps):
@@ -269,7 +319,7 @@ def bn_act_fwd(y, scale, shift, act, residual, z):
 
 def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False):
     a, b, c = desc(dz), desc(y), desc(dy)
-    ws, nbytes = _bn_ws(y.shape[1], y.device)
+    ws, nbytes = bn_acc(y.shape[1], y.device)
     _lib.check(_lib.lib().dsn_bn_act_bwd(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),
                                          ws.data_ptr(), nbytes, stream_ptr()), "bn_act_bwd")

@@ -78,6 +78,11 @@ int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w_packed, const dsn_tenso
 int32_t dsn_conv2d_stats_rows(int64_t out_pixels);
 int dsn_conv2d_fwd_stats(const dsn_tensor* x, const void* w_packed, const dsn_tensor* y, const dsn_conv_params* p,
                          float* stats, int32_t* rows_out, void* stream);
+/* Training forward of Conv2d followed by BatchNorm2d (Conv.forward, common.py:49-53, train mode), statistics fused: same
+ * epilogue reduction, but added with fp64 atomics into `acc` (dsn_bn_workspace_bytes(Co) bytes, ZERO ON ENTRY) -- no
+ * partial rows and no finalize launch: dsn_bn_act_fwd_acc folds the accumulators in its prologue. */
+int dsn_conv2d_fwd_bnacc(const dsn_tensor* x, const void* w_packed, const dsn_tensor* y, const dsn_conv_params* p,
+                         void* acc, int64_t acc_bytes, void* stream);
 int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p,
                                          int32_t ci_pad);
 /* oihw = 0: dw is packed [Co][KH][KW][ci_pad] (ci_pad >= x->c).
@@ -113,9 +118,13 @@ int dsn_unpack_wgrad(const float* dw_packed, float* grad_oihw, int32_t co, int32
  * initialize_weights (torch_utils.py:164-165).
  * dsn_bn_stats: per-channel batch mean / biased variance of y; writes scale = g*rstd, shift = b - mean*scale,
  *   mean, rstd; updates running_mean/var in place ((1-m)*old + m*(mean, unbiased var)).
- *   workspace: dsn_bn_workspace_bytes(c) bytes.
+ *   workspace: dsn_bn_workspace_bytes(c) bytes of fp64 accumulators, zero-filled ONCE by the caller (dsn_bn_stats
+ *   restores the zeros; one stream at a time).
+ * dsn_bn_act_fwd_acc: training BN + act (+ shortcut) straight from the accumulators dsn_conv2d_fwd_bnacc filled; writes
+ *   scale/shift/mean/rstd (saved for the backward pass) and updates the running statistics.  Leaves acc dirty.
  * dsn_bn_act_fwd:  z = act(y*scale + shift) + residual      (also the eval path of un-fused BN: RFB2 quirk Q3)
- * dsn_bn_act_bwd:  given dz, y: dy = BN/act backward, dgamma/dbeta (+)=, optional dres (+)= dz (shortcut)
+ * dsn_bn_act_bwd:  given dz, y: dy = BN/act backward, dgamma/dbeta (+)=.  workspace: dsn_bn_workspace_bytes(c) bytes,
+ *   ZERO ON ENTRY, left dirty (callers hand out slices of an arena cleared once per step).
  */
 int64_t dsn_bn_workspace_bytes(int32_t c);
 int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float* beta, float* running_mean,
@@ -126,6 +135,10 @@ int dsn_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count
                     float* mean, float* rstd, void* stream);
 int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const float* shift, int32_t act,
                    const dsn_tensor* residual, const dsn_tensor* z, void* stream);
+int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                       float* mean, float* rstd, int32_t act, const dsn_tensor* residual, const dsn_tensor* z,
+                       void* stream);
 int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                    const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                    float* dbeta, int32_t accumulate_param_grads, void* workspace, int64_t workspace_bytes,

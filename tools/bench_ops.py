@@ -65,6 +65,17 @@ def main():
             res["dgrad"] = timeit(lambda: ops.conv2d_dgrad(dy, wd, dx, p))
         if which in ("all", "wgrad"):
             res["wgrad"] = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ci, p, oihw=True))
+        if which == "wgrad":   # per-kernel split (gather kernel vs slab reduce) from the library's event profiler
+            ops.profile_enable(True)
+            for _ in range(5):
+                ops.conv2d_wgrad(x, dy, g, ci, p, oihw=True)
+            torch.cuda.synchronize()
+            prof = ops.profile_collect()
+            ops.profile_enable(False)
+            res.update({k_: v["ms"] / v["launches"] * 1e3 for k_, v in prof.items()})
+        if which == "wgrad":
+            print(f"{name:26s} " + "  ".join(f"{k_} {v:6.1f}us" for k_, v in res.items()), flush=True)
+            continue
         print(f"{name:26s} GF {flops/1e9:6.2f} MB {byts/1e6:6.1f} | " +
               " | ".join(f"{k_} {v:7.1f} us {flops/v/1e6:6.1f} TF/s {byts/v/1e3:6.0f} GB/s" for k_, v in res.items()), flush=True)
 
