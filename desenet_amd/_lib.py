@@ -38,6 +38,10 @@ PROTOTYPES = {
     "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
     "dsn_conv2d_stats_rows": (i32, [i64]),
     "dsn_conv2d_fwd_stats": (i32, [TP, vp, TP, CP, vp, vp, vp]),
+    "dsn_wgrad_job_bytes": (i64, []),
+    "dsn_conv2d_wgrad_plan": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
+    "dsn_conv2d_wgrad_plan_finish": (i32, [vp, i32, vp]),
+    "dsn_conv2d_wgrad_run": (i32, [vp, i32, vp, vp]),
     "dsn_conv2d_fwd_bnacc": (i32, [TP, vp, TP, CP, vp, i64, vp]),
     "dsn_bn_act_fwd_acc": (i32, [TP, vp, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, TP, TP, vp]),
     "dsn_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]),

@@ -200,7 +200,8 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
             co, ci, kh, kw = conv.weight.shape
             slot = _grad_slot(conv.weight)
             g = slot if slot is not None else torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device)
-            ops.conv2d_wgrad(x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None), oihw=True)
+            ops.conv2d_wgrad(x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None), oihw=True,
+                             queue=tape.wgrad_queue(x.device) if (side is None and conv.weight not in tape.grads) else None)
             if slot is None:
                 tape.add_grad(conv.weight, g)
         if conv.bias is not None and conv.bias.requires_grad:

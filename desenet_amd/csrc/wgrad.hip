@@ -41,8 +41,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <typename T, bool VECLOAD, int PK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                    float* __restrict__ out, const WGeom g) {
+__device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ out,
+                                           const WGeom& g, int bid) {
     constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW;
     constexpr int VPR = TB / VEC;          // vectors per tile row
     constexpr int NV = VPR / 8;            // vectors per thread per row (8 threads per row)
@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
     const int taps = g.KH * g.KW;
-    int bid = blockIdx.x;
     const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
     const int tco = bid % g.tiles_co; bid /= g.tiles_co;
     const int tap = bid % taps;
@@ -214,9 +213,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
 // rate of the re-reads).  Here dy is staged once per chunk and shared by the nine taps, the nine shifted x gathers hit the
 // same cache lines, 10 16-byte loads are in flight per thread, and every barrier is followed by 36 MFMAs per wave.
 template <int NT>
-__global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                 float* __restrict__ out, const WGeom g, uint32_t x_bytes,
-                                                                 uint32_t dy_bytes) {
+__device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                   float* __restrict__ out, const WGeom& g, uint32_t x_bytes,
+                                                   uint32_t dy_bytes, int bid) {
     constexpr int PKA = 32, ROW = TB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);                    // [2][PKA*ROW]
@@ -225,7 +224,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
-    int bid = blockIdx.x;
     const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
     const int tco = bid % g.tiles_co;
     const int split = bid / g.tiles_co;
@@ -343,61 +341,132 @@ __global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t
 // lane-groups each add every 16th slab with four 16-byte loads in flight (the old one-float-per-lane loop was pure load
 // latency: 64 dependent 256-byte reads per wave).  The 16 partial sums are combined in a fixed order -> deterministic.
 template <bool VEC4>
+__device__ __forceinline__ void wgrad_reduce_group(const float* __restrict__ slabs, float* __restrict__ dw, int64_t n, int S,
+                                                   int accumulate, int oihw, int Ci, int Cip, int taps, int64_t base,
+                                                   float (*part)[65]) {
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t j = base + q * 4;
+    f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (VEC4) {
+        if (j < n) {
+            const float* src = slabs + j;
+            int k = grp;
+            for (; k + 48 < S; k += 64) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 16) * n);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 32) * n);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 48) * n);
+                s0 += a; s1 += b; s2 += c; s3 += d;
+            }
+            for (; k < S; k += 16) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
+        }
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (j + e < n)
+                for (int k = grp; k < S; k += 16) s0[e] += slabs[(int64_t)k * n + j + e];
+    }
+    const f32x4 sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[grp][q * 4 + e] = sum[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        float v = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) v += part[g2][t];
+        const int64_t jj = base + t;
+        if (jj < n) {
+            int64_t dst = jj;
+            bool ok = true;
+            if (oihw) {
+                const int ci = (int)(jj % Cip);
+                const int64_t tt = jj / Cip;
+                const int tap = (int)(tt % taps);
+                const int64_t co = tt / taps;
+                ok = ci < Ci;
+                dst = (co * Ci + ci) * taps + tap;
+            }
+            if (ok) {
+                if (accumulate) v += dw[dst];
+                dw[dst] = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <bool VEC4>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                            int64_t n, int S, int accumulate, int oihw, int Ci, int Cip,
                                                            int taps) {
     __shared__ float part[16][65];
-    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
-        const int64_t j = base + q * 4;
-        f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-        if (VEC4) {
-            if (j < n) {
-                const float* src = slabs + j;
-                int k = grp;
-                for (; k + 48 < S; k += 64) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 16) * n);
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 32) * n);
-                    const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 48) * n);
-                    s0 += a; s1 += b; s2 += c; s3 += d;
-                }
-                for (; k < S; k += 16) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
-            }
-        } else {
-            for (int e = 0; e < 4; ++e)
-                if (j + e < n)
-                    for (int k = grp; k < S; k += 16) s0[e] += slabs[(int64_t)k * n + j + e];
-        }
-        const f32x4 sum = (s0 + s1) + (s2 + s3);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[grp][q * 4 + e] = sum[e];
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int t = threadIdx.x;
-            float v = 0.f;
-#pragma unroll
-            for (int g2 = 0; g2 < 16; ++g2) v += part[g2][t];
-            const int64_t jj = base + t;
-            if (jj < n) {
-                int64_t dst = jj;
-                bool ok = true;
-                if (oihw) {
-                    const int ci = (int)(jj % Cip);
-                    const int64_t tt = jj / Cip;
-                    const int tap = (int)(tt % taps);
-                    const int64_t co = tt / taps;
-                    ok = ci < Ci;
-                    dst = (co * Ci + ci) * taps + tap;
-                }
-                if (ok) {
-                    if (accumulate) v += dw[dst];
-                    dw[dst] = v;
-                }
-            }
-        }
-        __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64)
+        wgrad_reduce_group<VEC4>(slabs, dw, n, S, accumulate, oihw, Ci, Cip, taps, base, part);
+}
+
+// ---- single-layer kernels ---------------------------------------------------------------------------------------------------
+template <typename T, bool VECLOAD, int PK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                    float* __restrict__ out, const WGeom g) {
+    wgrad_body<T, VECLOAD, PK>(x, dy, out, g, blockIdx.x);
+}
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                 float* __restrict__ out, const WGeom g, uint32_t x_bytes,
+                                                                 uint32_t dy_bytes) {
+    wgrad_alltaps_body<NT>(x, dy, out, g, x_bytes, dy_bytes, blockIdx.x);
+}
+
+// ---- grouped kernels: the weight gradients of ALL layers of a backward pass in three launches ---------------------------------
+// dW feeds nothing but the optimizer, so nothing in the backward pass waits for it.  Layer by layer each wgrad is a 10-30 us
+// launch that cannot fill 256 CUs (a 64x64 tile per tap, split-K capped by the pixel count) followed by a 6-10 us slab
+// reduction: ~150 launches and ~2.2 ms per step at batch 8.  Queued instead (dsn_conv2d_wgrad_plan) and run together
+// (dsn_conv2d_wgrad_run), the blocks of every layer share one grid: a block finds its job by binary search over the
+// per-job first-block index (uniform per block: scalar loads) and then runs the same body as the single-layer kernel.
+struct WJob {
+    const void* x;
+    const void* dy;
+    float* out;            // slabs (S > 1) or dw
+    float* dw;
+    WGeom g;
+    uint32_t x_bytes, dy_bytes;
+    int32_t kind;          // 0: per-tap blocks, 1: all-taps blocks
+    int32_t dtype;
+    int32_t blocks[3];     // blocks of this job in the per-tap / all-taps / reduce launch
+    int32_t start[3];      // first block of this job in each launch
+    int64_t n_out;
+    double flops, bytes;
+};
+__device__ __forceinline__ int find_job(const WJob* __restrict__ jobs, int n, int bid, int k) {
+    int lo = 0, hi = n - 1;            // largest job index whose first block is <= bid
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start[k] <= bid) lo = mid; else hi = mid - 1;
     }
+    return lo;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WJob* __restrict__ jobs, int n) {
+    const int l = find_job(jobs, n, blockIdx.x, 0);
+    const WGeom g = jobs[l].g;
+    wgrad_body<T, true, 32>((const T*)jobs[l].x, (const T*)jobs[l].dy, jobs[l].out, g, blockIdx.x - jobs[l].start[0]);
+}
+__global__ __launch_bounds__(256, 2) void wgrad_alltaps_grouped_kernel(const WJob* __restrict__ jobs, int n) {
+    const int l = find_job(jobs, n, blockIdx.x, 1);
+    const WGeom g = jobs[l].g;
+    wgrad_alltaps_body<9>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, jobs[l].x_bytes,
+                          jobs[l].dy_bytes, blockIdx.x - jobs[l].start[1]);
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
+    __shared__ float part[16][65];
+    const int l = find_job(jobs, n, blockIdx.x, 2);
+    const WJob& j = jobs[l];
+    const int64_t base = (int64_t)(blockIdx.x - j.start[2]) * 64;
+    const int taps = j.g.KH * j.g.KW;
+    if (j.n_out % 4 == 0)    // slabs come 256-byte aligned out of the queue's arena
+        wgrad_reduce_group<true>(j.out, j.dw, j.n_out, j.g.S, j.g.accumulate, j.g.oihw, j.g.Ci, j.g.Cip, taps, base, part);
+    else
+        wgrad_reduce_group<false>(j.out, j.dw, j.n_out, j.g.S, j.g.accumulate, j.g.oihw, j.g.Ci, j.g.Cip, taps, base, part);
 }
 
 inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p) {
@@ -441,8 +510,11 @@ extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const d
     return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * row * sizeof(float) : 0;
 }
 
-extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
-                                const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream) {
+namespace {
+
+// Validate one layer's weight-gradient problem and describe it (geometry, split, block counts, slab placement).
+int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw, const dsn_conv_params* p,
+             void* workspace, int64_t workspace_bytes, WJob* job, bool* vec_out) {
     DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(dy) && dw && p, "conv wgrad: null/invalid argument");
     DSN_CHECK_ARG(x->dtype == dy->dtype && x->n == dy->n && ci_pad > 0 && (oihw ? ci_pad <= x->c : ci_pad >= x->c),
                   "conv wgrad: dtype/batch/channel mismatch");
@@ -458,8 +530,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
     const bool alltaps = use_alltaps(x, dy, p);
     g.S = choose_split(g, alltaps);
-    static int pk_bf16 = [] { const char* e = getenv("DSN_WGRAD_PK"); int v = e ? atoi(e) : 32; return (v == 64 || v == 128) ? v : 32; }();
-    const int PK = x->dtype == DSN_F32 ? 32 : pk_bf16;
+    const int PK = 32;
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
     g.accumulate = p->accumulate;
@@ -468,65 +539,165 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     if (oihw) g.Ci = (x->c < ci_pad) ? x->c : ci_pad, g.Cip = x->c;   // OIHW: ci_pad = REAL Ci, x may carry zero-padded channels
     const int64_t n_out = (int64_t)g.Co * g.KH * g.KW * g.Cip;
     float* out = dw;
-    hipStream_t st = (hipStream_t)stream;
     if (g.S > 1) {
         if (!workspace || workspace_bytes < (int64_t)g.S * n_out * (int64_t)sizeof(float))
             DSN_FAIL(DSN_EWORKSPACE, "conv wgrad: workspace too small (%lld bytes needed)",
                      (long long)((int64_t)g.S * n_out * sizeof(float)));
         out = (float*)workspace;
     }
+    const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
+    *vec_out = (g.Co % vec == 0) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
+               ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
+    *job = WJob{};
+    job->x = x->ptr; job->dy = dy->ptr; job->out = out; job->dw = dw; job->g = g;
+    job->x_bytes = (uint32_t)(((npix(x) - 1) * x->ldc + x->c) * es);      // only read by the all-taps kernel (use_alltaps
+    job->dy_bytes = (uint32_t)(((npix(dy) - 1) * dy->ldc + dy->c) * es);  // checked the sizes fit 32 bits)
+    job->kind = alltaps ? 1 : 0;
+    job->dtype = x->dtype;
+    job->blocks[job->kind] = g.tiles_ci * g.tiles_co * (alltaps ? 1 : g.KH * g.KW) * g.S;
+    job->blocks[2] = g.S > 1 ? (int32_t)((n_out + 63) / 64) : 0;
+    job->n_out = n_out;
+    job->flops = 2.0 * g.P * g.Co * g.Ci * g.KH * g.KW;
+    job->bytes = ((double)npix(x) * g.Ci + (double)g.P * g.Co) * es + (double)n_out * 4;
+    return DSN_OK;
+}
+
+constexpr size_t ALLTAPS_LDS = (size_t)2 * 32 * TB * 2 * (1 + 9);   // A + 9 shifted B tiles, double buffered: 80 KiB
+void alltaps_attr_once() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void*)wgrad_alltaps_bf16_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ALLTAPS_LDS);
+    (void)hipFuncSetAttribute((const void*)wgrad_alltaps_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ALLTAPS_LDS);
+    done = true;
+}
+
+}  // namespace
+
+extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
+                                const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream) {
+    WJob job;
+    bool vl = false;
+    int rc = make_job(x, dy, dw, ci_pad, oihw, p, workspace, workspace_bytes, &job, &vl);
+    if (rc) return rc;
+    const WGeom& g = job.g;
+    float* out = job.out;
+    hipStream_t st = (hipStream_t)stream;
     // packed layout with a padded channel axis: the reduction also visits the padding lanes, which no tile writes
     if (g.S > 1 && !g.oihw && g.Cip != g.Ci) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)g.S * n_out * sizeof(float), st);
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)g.S * job.n_out * sizeof(float), st);
         if (e != hipSuccess) DSN_FAIL((int)e, "conv wgrad: memset failed");
     }
-    const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
-    const bool vl = (g.Co % vec == 0) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
-                    ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
-    dim3 grid(g.tiles_ci * g.tiles_co * (alltaps ? 1 : g.KH * g.KW) * g.S), block(256);
+    static int pk_bf16 = [] { const char* e = getenv("DSN_WGRAD_PK"); int v = e ? atoi(e) : 32; return (v == 64 || v == 128) ? v : 32; }();
+    const int PK = (x->dtype == DSN_F32 || job.kind == 1) ? 32 : pk_bf16;     // (ppb is a multiple of 32; 64/128 only for tuning runs
+    if (PK != 32 && g.ppb % PK != 0) DSN_FAIL(DSN_EINVAL, "DSN_WGRAD_PK: pixel range per block is not a multiple of %d", PK);
+    dim3 grid(job.blocks[job.kind]), block(256);
     {
-    ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), 2.0 * g.P * g.Co * g.Ci * g.KH * g.KW,
-                   ((double)npix(x) * g.Ci + (double)g.P * g.Co) * es + (double)n_out * 4, st);
-    if (alltaps) {
-        constexpr int NT = 9;
-        const size_t lds = (size_t)2 * 32 * TB * 2 * (1 + NT);          // A + 9 shifted B tiles, double buffered: 80 KiB
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)wgrad_alltaps_bf16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            attr_set = true;
+        ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), job.flops, job.bytes, st);
+        if (job.kind == 1) {
+            alltaps_attr_once();
+            hipLaunchKernelGGL(wgrad_alltaps_bf16_kernel<9>, grid, block, ALLTAPS_LDS, st, (const bf16_t*)x->ptr,
+                               (const bf16_t*)dy->ptr, out, g, job.x_bytes, job.dy_bytes);
+        } else if (x->dtype == DSN_F32) {
+            if (vl)
+                hipLaunchKernelGGL((wgrad_kernel<float, true, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
+            else
+                hipLaunchKernelGGL((wgrad_kernel<float, false, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
+        } else {
+            const bf16_t *xp = (const bf16_t*)x->ptr, *yp = (const bf16_t*)dy->ptr;
+            if (!vl) hipLaunchKernelGGL((wgrad_kernel<bf16_t, false, 32>), grid, block, 0, st, xp, yp, out, g);
+            else if (PK == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 128>), grid, block, 0, st, xp, yp, out, g);
+            else if (PK == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 64>), grid, block, 0, st, xp, yp, out, g);
+            else hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 32>), grid, block, 0, st, xp, yp, out, g);
         }
-        const uint32_t xb = (uint32_t)(((npix(x) - 1) * x->ldc + x->c) * 2), yb = (uint32_t)(((npix(dy) - 1) * dy->ldc + dy->c) * 2);
-        hipLaunchKernelGGL(wgrad_alltaps_bf16_kernel<NT>, grid, block, lds, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out,
-                           g, xb, yb);
-    } else if (x->dtype == DSN_F32) {
-        if (vl)
-            hipLaunchKernelGGL((wgrad_kernel<float, true, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
-        else
-            hipLaunchKernelGGL((wgrad_kernel<float, false, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
-    } else {
-        const bf16_t *xp = (const bf16_t*)x->ptr, *yp = (const bf16_t*)dy->ptr;
-        if (!vl) hipLaunchKernelGGL((wgrad_kernel<bf16_t, false, 32>), grid, block, 0, st, xp, yp, out, g);
-        else if (PK == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 128>), grid, block, 0, st, xp, yp, out, g);
-        else if (PK == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 64>), grid, block, 0, st, xp, yp, out, g);
-        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, true, 32>), grid, block, 0, st, xp, yp, out, g);
-    }
     }
     DSN_LAUNCH_CHECK("conv wgrad");
     if (g.S > 1) {
-        ProfScope prof(KID_WGRAD_REDUCE, 0.0, (double)(g.S + 1) * n_out * 4, st);
-        int64_t b = (n_out + 63) / 64;
+        ProfScope prof(KID_WGRAD_REDUCE, 0.0, (double)(g.S + 1) * job.n_out * 4, st);
+        const int64_t b = job.blocks[2];
         const dim3 rgrid((int)(b > 8192 ? 8192 : b));
-        if (n_out % 4 == 0 && (uintptr_t)out % 16 == 0)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, st, out, dw, n_out, g.S, p->accumulate, g.oihw,
+        if (job.n_out % 4 == 0 && (uintptr_t)out % 16 == 0)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, st, out, dw, job.n_out, g.S, g.accumulate, g.oihw,
                                g.Ci, g.Cip, g.KH * g.KW);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, st, out, dw, n_out, g.S, p->accumulate, g.oihw,
+            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, st, out, dw, job.n_out, g.S, g.accumulate, g.oihw,
                                g.Ci, g.Cip, g.KH * g.KW);
         DSN_LAUNCH_CHECK("conv wgrad reduce");
-    } else if (g.Cip != g.Ci && !p->accumulate) {
-        // direct write leaves the padding lanes of dw untouched: they are defined to be zero
-        // (callers allocate dw zero-filled once; padding is never written afterwards).
+    }
+    return DSN_OK;
+}
+
+// ---- queued form: plan every layer's job during the backward pass, run them all in three launches at its end -----------------
+extern "C" int64_t dsn_wgrad_job_bytes(void) { return (int64_t)sizeof(WJob); }
+
+// Fills *job_out (HOST memory, dsn_wgrad_job_bytes() bytes); launches nothing.  DSN_EUNSUPPORTED when the layer cannot take
+// the grouped kernels (channel counts / pointers that rule out 16-byte loads, packed-layout padding): run dsn_conv2d_wgrad.
+// workspace must be 16-byte aligned and stay untouched until dsn_conv2d_wgrad_run has executed.
+extern "C" int dsn_conv2d_wgrad_plan(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
+                                     const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* job_out) {
+    DSN_CHECK_ARG(job_out, "conv wgrad plan: null job");
+    WJob job;
+    bool vl = false;
+    int rc = make_job(x, dy, dw, ci_pad, oihw, p, workspace, workspace_bytes, &job, &vl);
+    if (rc) return rc;
+    if (!vl || (job.g.S > 1 && !job.g.oihw && job.g.Cip != job.g.Ci) || ((uintptr_t)job.out % 16) != 0)
+        DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: layer needs the single-layer path");
+    *(WJob*)job_out = job;
+    return DSN_OK;
+}
+
+// jobs_host: n planned jobs, contiguous.  Assigns every job its first block in each of the three launches (in place) and
+// returns the three grid sizes + totals in launch_out[8] = {grid per-tap, grid all-taps, grid reduce, dtype, flops, bytes,
+// reduce bytes, 0} (doubles).  Upload the array AFTER this call.
+extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* launch_out) {
+    DSN_CHECK_ARG(jobs_host && n > 0 && launch_out, "conv wgrad plan_finish: bad arguments");
+    WJob* jobs = (WJob*)jobs_host;
+    int64_t start[3] = {0, 0, 0};
+    double flops = 0, bytes = 0, rbytes = 0;
+    for (int i = 0; i < n; ++i) {
+        DSN_CHECK_ARG(jobs[i].dtype == jobs[0].dtype, "conv wgrad plan_finish: mixed dtypes in one queue");
+        for (int k = 0; k < 3; ++k) {
+            jobs[i].start[k] = (int32_t)start[k];
+            start[k] += jobs[i].blocks[k];
+        }
+        flops += jobs[i].flops;
+        bytes += jobs[i].bytes;
+        if (jobs[i].g.S > 1) rbytes += (double)(jobs[i].g.S + 1) * jobs[i].n_out * 4;
+    }
+    for (int k = 0; k < 3; ++k)
+        DSN_CHECK_ARG(start[k] < (1ll << 31), "conv wgrad plan_finish: too many blocks");
+    launch_out[0] = (double)start[0]; launch_out[1] = (double)start[1]; launch_out[2] = (double)start[2];
+    launch_out[3] = (double)jobs[0].dtype; launch_out[4] = flops; launch_out[5] = bytes; launch_out[6] = rbytes;
+    launch_out[7] = 0;
+    return DSN_OK;
+}
+
+// jobs_dev: the device copy of the finished plan.  Three launches: per-tap blocks, all-taps blocks, slab reductions.
+extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const double* launch, void* stream) {
+    DSN_CHECK_ARG(jobs_dev && n > 0 && launch, "conv wgrad run: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const WJob* jobs = (const WJob*)jobs_dev;
+    const int g0 = (int)launch[0], g1 = (int)launch[1], g2 = (int)launch[2], dtype = (int)launch[3];
+    {
+        ProfScope prof(KID_WGRAD + (dtype == DSN_BF16 ? 1 : 0), launch[4], launch[5], st);
+        if (g0 > 0) {
+            if (dtype == DSN_F32)
+                hipLaunchKernelGGL(wgrad_grouped_kernel<float>, dim3(g0), dim3(256), 0, st, jobs, n);
+            else
+                hipLaunchKernelGGL(wgrad_grouped_kernel<bf16_t>, dim3(g0), dim3(256), 0, st, jobs, n);
+        }
+        if (g1 > 0) {
+            DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: all-taps jobs are bf16 only");
+            alltaps_attr_once();
+            hipLaunchKernelGGL(wgrad_alltaps_grouped_kernel, dim3(g1), dim3(256), ALLTAPS_LDS, st, jobs, n);
+        }
+    }
+    DSN_LAUNCH_CHECK("conv wgrad grouped");
+    if (g2 > 0) {
+        ProfScope prof(KID_WGRAD_REDUCE, 0.0, launch[6], st);
+        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3(g2), dim3(256), 0, st, jobs, n);
+        DSN_LAUNCH_CHECK("conv wgrad grouped reduce");
     }
     return DSN_OK;
 }

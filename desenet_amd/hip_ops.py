@@ -149,16 +149,114 @@ def scratch(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False):
+def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False, queue: "Optional[WgradQueue]" = None):
     """oihw=False: dw packed [Co][KH][KW][ci] (ci >= x channels).  oihw=True: dw is the OIHW fp32 gradient itself
-    (ci = real input channels <= x channels); p.accumulate adds into it."""
+    (ci = real input channels <= x channels); p.accumulate adds into it.
+    queue: defer the launch -- the job is planned now and runs with every other queued layer at queue.flush()."""
     L = _lib.lib()
     a, b = desc(x), desc(dy)
     nbytes = L.dsn_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(b), C.byref(p), ci)
+    if queue is not None:
+        slab = queue.slab(nbytes) if nbytes else None
+        rc = L.dsn_conv2d_wgrad_plan(C.byref(a), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p), _p(slab), nbytes,
+                                     queue.next_job_ptr())
+        if rc == 0:
+            queue.commit(x, dy, dw, slab)
+            return dw
+        if rc != DSN_EUNSUPPORTED:
+            _lib.check(rc, "conv2d_wgrad_plan")
     ws = scratch(nbytes, x.device) if nbytes else None
     _lib.check(L.dsn_conv2d_wgrad(C.byref(a), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p), _p(ws), nbytes,
                                   stream_ptr()), "conv2d_wgrad")
     return dw
+
+
+DSN_EUNSUPPORTED = -2
+_wgrad_arena = {}          # device -> persistent slab buffer (bump-allocated within a backward pass)
+_wgrad_pinned = {}         # device -> {"ring": [...], "events": [...], "next": int, "capture": [...]}
+
+
+class WgradQueue:
+    """Weight-gradient jobs of one backward pass: planned layer by layer, launched together by flush() (three launches for
+    the whole network instead of two per layer).  Slabs live in a persistent per-device arena, the job table travels through
+    a pinned host buffer (one small H2D copy per pass; under hipGraph capture it becomes a memcpy node of the graph)."""
+    CAP = 512
+    RING, CAPTURE_POOL = 4, 32
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.job_bytes = int(_lib.lib().dsn_wgrad_job_bytes())
+        self.n = 0
+        self.keep = []
+        self.offset = 0
+        self.extra = 0
+        self.host = None
+
+    # -- pinned job table -------------------------------------------------------------------------------------------------
+    def _pool(self):
+        pool = _wgrad_pinned.get(self.device)
+        if pool is None:
+            mk = lambda: torch.empty(self.CAP * self.job_bytes, dtype=torch.uint8, pin_memory=True)
+            pool = _wgrad_pinned[self.device] = {"ring": [mk() for _ in range(self.RING)], "events": [None] * self.RING,
+                                                 "next": 0, "capture": [mk() for _ in range(self.CAPTURE_POOL)]}
+        return pool
+
+    def _acquire_host(self):
+        pool = self._pool()
+        if torch.cuda.is_current_stream_capturing():
+            if not pool["capture"]:
+                raise RuntimeError("WgradQueue: out of pinned job tables for hipGraph capture")
+            self.slot = None
+            return pool["capture"].pop()        # owned by the captured graph from now on (never reused)
+        i = pool["next"]
+        pool["next"] = (i + 1) % self.RING
+        ev = pool["events"][i]
+        if ev is not None:
+            ev.synchronize()                     # the copy that last read this buffer has executed (normally long ago)
+        self.slot = i
+        return pool["ring"][i]
+
+    def next_job_ptr(self):
+        if self.n >= self.CAP:
+            raise RuntimeError(f"WgradQueue: more than {self.CAP} layers queued")
+        if self.host is None:
+            self.host = self._acquire_host()
+        return self.host.data_ptr() + self.n * self.job_bytes
+
+    # -- slab arena ---------------------------------------------------------------------------------------------------------
+    def slab(self, nbytes):
+        n = (nbytes + 255) // 256 * 256
+        arena = _wgrad_arena.get(self.device)
+        if arena is not None and self.offset + n <= arena.numel():
+            t = arena[self.offset:self.offset + n]
+            self.offset += n
+            return t
+        self.extra += n                          # does not fit: a one-off buffer now, a larger arena from the next pass on
+        t = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def commit(self, x, dy, dw, slab):
+        self.keep.append((x, dy, dw))
+        self.n += 1
+
+    def flush(self):
+        if self.n:
+            L = _lib.lib()
+            launch = (C.c_double * 8)()
+            _lib.check(L.dsn_conv2d_wgrad_plan_finish(self.host.data_ptr(), self.n, launch), "conv2d_wgrad_plan_finish")
+            nb = self.n * self.job_bytes
+            dev = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            dev.copy_(self.host[:nb], non_blocking=True)
+            if self.slot is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pool()["events"][self.slot] = ev
+            _lib.check(L.dsn_conv2d_wgrad_run(dev.data_ptr(), self.n, launch, stream_ptr()), "conv2d_wgrad_run")
+        if self.extra and not torch.cuda.is_current_stream_capturing():
+            need = self.offset + self.extra      # everything is enqueued on this stream: safe to replace the arena now
+            _wgrad_arena[self.device] = torch.empty(int(need * 1.1) + (1 << 20), dtype=torch.uint8, device=self.device)
+        self.n, self.keep, self.offset, self.extra, self.host = 0, [], 0, 0, None
 
 
 class WeightBank:

@@ -73,6 +73,17 @@ class Tape:
         self.cursor = len(self.stack)
         self.grads = {}
         self.forked = set()
+        self.wq = None
+
+    def wgrad_queue(self, device):
+        """Queue that collects this backward pass's weight-gradient jobs (launched together by join()); None when the
+        side-stream variant is selected instead."""
+        if _use_side_stream:
+            return None
+        q = getattr(self, "wq", None)
+        if q is None:
+            q = self.wq = _ops().WgradQueue(device)
+        return q
 
     def fork(self, device):
         """Side stream that may start once everything enqueued so far on the current stream is done (or None)."""
@@ -83,7 +94,11 @@ class Tape:
         return side
 
     def join(self):
-        """The current stream waits for every side stream used since begin_backward()."""
+        """End of a backward pass: launch the queued weight gradients; the current stream waits for every side stream used
+        since begin_backward()."""
+        q = getattr(self, "wq", None)
+        if q is not None:
+            q.flush()
         for side in getattr(self, "forked", ()):
             torch.cuda.current_stream(side.device).wait_stream(side)
         self.forked = set()

@@ -90,6 +90,19 @@ int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* 
  *           channels); with p->accumulate the result is ADDED to dw (gradient accumulation straight into .grad). */
 int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
                      const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream);
+/* Queued form of the same computation.  dW feeds nothing but the optimizer, so a backward pass can PLAN every layer's
+ * weight gradient as it goes (no launch) and RUN them all at its end in three launches (per-tap blocks, all-taps blocks,
+ * slab reductions): the blocks of ~80 small layers share one grid instead of 150 launches that each under-fill the chip.
+ *   dsn_conv2d_wgrad_plan: same arguments as dsn_conv2d_wgrad + job_out (HOST, dsn_wgrad_job_bytes() bytes).  x, dy, dw and
+ *     workspace must stay valid and untouched until the run has executed.  DSN_EUNSUPPORTED: use dsn_conv2d_wgrad.
+ *   dsn_conv2d_wgrad_plan_finish: jobs_host = n planned jobs, contiguous; assigns block ranges in place and fills
+ *     launch_out[8].  Copy jobs_host to the device AFTER this call.
+ *   dsn_conv2d_wgrad_run: jobs_dev = device copy of the finished plan. */
+int64_t dsn_wgrad_job_bytes(void);
+int dsn_conv2d_wgrad_plan(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
+                          const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* job_out);
+int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* launch_out);
+int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const double* launch, void* stream);
 
 /* weight packing: OIHW fp32 master weights (the state_dict layout, `...conv.weight [c2,c1,k,k]`) -> kernel layouts.
  * ci_pad >= ci zero-pads the input-channel axis (Focus: 12 -> 16 for 16-byte bf16 loads).
