@@ -33,7 +33,7 @@ template <> struct VecIO<float, 4> {
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
     }
     __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
-        *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(p));
     }
 };
 template <> struct VecIO<bf16_t, 8> {
@@ -46,10 +46,25 @@ template <> struct VecIO<bf16_t, 8> {
         bf16x8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
-        *reinterpret_cast<bf16x8*>(p) = v;
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
     }
 };
 template <typename T> struct VW { static constexpr int N = 16 / sizeof(T); };
+
+// V consecutive per-channel fp32 constants (c0 is a multiple of V, arrays are 32-byte aligned): 16-byte loads instead of V
+// scalar ones -- a thread used to issue up to 48 scalar loads of constants before touching its 2-8 data vectors.
+template <int V> __device__ __forceinline__ void ldvec(const float* __restrict__ p, float (&o)[V]) {
+    if constexpr (V % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < V / 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            o[4 * i] = v[0]; o[4 * i + 1] = v[1]; o[4 * i + 2] = v[2]; o[4 * i + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = p[i];
+    }
+}
 
 // ---- functors ----------------------------------------------------------------------------------------------------------
 // Reductions: accumulate two per-channel quantities from (a = in0, b = in1).
@@ -65,8 +80,7 @@ template <int V> struct BwdRedF {           // sum g, sum g*yhat with g = dz * a
     BnParams p;
     float sc[V], sh[V], mu[V], rs[V];
     __device__ __forceinline__ void prepare(int c0, const float*) {
-#pragma unroll
-        for (int k = 0; k < V; ++k) { sc[k] = p.scale[c0 + k]; sh[k] = p.shift[c0 + k]; mu[k] = p.mean[c0 + k]; rs[k] = p.rstd[c0 + k]; }
+        ldvec<V>(p.scale + c0, sc); ldvec<V>(p.shift + c0, sh); ldvec<V>(p.mean + c0, mu); ldvec<V>(p.rstd + c0, rs);
     }
     __device__ __forceinline__ void acc(const float (&y)[V], const float (&dz)[V], float (&q0)[V], float (&q1)[V]) const {
 #pragma unroll
@@ -82,10 +96,13 @@ template <int V> struct FwdF {              // act(y*scale + shift) [+ res]
     BnParams p; bool has_res;
     float sc[V], sh[V];
     __device__ __forceinline__ void prepare(int c0, const float* pro) {     // pro: (scale, shift) from the kernel prologue
+        if (pro) {
+            ldvec<V>(pro + c0, sc); ldvec<V>(pro + p.C + c0, sh);
+        } else if (p.scale) {
+            ldvec<V>(p.scale + c0, sc); ldvec<V>(p.shift + c0, sh);
+        } else {
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            sc[k] = pro ? pro[c0 + k] : (p.scale ? p.scale[c0 + k] : 1.f);
-            sh[k] = pro ? pro[p.C + c0 + k] : (p.scale ? p.shift[c0 + k] : 0.f);
+            for (int k = 0; k < V; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
         }
     }
     __device__ __forceinline__ void apply(const float (&y)[V], const float (&r)[V], float (&o)[V]) const {
@@ -98,14 +115,18 @@ template <int V> struct FwdF {              // act(y*scale + shift) [+ res]
 };
 template <int V> struct BwdApplyF {         // BN: scale*(g - mean_g - yhat*mean_gyhat);  no BN: dz*act'(y)
     BnParams p;
-    float sc[V], sh[V], mu[V], rs[V], m1[V], m2[V];
-    __device__ __forceinline__ void prepare(int c0, const float* pro) {     // pro: (mean g, mean g*yhat) from the prologue
+    float sc[V], sh[V], mu[V], ka[V], kb[V];     // dy = sc*g + ka*(y - mu) + kb,  ka = -sc*rstd*mean_gyhat, kb = -sc*mean_g
+    __device__ __forceinline__ void prepare(int c0, const float* pro) {     // pro: [sc, sh, mu, ka, kb] from the prologue
         if (!p.scale) return;
+        if (pro) {
+            ldvec<V>(pro + c0, sc); ldvec<V>(pro + p.C + c0, sh); ldvec<V>(pro + 2 * p.C + c0, mu);
+            ldvec<V>(pro + 3 * p.C + c0, ka); ldvec<V>(pro + 4 * p.C + c0, kb);
+        } else {
+            float rs[V], m1[V], m2[V];
+            ldvec<V>(p.scale + c0, sc); ldvec<V>(p.shift + c0, sh); ldvec<V>(p.mean + c0, mu); ldvec<V>(p.rstd + c0, rs);
+            ldvec<V>(p.means + c0, m1); ldvec<V>(p.means + p.C + c0, m2);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            sc[k] = p.scale[c0 + k]; sh[k] = p.shift[c0 + k]; mu[k] = p.mean[c0 + k]; rs[k] = p.rstd[c0 + k];
-            m1[k] = pro ? pro[c0 + k] : p.means[c0 + k];
-            m2[k] = pro ? pro[p.C + c0 + k] : p.means[p.C + c0 + k];
+            for (int k = 0; k < V; ++k) { ka[k] = -sc[k] * rs[k] * m2[k]; kb[k] = -sc[k] * m1[k]; }
         }
     }
     __device__ __forceinline__ void apply(const float (&y)[V], const float (&dz)[V], float (&o)[V]) const {
@@ -113,7 +134,7 @@ template <int V> struct BwdApplyF {         // BN: scale*(g - mean_g - yhat*mean
         for (int k = 0; k < V; ++k) {
             if (p.scale) {
                 const float g = dz[k] * act_grad(y[k] * sc[k] + sh[k], p.act);
-                o[k] = sc[k] * (g - m1[k] - ((y[k] - mu[k]) * rs[k]) * m2[k]);
+                o[k] = sc[k] * g + (ka[k] * (y[k] - mu[k]) + kb[k]);
             } else {
                 o[k] = dz[k] * act_grad(y[k], p.act);
             }
@@ -194,7 +215,7 @@ struct EwPro {
     const float *gamma, *beta;
     float *running_mean, *running_var;
     float momentum, eps;
-    float *scale, *shift, *mean, *rstd;     // forward: saved for the backward pass
+    float *scale, *shift, *mean, *rstd;     // forward: written (saved for the backward pass); backward: read
     float *dgamma, *dbeta;                  // backward: parameter gradients
     int32_t accumulate;
 };
@@ -222,8 +243,12 @@ __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
                 }
             }
         } else {
-            lds[c] = (float)(s / q.a.count);
-            lds[C + c] = (float)(ss / q.a.count);
+            const float sc = q.scale[c], m1 = (float)(s / q.a.count), m2 = (float)(ss / q.a.count);
+            lds[c] = sc;
+            lds[C + c] = q.shift[c];
+            lds[2 * C + c] = q.mean[c];
+            lds[3 * C + c] = -sc * q.rstd[c] * m2;
+            lds[4 * C + c] = -sc * m1;
             if (writer) {
                 if (q.dbeta) q.dbeta[c] = q.accumulate ? q.dbeta[c] + (float)s : (float)s;
                 if (q.dgamma) q.dgamma[c] = q.accumulate ? q.dgamma[c] + (float)ss : (float)ss;
@@ -236,7 +261,7 @@ __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
 template <typename T, int V, bool HAS_B, bool PRO, typename F>
 __global__ __launch_bounds__(THREADS) void ew2_kernel(const T* __restrict__ a, int64_t ald, const T* __restrict__ b,
                                                       int64_t bld, T* __restrict__ o, int64_t old_, Strip s, const EwPro pro, F f) {
-    __shared__ float s_pro[PRO ? 2 * PRO_MAXC : 1];
+    __shared__ __attribute__((aligned(16))) float s_pro[PRO ? 5 * PRO_MAXC : 4];
     if (PRO) ew_prologue(pro, s_pro);
     const float* lds = PRO ? s_pro : nullptr;
     const int ncv = s.C / V;
@@ -360,10 +385,18 @@ inline bool same_shape(const dsn_tensor* a, const dsn_tensor* b) {
     return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c && a->dtype == b->dtype;
 }
 // strips: enough blocks to fill the chip, each thread one UNROLL-deep sweep when the tensor is large enough
-inline Strip make_strip(int64_t P, int C, int V, int max_blocks, int* nblocks) {
+inline Strip make_strip(int64_t P, int C, int V, int max_blocks, int* nblocks, bool adaptive = true) {
     const int ncv = C / V;
     const int TX = ncv < THREADS ? ncv : THREADS, TY = THREADS / TX;
-    int64_t per = (int64_t)TY * UNROLL;
+    // vectors per thread: UNROLL when the tensor can still give every SIMD a few waves that way, fewer on small maps (a
+    // thread's 8*UNROLL elements are serial ALU work -- exp, rcp, converts -- that nothing hides at one wave per SIMD)
+    const int64_t vectors = P * ncv;
+    static const int ufix = [] { const char* e = getenv("DSN_EW_UNROLL"); return e ? atoi(e) : 0; }();   // tuning knob
+    int u = (int)(vectors / (256 * 4 * 64 * 2));
+    u = u < 1 ? 1 : (u > UNROLL ? UNROLL : u);
+    if (ufix > 0) u = ufix > UNROLL ? UNROLL : ufix;
+    if (!adaptive) u = UNROLL;      // reductions: every block ends with an LDS fold + 2C atomics -> fewer, fatter blocks
+    int64_t per = (int64_t)TY * u;
     int64_t nb = (P + per - 1) / per;
     if (nb > max_blocks) {
         per = (P + max_blocks - 1) / max_blocks;
@@ -381,11 +414,11 @@ void launch_reduce(bool vec, const dsn_tensor* a, const dsn_tensor* b, const BnA
     constexpr int VV = VW<T>::N;
     const int64_t P = npix(a);
     if (vec) {
-        Strip s = make_strip(P, a->c, VV, MAX_RED_BLOCKS, nblocks);
+        Strip s = make_strip(P, a->c, VV, MAX_RED_BLOCKS, nblocks, false);
         hipLaunchKernelGGL((reduce2_kernel<T, VV, HAS_B, F<VV>>), dim3(*nblocks), dim3(THREADS), 0, st, (const T*)a->ptr,
                            a->ldc, b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, s, fin, F<VV>{args...});
     } else {
-        Strip s = make_strip(P, a->c, 1, MAX_RED_BLOCKS, nblocks);
+        Strip s = make_strip(P, a->c, 1, MAX_RED_BLOCKS, nblocks, false);
         hipLaunchKernelGGL((reduce2_kernel<T, 1, HAS_B, F<1>>), dim3(*nblocks), dim3(THREADS), 0, st, (const T*)a->ptr,
                            a->ldc, b ? (const T*)b->ptr : nullptr, b ? b->ldc : 0, s, fin, F<1>{args...});
     }
@@ -533,6 +566,7 @@ extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const f
     EwPro pro{};
     pro.a = f;
     pro.mode = 1;
+    pro.scale = (float*)scale; pro.shift = (float*)shift; pro.mean = (float*)mean; pro.rstd = (float*)rstd;   // read only
     pro.dgamma = dgamma; pro.dbeta = dbeta; pro.accumulate = accumulate;
     {
         ProfScope prof(KID_BN_BWD_APPLY, 0.0, 3.0 * P * y->c * esz, st);

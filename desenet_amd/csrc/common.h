@@ -53,7 +53,9 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: these kernels are ALU-latency bound on the
+// small maps (one wave per SIMD), and 1 ulp is far inside the fp32 parity tolerance (1e-3 relative).
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == DSN_ACT_SILU) return v * sigmoidf_(v);
     if (act == DSN_ACT_SIGMOID) return sigmoidf_(v);

@@ -445,11 +445,11 @@ __device__ __forceinline__ int find_job(const WJob* __restrict__ jobs, int n, in
     }
     return lo;
 }
-template <typename T>
+template <typename T, int PK>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     const int l = find_job(jobs, n, blockIdx.x, 0);
     const WGeom g = jobs[l].g;
-    wgrad_body<T, true, 32>((const T*)jobs[l].x, (const T*)jobs[l].dy, jobs[l].out, g, blockIdx.x - jobs[l].start[0]);
+    wgrad_body<T, true, PK>((const T*)jobs[l].x, (const T*)jobs[l].dy, jobs[l].out, g, blockIdx.x - jobs[l].start[0]);
 }
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     const int l = find_job(jobs, n, blockIdx.x, 1);
@@ -484,9 +484,9 @@ inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
 
 inline int choose_split(const WGeom& g, bool alltaps = false) {
     const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
-    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
     static const int scap = [] { const char* e = getenv("DSN_WGRAD_SCAP"); return e ? atoi(e) : 256; }();
-    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 256; }();
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 512; }();
     const int tgt = alltaps ? target / 2 : target, cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
     int64_t s = (tgt + base - 1) / base;
     const int64_t smax = (g.P + minpx - 1) / minpx;
@@ -530,7 +530,8 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
     const bool alltaps = use_alltaps(x, dy, p);
     g.S = choose_split(g, alltaps);
-    const int PK = 32;
+    static const int gpk = [] { const char* e = getenv("DSN_WGRAD_GPK"); return (e && atoi(e) == 64) ? 64 : 32; }();
+    const int PK = gpk;       // pixel ranges are multiples of the largest chunk any kernel variant may use
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
     g.accumulate = p->accumulate;
@@ -682,10 +683,13 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
     {
         ProfScope prof(KID_WGRAD + (dtype == DSN_BF16 ? 1 : 0), launch[4], launch[5], st);
         if (g0 > 0) {
+            static const int gpk = [] { const char* e = getenv("DSN_WGRAD_GPK"); return (e && atoi(e) == 64) ? 64 : 32; }();
             if (dtype == DSN_F32)
-                hipLaunchKernelGGL(wgrad_grouped_kernel<float>, dim3(g0), dim3(256), 0, st, jobs, n);
+                hipLaunchKernelGGL((wgrad_grouped_kernel<float, 32>), dim3(g0), dim3(256), 0, st, jobs, n);
+            else if (gpk == 64)
+                hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 64>), dim3(g0), dim3(256), 0, st, jobs, n);
             else
-                hipLaunchKernelGGL(wgrad_grouped_kernel<bf16_t>, dim3(g0), dim3(256), 0, st, jobs, n);
+                hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 32>), dim3(g0), dim3(256), 0, st, jobs, n);
         }
         if (g1 > 0) {
             DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: all-taps jobs are bf16 only");

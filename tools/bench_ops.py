@@ -39,10 +39,38 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 
+BN_SHAPES = [(8, 32, 320, 320), (8, 64, 160, 160), (8, 32, 160, 160), (8, 64, 80, 80), (8, 128, 80, 80), (8, 128, 40, 40),
+             (8, 256, 40, 40), (8, 256, 20, 20), (8, 512, 20, 20)]
+
+
+def bench_bn():
+    """BatchNorm + SiLU elementwise passes (training fwd apply, bwd reduce + apply) per activation shape, in-graph time."""
+    dt = torch.bfloat16
+    for n, c, h, w in BN_SHAPES:
+        y = ops.new_act(n, c, h, w, dt, "cuda"); y.normal_()
+        dz = ops.new_act(n, c, h, w, dt, "cuda"); dz.normal_()
+        z = ops.new_act(n, c, h, w, dt, "cuda")
+        dy = ops.new_act(n, c, h, w, dt, "cuda")
+        g = torch.ones(c, device="cuda"); b = torch.zeros(c, device="cuda")
+        rm = torch.zeros(c, device="cuda"); rv = torch.ones(c, device="cuda")
+        sc, sh, mu, rs = ops.bn_stats(y, g, b, rm, rv, 0.03, 1e-3)
+        dg = torch.zeros(c, device="cuda"); db = torch.zeros(c, device="cuda")
+        mb = y.numel() * 2 / 1e6
+        ops.bn_arena_begin(y.device)
+        t_st = timeit(lambda: ops.bn_stats(y, g, b, rm, rv, 0.03, 1e-3))
+        t_f = timeit(lambda: ops.bn_act_fwd(y, sc, sh, ops.ACT_SILU, None, z))
+        ops.bn_arena_begin(y.device)
+        t_b = timeit(lambda: ops.bn_act_bwd(dz, y, sc, sh, mu, rs, ops.ACT_SILU, dy, dg, db, accumulate=True), iters=20)
+        print(f"{n}x{c}x{h}x{w} {mb:6.1f} MB | stats {t_st:6.1f} us | fwd {t_f:6.1f} us {2*mb/t_f*1e-3:5.2f} TB/s | "
+              f"bwd(reduce+apply) {t_b:6.1f} us {5*mb/t_b*1e-3:5.2f} TB/s", flush=True)
+
+
 def main():
     dt = torch.bfloat16
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     only = sys.argv[2] if len(sys.argv) > 2 else None
+    if which == "bn":
+        return bench_bn()
     for name, n, ci, h, w, co, k, s in LAYERS:
         if only and only not in name:
             continue
