@@ -59,10 +59,10 @@ extern "C" int32_t dsn_profile_kernel_count(void) { return KID_COUNT; }
 
 extern "C" const char* dsn_profile_kernel_name(int32_t kid) {
     static thread_local char buf[64];
-    static const char* cfg[5] = {"128x128", "128x64", "64x64", "128x32", "64x16"};
+    static const char* cfg[7] = {"128x128", "128x64", "64x64", "128x32", "64x16", "32x64", "64x32"};
     if (kid >= KID_IGEMM && kid < KID_WGRAD) {
         const int dt = kid / 20, c = (kid % 20) / 2, dg = kid & 1;
-        snprintf(buf, sizeof(buf), "igemm_%s_%s_%s", dt ? "bf16" : "f32", c < 5 ? cfg[c] : "?", dg ? "dgrad" : "fwd");
+        snprintf(buf, sizeof(buf), "igemm_%s_%s_%s", dt ? "bf16" : "f32", c < 7 ? cfg[c] : "?", dg ? "dgrad" : "fwd");
         return buf;
     }
     switch (kid) {

@@ -20,6 +20,8 @@
 // Epilogue: accumulators (+bias, activation) are staged through LDS as fp32, optional BatchNorm partial sums (per-channel
 // sum / sum of squares over the tile's rows, from the un-rounded fp32 values) are written for the finalize kernel, and the
 // tile leaves with 16-byte stores (+ residual, += destination) -- instead of 2-byte stores per lane.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -426,7 +428,7 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
                bool vec, hipStream_t st, int* tiles_m_out) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
-                        : (BM == 128 && BN == 32) ? 3 : 4;
+                        : (BM == 128 && BN == 32) ? 3 : (BM == 64 && BN == 16) ? 4 : (BM == 32 && BN == 64) ? 5 : 6;
     const int64_t src_elems_ld = ((int64_t)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws - 1) * g.sld + g.Cs;
     g.fits32 = (src_elems_ld < ((1ll << 30) - (1ll << 22))) && ((int64_t)g.Cd * g.Ktot < (1ll << 30));
     g.src_bytes = (uint32_t)(src_elems_ld * sizeof(T));
@@ -485,14 +487,32 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
                      (((uintptr_t)w) % 16 == 0);
     // tile choice: wide-N tiles for wide layers, tall-skinny for narrow ones; small M prefers smaller tiles so the
     // grid still covers the 256 CUs.
-    const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.Cd + 127) / 128);
-    if (g.Cd > 64 && big >= 256)
-        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
-    if (g.Cd > 32 && (int64_t)((g.M + 127) / 128) * ((g.Cd + 63) / 64) >= 192)
-        return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
-    if (g.Cd > 32) return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
-    if (g.Cd > 16) return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
-    return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+    static const int force = [] { const char* e = getenv("DSN_IGEMM_CFG"); return e ? atoi(e) : -1; }();    // tuning knob
+    switch (force) {
+        case 0: return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        case 1: return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        case 2: return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        case 3: return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        case 4: return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        case 5: return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        case 6: return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        default: break;
+    }
+    // Tile choice, from tools/sweep_igemm.sh on the DeSeNet-s layer shapes (batch 8): these layers are latency-bound, not
+    // MFMA-bound, so SMALL tiles win almost everywhere (more blocks per CU hide the load -> LDS -> MFMA round trips);
+    // only the few large GEMMs (FFM 3x3: 1600 tiles x K 2304) amortise a 128x128 tile.
+    const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.Cd + 63) / 64);
+    if (g.Cd <= 16) return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+    if (g.Cd <= 32) {
+        if (g.M >= 400000)      // Focus conv / stem dgrad: 128 pixels x 32 channels
+            return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
+        return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 64x32
+    }
+    if (tiles64 >= 1536 && g.Ktot >= 1024)
+        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 128x128
+    if (tiles64 < 256)
+        return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 32x64
+    return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);          // 64x64
 }
 
 int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const dsn_conv_params* p) {

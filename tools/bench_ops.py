@@ -7,6 +7,13 @@ sys.path.insert(0, ".")
 from desenet_amd import hip_ops as ops
 
 LAYERS = [  # name, N, Ci, H, W, Co, k, s
+    ("c3 cv1 128->64 k1 @80", 8, 128, 80, 80, 64, 1, 1),
+    ("bneck 64->64 k1 @80", 8, 64, 80, 80, 64, 1, 1),
+    ("c3 cv3 128->128 k1 @80", 8, 128, 80, 80, 128, 1, 1),
+    ("bneck 128->128 k1 @40", 8, 128, 40, 40, 128, 1, 1),
+    ("c3 cv1 256->128 k1 @40", 8, 256, 40, 40, 128, 1, 1),
+    ("c3 cv1 512->256 k1 @20", 8, 512, 20, 20, 256, 1, 1),
+    ("c3 cv3 512->512 k1 @20", 8, 512, 20, 20, 512, 1, 1),
     ("focus 16->32 k3 @320", 8, 16, 320, 320, 32, 3, 1),
     ("l1 32->64 k3s2 @320", 8, 32, 320, 320, 64, 3, 2),
     ("c3 cv1 64->32 k1 @160", 8, 64, 160, 160, 32, 1, 1),
