@@ -66,6 +66,8 @@ PROTOTYPES = {
     "dsn_bilinear_ac_bwd": (i32, [TP, i32, TP, i32, vp, i64, vp]),
     "dsn_window_reduce_workspace_bytes": (i64, [i32, i32, i32]),
     "dsn_adaptive_avgpool": (i32, [TP, TP, vp, i64, vp]),
+    "dsn_adaptive_avgpool_bwd_multi": (i32, [vp, i32, TP, i32, vp]),
+    "dsn_maxpool_s1_bwd_multi": (i32, [vp, vp, vp, i32, TP, i32, vp]),
     "dsn_adaptive_avgpool_bwd": (i32, [TP, TP, i32, vp]),
     "dsn_copy": (i32, [TP, TP, i32, vp]),
     "dsn_ffm_scale": (i32, [TP, TP, TP, vp]),

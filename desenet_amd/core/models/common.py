@@ -166,8 +166,8 @@ class SPP(HipModule):
         dcat = self.cv2.bwd(tape, dy)
         idxs = tape.pop()
         d0 = dcat[:, :c_]
-        for i, (mp, idx) in enumerate(zip(self.m, idxs), 1):
-            ops.maxpool_s1_bwd(dcat[:, i * c_:(i + 1) * c_], idx, d0, int(mp.kernel_size), accumulate=True)
+        ops.maxpool_s1_bwd_multi([dcat[:, i * c_:(i + 1) * c_] for i in range(1, len(self.m) + 1)], idxs,
+                                 [int(mp.kernel_size) for mp in self.m], d0, accumulate=True)      # one pass for the three pools
         return self.cv1.bwd(tape, d0, dx, acc, need_dx)
 
 
@@ -376,13 +376,13 @@ class PyramidPooling(HipModule):
         elif self.short_cut:
             ops.copy(dy[:, :c], dx, accumulate=acc)
             acc = True
+        dpools = []
         for j, (pool, conv) in reversed(list(enumerate(self._branches()))):
             ksz = pool.output_size if isinstance(pool.output_size, int) else pool.output_size[0]
             df = ops.bilinear_ac_bwd(dy[:, base + j * oc: base + (j + 1) * oc],
                                      ops.new_act(n, oc, ksz, ksz, dy.dtype, dy.device))
-            dpool = conv.bwd(tape, df)
-            ops.adaptive_avgpool_bwd(dpool, dx, accumulate=acc)
-            acc = True
+            dpools.append(conv.bwd(tape, df))
+        ops.adaptive_avgpool_bwd_multi(dpools, dx, accumulate=acc)      # the four grids in one pass over dx
         return dx
 
 

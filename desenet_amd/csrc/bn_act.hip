@@ -16,41 +16,6 @@ constexpr int THREADS = 256;
 constexpr int UNROLL = 4;
 constexpr int MAX_RED_BLOCKS = 1024;
 
-// ---- 16-byte (or scalar) channel vectors ---------------------------------------------------------------------------------
-template <typename T, int V> struct VecIO {   // generic / scalar
-    __device__ static __forceinline__ void load(const T* p, float (&o)[V]) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) o[i] = to_f32<T>(p[i]);
-    }
-    __device__ static __forceinline__ void store(T* p, const float (&o)[V]) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) p[i] = from_f32<T>(o[i]);
-    }
-};
-template <> struct VecIO<float, 4> {
-    __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-    }
-    __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
-        __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(p));
-    }
-};
-template <> struct VecIO<bf16_t, 8> {
-    __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
-    }
-    __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
-        bf16x8 v;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
-    }
-};
-template <typename T> struct VW { static constexpr int N = 16 / sizeof(T); };
-
 // V consecutive per-channel fp32 constants (c0 is a multiple of V, arrays are 32-byte aligned): 16-byte loads instead of V
 // scalar ones -- a thread used to issue up to 48 scalar loads of constants before touching its 2-8 data vectors.
 template <int V> __device__ __forceinline__ void ldvec(const float* __restrict__ p, float (&o)[V]) {

@@ -256,6 +256,112 @@ __global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, int64_t yl
     }
 }
 
+// Vectorised multi-source form: dx (+)= sum_i avgpool_bwd(dy_i) for up to 4 pooled gradients with different grids, ONE
+// pass over dx with 16-byte accesses (PyramidPooling backward: four pools accumulate into the same dx).
+struct PoolSrcs {
+    const void* dy[4];
+    int64_t ld[4];
+    int32_t KH[4], KW[4];
+    int32_t n;
+};
+template <typename T, int V>
+__global__ void adaptive_avgpool_bwd_multi_kernel(const PoolSrcs srcs, T* __restrict__ dx, int64_t xld, int N, int H, int W,
+                                                  int C, int accumulate) {
+    const int ncv = C / V;
+    const int64_t total = (int64_t)N * H * W * ncv;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % ncv);
+        int64_t t = i / ncv;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
+        for (int b = 0; b < srcs.n; ++b) {
+            const int KH = srcs.KH[b], KW = srcs.KW[b];
+            const T* dy = (const T*)srcs.dy[b];
+            const int oh0 = (h * KH) / H, ow0 = (w * KW) / W;
+            const int oh_lo = H < KH ? 0 : (oh0 > 0 ? oh0 - 1 : 0), oh_hi = H < KH ? KH - 1 : (oh0 + 1 < KH ? oh0 + 1 : KH - 1);
+            const int ow_lo = W < KW ? 0 : (ow0 > 0 ? ow0 - 1 : 0), ow_hi = W < KW ? KW - 1 : (ow0 + 1 < KW ? ow0 + 1 : KW - 1);
+            for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+                const int h0 = bin_lo(oh, H, KH), h1 = bin_hi(oh, H, KH);
+                if (h < h0 || h >= h1) continue;
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    const int w0 = bin_lo(ow, W, KW), w1 = bin_hi(ow, W, KW);
+                    if (w < w0 || w >= w1) continue;
+                    float v[V];
+                    VecIO<T, V>::load(dy + (((int64_t)n * KH + oh) * KW + ow) * srcs.ld[b] + cv * V, v);
+                    const float area = (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+                    for (int k = 0; k < V; ++k) s[k] += v[k] / area;
+                }
+            }
+        }
+        T* o = dx + (((int64_t)n * H + h) * W + w) * xld + cv * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += old[k];
+        }
+        VecIO<T, V>::store(o, s);
+    }
+}
+
+// Max-pool backward as a scatter through LDS: a block owns one image and one 16-byte channel vector, zeroes an [H*W][V]
+// fp32 image of dx in LDS, walks every output pixel of every pool ONCE (16-byte dy load + V indices) adding into the
+// arg-max position with LDS atomics, then writes dx out.  The gather form above reads k*k (25 / 81 / 169) index + gradient
+// pairs per input pixel.  fp32 LDS atomics: the summation order inside a pixel is not fixed (ATen's CUDA max_pool2d
+// backward uses atomicAdd the same way).
+struct MaxSrcs {
+    const void* dy[3];
+    int64_t ld[3];
+    const int32_t* idx[3];
+    int32_t n;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool_bwd_scatter_kernel(const MaxSrcs srcs, T* __restrict__ dx, int64_t xld, int HW,
+                                                                  int C, int accumulate) {
+    extern __shared__ float sacc[];          // [HW][V]
+    const int ncv = C / V;
+    const int n = blockIdx.x / ncv, cv = blockIdx.x % ncv;
+    for (int i = threadIdx.x; i < HW * V; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    for (int b = 0; b < srcs.n; ++b) {
+        const T* dy = (const T*)srcs.dy[b];
+        const int32_t* idx = srcs.idx[b];
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int64_t op = (int64_t)n * HW + p;
+            float g[V];
+            VecIO<T, V>::load(dy + op * srcs.ld[b] + cv * V, g);
+            int q[V];
+#pragma unroll
+            for (int k = 0; k < V; k += 4) {
+                const u32x4 qi = *reinterpret_cast<const u32x4*>(idx + op * C + cv * V + k);
+                q[k] = (int)qi[0]; q[k + 1] = (int)qi[1]; q[k + 2] = (int)qi[2]; q[k + 3] = (int)qi[3];
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                __hip_atomic_fetch_add(&sacc[q[k] * V + k], g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = sacc[p * V + k];
+        T* o = dx + ((int64_t)n * HW + p) * xld + cv * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += old[k];
+        }
+        VecIO<T, V>::store(o, s);
+    }
+}
+
 // ---- FFM: out = feat*att + feat                                                          (common.py:240-241) --------
 template <typename T>
 __global__ void ffm_scale_kernel(const T* __restrict__ f, int64_t fld, const T* __restrict__ att, int64_t ald,
@@ -414,17 +520,54 @@ extern "C" int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t*
     return DSN_OK;
 }
 
-extern "C" int dsn_maxpool_s1_bwd(const dsn_tensor* dy, const int32_t* idx, const dsn_tensor* dx, int32_t k,
-                                  int32_t accumulate, void* stream) {
-    DSN_CHECK_ARG(tensor_ok(dy) && tensor_ok(dx) && same_nhwc(dy, dx) && idx && k >= 1 && (k & 1),
-                  "maxpool_s1_bwd: invalid arguments");
-    const int64_t total = npix(dx) * dx->c;
-    DSN_DISPATCH_DTYPE(dx->dtype, T,
-                       hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                                          (const T*)dy->ptr, dy->ldc, idx, (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w,
-                                          dx->c, k, accumulate));
+namespace {
+inline bool vec16(const dsn_tensor* t) {
+    const int vw = t->dtype == DSN_F32 ? 4 : 8;
+    return t->c % vw == 0 && t->ldc % vw == 0 && ((uintptr_t)t->ptr % 16) == 0;
+}
+}  // namespace
+
+extern "C" int dsn_maxpool_s1_bwd_multi(const dsn_tensor* dys, const void* const* idxs, const int32_t* ks, int32_t n_src,
+                                        const dsn_tensor* dx, int32_t accumulate, void* stream) {
+    DSN_CHECK_ARG(dys && idxs && ks && n_src >= 1 && n_src <= 3 && tensor_ok(dx), "maxpool_s1_bwd_multi: invalid arguments");
+    bool vec = vec16(dx);
+    for (int i = 0; i < n_src; ++i) {
+        DSN_CHECK_ARG(tensor_ok(&dys[i]) && same_nhwc(&dys[i], dx) && idxs[i] && ks[i] >= 1 && (ks[i] & 1),
+                      "maxpool_s1_bwd_multi: source %d does not match dx", i);
+        vec = vec && vec16(&dys[i]) && ((uintptr_t)idxs[i] % 16 == 0);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = dx->h * dx->w;
+    const int V = dx->dtype == DSN_F32 ? 4 : 8;
+    const size_t lds = (size_t)HW * V * sizeof(float);
+    if (vec && lds <= 60 * 1024) {
+        MaxSrcs srcs{};
+        srcs.n = n_src;
+        for (int i = 0; i < n_src; ++i) { srcs.dy[i] = dys[i].ptr; srcs.ld[i] = dys[i].ldc; srcs.idx[i] = (const int32_t*)idxs[i]; }
+        const dim3 grid(dx->n * (dx->c / V));
+        if (dx->dtype == DSN_F32)
+            hipLaunchKernelGGL((maxpool_bwd_scatter_kernel<float, 4>), grid, dim3(256), lds, st, srcs, (float*)dx->ptr, dx->ldc,
+                               HW, dx->c, accumulate);
+        else
+            hipLaunchKernelGGL((maxpool_bwd_scatter_kernel<bf16_t, 8>), grid, dim3(256), lds, st, srcs, (bf16_t*)dx->ptr,
+                               dx->ldc, HW, dx->c, accumulate);
+    } else {
+        const int64_t total = npix(dx) * dx->c;
+        for (int i = 0; i < n_src; ++i)
+            DSN_DISPATCH_DTYPE(dx->dtype, T,
+                               hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st,
+                                                  (const T*)dys[i].ptr, dys[i].ldc, (const int32_t*)idxs[i], (T*)dx->ptr,
+                                                  dx->ldc, dx->n, dx->h, dx->w, dx->c, ks[i], (accumulate || i > 0) ? 1 : 0));
+    }
     DSN_LAUNCH_CHECK("maxpool_s1_bwd");
     return DSN_OK;
+}
+
+extern "C" int dsn_maxpool_s1_bwd(const dsn_tensor* dy, const int32_t* idx, const dsn_tensor* dx, int32_t k,
+                                  int32_t accumulate, void* stream) {
+    DSN_CHECK_ARG(dy && idx, "maxpool_s1_bwd: invalid arguments");
+    const void* idxs[1] = {idx};
+    return dsn_maxpool_s1_bwd_multi(dy, idxs, &k, 1, dx, accumulate, stream);
 }
 
 extern "C" int dsn_upsample_nearest2x(const dsn_tensor* x, const dsn_tensor* y, void* stream) {
@@ -533,16 +676,44 @@ extern "C" int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, vo
     return DSN_OK;
 }
 
-extern "C" int dsn_adaptive_avgpool_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream) {
-    DSN_CHECK_ARG(tensor_ok(dx) && tensor_ok(dy) && dx->dtype == dy->dtype && dx->n == dy->n && dx->c == dy->c,
-                  "adaptive_avgpool_bwd: invalid arguments");
-    const int64_t total = npix(dx) * dx->c;
-    DSN_DISPATCH_DTYPE(dx->dtype, T,
-                       hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
-                                          (hipStream_t)stream, (const T*)dy->ptr, dy->ldc, (T*)dx->ptr, dx->ldc, dx->n,
-                                          dx->h, dx->w, dx->c, dy->h, dy->w, accumulate));
+extern "C" int dsn_adaptive_avgpool_bwd_multi(const dsn_tensor* dys, int32_t n_src, const dsn_tensor* dx, int32_t accumulate,
+                                              void* stream) {
+    DSN_CHECK_ARG(dys && n_src >= 1 && n_src <= 4 && tensor_ok(dx), "adaptive_avgpool_bwd_multi: invalid arguments");
+    bool vec = vec16(dx);
+    for (int i = 0; i < n_src; ++i) {
+        DSN_CHECK_ARG(tensor_ok(&dys[i]) && dx->dtype == dys[i].dtype && dx->n == dys[i].n && dx->c == dys[i].c,
+                      "adaptive_avgpool_bwd_multi: source %d does not match dx", i);
+        vec = vec && vec16(&dys[i]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) {
+        PoolSrcs srcs{};
+        srcs.n = n_src;
+        for (int i = 0; i < n_src; ++i) {
+            srcs.dy[i] = dys[i].ptr; srcs.ld[i] = dys[i].ldc; srcs.KH[i] = dys[i].h; srcs.KW[i] = dys[i].w;
+        }
+        const int V = dx->dtype == DSN_F32 ? 4 : 8;
+        const int64_t total = npix(dx) * (dx->c / V);
+        if (dx->dtype == DSN_F32)
+            hipLaunchKernelGGL((adaptive_avgpool_bwd_multi_kernel<float, 4>), dim3(ew_grid(total)), dim3(256), 0, st, srcs,
+                               (float*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dx->c, accumulate);
+        else
+            hipLaunchKernelGGL((adaptive_avgpool_bwd_multi_kernel<bf16_t, 8>), dim3(ew_grid(total)), dim3(256), 0, st, srcs,
+                               (bf16_t*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dx->c, accumulate);
+    } else {
+        const int64_t total = npix(dx) * dx->c;
+        for (int i = 0; i < n_src; ++i)
+            DSN_DISPATCH_DTYPE(dx->dtype, T,
+                               hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st,
+                                                  (const T*)dys[i].ptr, dys[i].ldc, (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w,
+                                                  dx->c, dys[i].h, dys[i].w, (accumulate || i > 0) ? 1 : 0));
+    }
     DSN_LAUNCH_CHECK("adaptive_avgpool_bwd");
     return DSN_OK;
+}
+
+extern "C" int dsn_adaptive_avgpool_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream) {
+    return dsn_adaptive_avgpool_bwd_multi(dy, 1, dx, accumulate, stream);
 }
 
 extern "C" int dsn_ffm_scale(const dsn_tensor* feat, const dsn_tensor* att, const dsn_tensor* out, void* stream) {

@@ -455,6 +455,18 @@ def maxpool_s1_bwd(dy, idx, dx, k, accumulate=False):
     return dx
 
 
+def maxpool_s1_bwd_multi(dys, idxs, ks, dx, accumulate=False):
+    """dx (+)= sum_i maxpool_s1_bwd(dys[i], idxs[i], ks[i]) in one pass (SPP: three pools of one input)."""
+    n = len(dys)
+    arr = (dsn_tensor * n)(*[desc(t) for t in dys])
+    ip = (C.c_void_p * n)(*[t.data_ptr() for t in idxs])
+    kk = (C.c_int32 * n)(*[int(k) for k in ks])
+    b = desc(dx)
+    _lib.check(_lib.lib().dsn_maxpool_s1_bwd_multi(C.cast(arr, C.c_void_p), C.cast(ip, C.c_void_p), C.cast(kk, C.c_void_p), n,
+                                                   C.byref(b), int(accumulate), stream_ptr()), "maxpool_s1_bwd_multi")
+    return dx
+
+
 def upsample_nearest2x(x, y):
     a, b = desc(x), desc(y)
     _lib.check(_lib.lib().dsn_upsample_nearest2x(C.byref(a), C.byref(b), stream_ptr()), "upsample_nearest2x")
@@ -511,6 +523,16 @@ def adaptive_avgpool_bwd(dy, dx, accumulate=False):
     a, b = desc(dy), desc(dx)
     _lib.check(_lib.lib().dsn_adaptive_avgpool_bwd(C.byref(a), C.byref(b), int(accumulate), stream_ptr()),
                "adaptive_avgpool_bwd")
+    return dx
+
+
+def adaptive_avgpool_bwd_multi(dys, dx, accumulate=False):
+    """dx (+)= sum_i adaptive_avgpool_bwd(dys[i]) in one pass (PyramidPooling: four grids pool the same input)."""
+    n = len(dys)
+    arr = (dsn_tensor * n)(*[desc(t) for t in dys])
+    b = desc(dx)
+    _lib.check(_lib.lib().dsn_adaptive_avgpool_bwd_multi(C.cast(arr, C.c_void_p), n, C.byref(b), int(accumulate),
+                                                         stream_ptr()), "adaptive_avgpool_bwd_multi")
     return dx
 
 

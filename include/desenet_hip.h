@@ -175,6 +175,10 @@ int dsn_focus_s2d(const float* x_nchw, int32_t n, int32_t c, int32_t h, int32_t 
 int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream);
 int dsn_maxpool_s1_bwd(const dsn_tensor* dy, const int32_t* idx, const dsn_tensor* dx, int32_t k,
                        int32_t accumulate, void* stream);
+/* dx (+)= sum_i maxpool_s1_bwd(dys[i], idxs[i], ks[i]), i < n_src <= 3: the three SPP pools (common.py:177-185) in ONE pass
+ * (dys: contiguous array of descriptors). */
+int dsn_maxpool_s1_bwd_multi(const dsn_tensor* dys, const void* const* idxs, const int32_t* ks, int32_t n_src,
+                             const dsn_tensor* dx, int32_t accumulate, void* stream);
 int dsn_upsample_nearest2x(const dsn_tensor* x, const dsn_tensor* y, void* stream);
 int dsn_upsample_nearest2x_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream);
 int dsn_bilinear_ac(const dsn_tensor* x, const dsn_tensor* y, int32_t out_nchw, void* stream);
@@ -185,6 +189,9 @@ int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const dsn_tensor*
 int64_t dsn_window_reduce_workspace_bytes(int32_t n_segments, int32_t rows, int32_t c);
 int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, void* workspace, int64_t workspace_bytes, void* stream);
 int dsn_adaptive_avgpool_bwd(const dsn_tensor* dy, const dsn_tensor* dx, int32_t accumulate, void* stream);
+/* dx (+)= sum_i adaptive_avgpool_bwd(dys[i]), i < n_src <= 4: the four PyramidPooling grids (common.py:597-613) in ONE pass */
+int dsn_adaptive_avgpool_bwd_multi(const dsn_tensor* dys, int32_t n_src, const dsn_tensor* dx, int32_t accumulate,
+                                   void* stream);
 int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumulate, void* stream);
 
 /* ---- FFM channel attention (common.py:236-242): out = feat*att + feat, att: [N,1,1,C] ------------------------ */
