@@ -67,6 +67,7 @@ PROTOTYPES = {
     "dsn_window_reduce_workspace_bytes": (i64, [i32, i32, i32]),
     "dsn_adaptive_avgpool": (i32, [TP, TP, vp, i64, vp]),
     "dsn_adaptive_avgpool_bwd_multi": (i32, [vp, i32, TP, i32, vp]),
+    "dsn_maxpool_s1_multi": (i32, [TP, vp, vp, vp, i32, vp]),
     "dsn_maxpool_s1_bwd_multi": (i32, [vp, vp, vp, i32, TP, i32, vp]),
     "dsn_adaptive_avgpool_bwd": (i32, [TP, TP, i32, vp]),
     "dsn_copy": (i32, [TP, TP, i32, vp]),

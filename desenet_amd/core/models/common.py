@@ -152,11 +152,9 @@ class SPP(HipModule):
         n, _, h, w = x.shape
         cat = ops.new_act(n, c_ * (len(self.m) + 1), h, w, x.dtype, x.device)
         x0 = self.cv1.fwd(x, tape, cat[:, :c_])
-        idxs = []
-        for i, mp in enumerate(self.m, 1):
-            idx = torch.empty((n, h, w, c_), dtype=torch.int32, device=x.device) if tape is not None else None
-            ops.maxpool_s1(x0, cat[:, i * c_:(i + 1) * c_], int(mp.kernel_size), idx)
-            idxs.append(idx)
+        idxs = [torch.empty((n, h, w, c_), dtype=torch.int32, device=x.device) if tape is not None else None for _ in self.m]
+        ops.maxpool_s1_multi(x0, [cat[:, i * c_:(i + 1) * c_] for i in range(1, len(self.m) + 1)],
+                             [int(mp.kernel_size) for mp in self.m], idxs)          # one launch, x0 read once
         if tape is not None:
             tape.push(idxs)
         return self.cv2.fwd(cat, tape, out)

@@ -62,6 +62,82 @@ __global__ void maxpool_kernel(const T* __restrict__ x, int64_t xld, T* __restri
     }
 }
 
+// Stride-1 max pools of ONE input at up to three window sizes (SPP: 5 / 9 / 13) in one launch.  A block owns one image and
+// one 16-byte channel vector: the [H*W][V] tile is loaded into LDS once, and each pool is computed separably -- horizontal
+// (max, first column) per pixel, then vertical over rows -- 2k LDS reads per output instead of k*k global ones.  "First row
+// holding the maximum, first column inside that row" is exactly ATen's first maximum in row-major window order.
+struct MaxFwd {
+    void* y[3];
+    int64_t ld[3];
+    int32_t* idx[3];
+    int32_t k[3];
+    int32_t n;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict__ x, int64_t xld, const MaxFwd out, int H, int W,
+                                                            int C) {
+    extern __shared__ float smp[];
+    const int HW = H * W;
+    float* sx = smp;                                   // [HW][V] input
+    float* hv = smp + (size_t)HW * V;                  // [HW][V] horizontal max
+    int* hc = reinterpret_cast<int*>(hv + (size_t)HW * V);   // [HW][V] its column
+    const int ncv = C / V;
+    const int n = blockIdx.x / ncv, cv = blockIdx.x % ncv;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        float v[V];
+        VecIO<T, V>::load(x + ((int64_t)n * HW + p) * xld + cv * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) sx[p * V + k] = v[k];
+    }
+    __syncthreads();
+    for (int b = 0; b < out.n; ++b) {
+        const int r = out.k[b] / 2;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int row = p / W, w = p - row * W;
+            const int w0 = w - r < 0 ? 0 : w - r, w1 = w + r >= W ? W - 1 : w + r;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float best = -INFINITY;
+                int bc = -1;
+                for (int col = w0; col <= w1; ++col) {
+                    const float val = sx[(row * W + col) * V + k];
+                    if (val > best || bc < 0 || val != val) { best = val; bc = col; }
+                }
+                hv[p * V + k] = best;
+                hc[p * V + k] = bc;
+            }
+        }
+        __syncthreads();
+        T* y = (T*)out.y[b];
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int h = p / W, w = p - h * W;
+            const int h0 = h - r < 0 ? 0 : h - r, h1 = h + r >= H ? H - 1 : h + r;
+            float res[V];
+            int q[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float best = -INFINITY;
+                int bi = -1;
+                for (int row = h0; row <= h1; ++row) {
+                    const float val = hv[(row * W + w) * V + k];
+                    if (val > best || bi < 0 || val != val) { best = val; bi = row * W + hc[(row * W + w) * V + k]; }
+                }
+                res[k] = best;
+                q[k] = bi;
+            }
+            const int64_t op = (int64_t)n * HW + p;
+            VecIO<T, V>::store(y + op * out.ld[b] + cv * V, res);
+            if (out.idx[b]) {
+#pragma unroll
+                for (int k = 0; k < V; k += 4)
+                    *reinterpret_cast<u32x4*>(out.idx[b] + op * C + cv * V + k) =
+                        u32x4{(uint32_t)q[k], (uint32_t)q[k + 1], (uint32_t)q[k + 2], (uint32_t)q[k + 3]};
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // dx[n][q][c] (+)= sum over outputs p whose window contains q and whose arg-max is q
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int64_t yld, const int32_t* __restrict__ idx,
@@ -469,15 +545,29 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict_
     }
 }
 
+// out[seg][c] (+)= sum_k partial[seg*S + k][c].  A block owns one segment and 32 channels; its 8 thread groups each add
+// every 8th partial row (independent loads in flight), LDS folds the 8 sums in a fixed order.  (One thread per output
+// walking all S rows serially took 13 us for a few KB.)
 template <typename T>
-__global__ void window_finalize_kernel(const float* __restrict__ partial, int S, int64_t nseg, int C, T* __restrict__ out,
-                                       int64_t old_, int accumulate) {
-    const int64_t total = nseg * C;
-    GRID_STRIDE(i, total) {
-        const int c = (int)(i % C);
-        const int64_t seg = i / C;
+__global__ __launch_bounds__(256) void window_finalize_kernel(const float* __restrict__ partial, int S, int64_t nseg, int C,
+                                                              T* __restrict__ out, int64_t old_, int accumulate) {
+    __shared__ float red[8][33];
+    const int cgroups = (C + 31) / 32;
+    const int64_t seg = blockIdx.x / cgroups;
+    const int c = (blockIdx.x % cgroups) * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+    float v0 = 0.f, v1 = 0.f;
+    if (c < C) {
+        const float* src = partial + seg * S * C + c;
+        int k = ty;
+        for (; k + 8 < S; k += 16) { v0 += src[(int64_t)k * C]; v1 += src[(int64_t)(k + 8) * C]; }
+        if (k < S) v0 += src[(int64_t)k * C];
+    }
+    red[ty][threadIdx.x & 31] = v0 + v1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
         float v = 0.f;
-        for (int k = 0; k < S; ++k) v += partial[(seg * S + k) * C + c];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v += red[t][threadIdx.x];
         T* o = out + seg * old_ + c;
         if (accumulate) v += to_f32<T>(*o);
         *o = from_f32<T>(v);
@@ -509,23 +599,57 @@ extern "C" int dsn_focus_s2d(const float* x, int32_t n, int32_t c, int32_t h, in
     return DSN_OK;
 }
 
-extern "C" int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream) {
-    DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(y) && same_nhwc(x, y) && k >= 1 && (k & 1), "maxpool_s1: invalid arguments");
-    DSN_CHECK_ARG((int64_t)x->h * x->w < (1ll << 31), "maxpool_s1: map too large");
-    const int64_t total = npix(x) * x->c;
-    DSN_DISPATCH_DTYPE(x->dtype, T,
-                       hipLaunchKernelGGL(maxpool_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                                          (const T*)x->ptr, x->ldc, (T*)y->ptr, y->ldc, idx, x->n, x->h, x->w, x->c, k));
-    DSN_LAUNCH_CHECK("maxpool_s1");
-    return DSN_OK;
-}
-
 namespace {
 inline bool vec16(const dsn_tensor* t) {
     const int vw = t->dtype == DSN_F32 ? 4 : 8;
     return t->c % vw == 0 && t->ldc % vw == 0 && ((uintptr_t)t->ptr % 16) == 0;
 }
 }  // namespace
+
+extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, void* const* idxs, const int32_t* ks,
+                                    int32_t n_out, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && ys && ks && n_out >= 1 && n_out <= 3, "maxpool_s1_multi: invalid arguments");
+    DSN_CHECK_ARG((int64_t)x->h * x->w < (1ll << 31), "maxpool_s1_multi: map too large");
+    bool vec = vec16(x);
+    for (int i = 0; i < n_out; ++i) {
+        DSN_CHECK_ARG(tensor_ok(&ys[i]) && same_nhwc(x, &ys[i]) && ks[i] >= 1 && (ks[i] & 1),
+                      "maxpool_s1_multi: output %d does not match x", i);
+        vec = vec && vec16(&ys[i]) && (!idxs || !idxs[i] || (uintptr_t)idxs[i] % 16 == 0);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = x->h * x->w;
+    const int V = x->dtype == DSN_F32 ? 4 : 8;
+    const size_t lds = (size_t)HW * V * 3 * sizeof(float);
+    if (vec && lds <= 60 * 1024) {
+        MaxFwd out{};
+        out.n = n_out;
+        for (int i = 0; i < n_out; ++i) {
+            out.y[i] = ys[i].ptr; out.ld[i] = ys[i].ldc; out.idx[i] = idxs ? (int32_t*)idxs[i] : nullptr; out.k[i] = ks[i];
+        }
+        const dim3 grid(x->n * (x->c / V));
+        if (x->dtype == DSN_F32)
+            hipLaunchKernelGGL((maxpool_multi_kernel<float, 4>), grid, dim3(256), lds, st, (const float*)x->ptr, x->ldc, out,
+                               x->h, x->w, x->c);
+        else
+            hipLaunchKernelGGL((maxpool_multi_kernel<bf16_t, 8>), grid, dim3(256), lds, st, (const bf16_t*)x->ptr, x->ldc, out,
+                               x->h, x->w, x->c);
+    } else {
+        const int64_t total = npix(x) * x->c;
+        for (int i = 0; i < n_out; ++i)
+            DSN_DISPATCH_DTYPE(x->dtype, T,
+                               hipLaunchKernelGGL(maxpool_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x->ptr,
+                                                  x->ldc, (T*)ys[i].ptr, ys[i].ldc, idxs ? (int32_t*)idxs[i] : nullptr, x->n,
+                                                  x->h, x->w, x->c, ks[i]));
+    }
+    DSN_LAUNCH_CHECK("maxpool_s1");
+    return DSN_OK;
+}
+
+extern "C" int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream) {
+    DSN_CHECK_ARG(y, "maxpool_s1: invalid arguments");
+    void* idxs[1] = {idx};
+    return dsn_maxpool_s1_multi(x, y, idxs, &k, 1, stream);
+}
 
 extern "C" int dsn_maxpool_s1_bwd_multi(const dsn_tensor* dys, const void* const* idxs, const int32_t* ks, int32_t n_src,
                                         const dsn_tensor* dx, int32_t accumulate, void* stream) {
@@ -634,7 +758,7 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
         DSN_DISPATCH_DTYPE(dx->dtype, T, {
             hipLaunchKernelGGL((window_reduce_kernel<T, WR_BILINEAR_BWD>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
                                (const T*)dy->ptr, (const T*)nullptr, (float*)workspace, g);
-            hipLaunchKernelGGL(window_finalize_kernel<T>, dim3(ew_grid(nseg * dx->c)), dim3(256), 0, st,
+            hipLaunchKernelGGL(window_finalize_kernel<T>, dim3((unsigned)(nseg * ((dx->c + 31) / 32))), dim3(256), 0, st,
                                (const float*)workspace, g.S, nseg, dx->c, (T*)dx->ptr, dx->ldc, accumulate);
         });
         DSN_LAUNCH_CHECK("bilinear_ac_bwd (split)");
@@ -669,7 +793,7 @@ extern "C" int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, vo
     DSN_DISPATCH_DTYPE(x->dtype, T, {
         hipLaunchKernelGGL((window_reduce_kernel<T, WR_AVGPOOL>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
                            (const T*)x->ptr, (const T*)nullptr, (float*)workspace, g);
-        hipLaunchKernelGGL(window_finalize_kernel<T>, dim3(ew_grid(nseg * x->c)), dim3(256), 0, st,
+        hipLaunchKernelGGL(window_finalize_kernel<T>, dim3((unsigned)(nseg * ((x->c + 31) / 32))), dim3(256), 0, st,
                            (const float*)workspace, g.S, nseg, x->c, (T*)y->ptr, y->ldc, 0);
     });
     DSN_LAUNCH_CHECK("adaptive_avgpool");
@@ -745,7 +869,7 @@ extern "C" int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat,
     DSN_DISPATCH_DTYPE(feat->dtype, T, {
         hipLaunchKernelGGL((window_reduce_kernel<T, WR_FFM_ATT>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
                            (const T*)dout->ptr, (const T*)feat->ptr, (float*)workspace, g);
-        hipLaunchKernelGGL(window_finalize_kernel<T>, dim3(ew_grid(nseg * feat->c)), dim3(256), 0, st,
+        hipLaunchKernelGGL(window_finalize_kernel<T>, dim3((unsigned)(nseg * ((feat->c + 31) / 32))), dim3(256), 0, st,
                            (const float*)workspace, g.S, nseg, feat->c, (T*)datt->ptr, datt->ldc, 0);
         hipLaunchKernelGGL(ffm_scale_bwd_feat_kernel<T>, dim3(ew_grid(P * feat->c)), dim3(256), 0, st,
                            (const T*)dout->ptr, dout->ldc, (const T*)att->ptr, att->ldc, (T*)dfeat->ptr, dfeat->ldc, HW,

@@ -455,6 +455,18 @@ def maxpool_s1_bwd(dy, idx, dx, k, accumulate=False):
     return dx
 
 
+def maxpool_s1_multi(x, ys, ks, idxs=None):
+    """Stride-1 max pools of one input at several window sizes in one launch (SPP).  idxs: list of int32 tensors or None."""
+    n = len(ys)
+    a = desc(x)
+    arr = (dsn_tensor * n)(*[desc(t) for t in ys])
+    kk = (C.c_int32 * n)(*[int(k) for k in ks])
+    ip = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in (idxs or [None] * n)])
+    _lib.check(_lib.lib().dsn_maxpool_s1_multi(C.byref(a), C.cast(arr, C.c_void_p), C.cast(ip, C.c_void_p),
+                                               C.cast(kk, C.c_void_p), n, stream_ptr()), "maxpool_s1_multi")
+    return ys
+
+
 def maxpool_s1_bwd_multi(dys, idxs, ks, dx, accumulate=False):
     """dx (+)= sum_i maxpool_s1_bwd(dys[i], idxs[i], ks[i]) in one pass (SPP: three pools of one input)."""
     n = len(dys)

@@ -173,6 +173,10 @@ int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const ds
 int dsn_focus_s2d(const float* x_nchw, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
                   void* stream);
 int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream);
+/* the same pool at n_out <= 3 window sizes ks[i] of ONE input (SPP: 5, 9, 13) in one launch; ys: contiguous descriptors,
+ * idxs (array of int32 pointers, or NULL / NULL entries in eval) */
+int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, void* const* idxs, const int32_t* ks, int32_t n_out,
+                         void* stream);
 int dsn_maxpool_s1_bwd(const dsn_tensor* dy, const int32_t* idx, const dsn_tensor* dx, int32_t k,
                        int32_t accumulate, void* stream);
 /* dx (+)= sum_i maxpool_s1_bwd(dys[i], idxs[i], ks[i]), i < n_src <= 3: the three SPP pools (common.py:177-185) in ONE pass
