@@ -78,16 +78,16 @@ __global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict_
                                                             int C) {
     extern __shared__ float smp[];
     const int HW = H * W;
-    float* sx = smp;                                   // [HW][V] input
-    float* hv = smp + (size_t)HW * V;                  // [HW][V] horizontal max
-    int* hc = reinterpret_cast<int*>(hv + (size_t)HW * V);   // [HW][V] its column
+    float* sx = smp;                                   // [V][HW] input planes (lane = pixel: conflict-free LDS)
+    float* hv = smp + (size_t)HW * V;                  // [V][HW] horizontal max
+    int* hc = reinterpret_cast<int*>(hv + (size_t)HW * V);   // [V][HW] its column
     const int ncv = C / V;
     const int n = blockIdx.x / ncv, cv = blockIdx.x % ncv;
     for (int p = threadIdx.x; p < HW; p += 256) {
         float v[V];
         VecIO<T, V>::load(x + ((int64_t)n * HW + p) * xld + cv * V, v);
 #pragma unroll
-        for (int k = 0; k < V; ++k) sx[p * V + k] = v[k];
+        for (int k = 0; k < V; ++k) sx[k * HW + p] = v[k];
     }
     __syncthreads();
     for (int b = 0; b < out.n; ++b) {
@@ -100,11 +100,11 @@ __global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict_
                 float best = -INFINITY;
                 int bc = -1;
                 for (int col = w0; col <= w1; ++col) {
-                    const float val = sx[(row * W + col) * V + k];
+                    const float val = sx[k * HW + row * W + col];
                     if (val > best || bc < 0 || val != val) { best = val; bc = col; }
                 }
-                hv[p * V + k] = best;
-                hc[p * V + k] = bc;
+                hv[k * HW + p] = best;
+                hc[k * HW + p] = bc;
             }
         }
         __syncthreads();
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict_
                 float best = -INFINITY;
                 int bi = -1;
                 for (int row = h0; row <= h1; ++row) {
-                    const float val = hv[(row * W + w) * V + k];
-                    if (val > best || bi < 0 || val != val) { best = val; bi = row * W + hc[(row * W + w) * V + k]; }
+                    const float val = hv[k * HW + row * W + w];
+                    if (val > best || bi < 0 || val != val) { best = val; bi = row * W + hc[k * HW + row * W + w]; }
                 }
                 res[k] = best;
                 q[k] = bi;
@@ -399,7 +399,7 @@ struct MaxSrcs {
 template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool_bwd_scatter_kernel(const MaxSrcs srcs, T* __restrict__ dx, int64_t xld, int HW,
                                                                   int C, int accumulate) {
-    extern __shared__ float sacc[];          // [HW][V]
+    extern __shared__ float sacc[];          // [V][HW] planes
     const int ncv = C / V;
     const int n = blockIdx.x / ncv, cv = blockIdx.x % ncv;
     for (int i = threadIdx.x; i < HW * V; i += 256) sacc[i] = 0.f;
@@ -419,14 +419,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_scatter_kernel(const MaxSrcs 
             }
 #pragma unroll
             for (int k = 0; k < V; ++k)
-                __hip_atomic_fetch_add(&sacc[q[k] * V + k], g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sacc[k * HW + q[k]], g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
     for (int p = threadIdx.x; p < HW; p += 256) {
         float s[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) s[k] = sacc[p * V + k];
+        for (int k = 0; k < V; ++k) s[k] = sacc[k * HW + p];
         T* o = dx + ((int64_t)n * HW + p) * xld + cv * V;
         if (accumulate) {
             float old[V];
