@@ -135,6 +135,84 @@ def test_wgrad_large_reduction_and_padding(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_queue_matches_single_layer(ops, dtype):
+    """dsn_conv2d_wgrad_plan / _plan_finish / _run: several layers' weight gradients in three grouped launches give the same
+    numbers as one dsn_conv2d_wgrad per layer -- per-tap and (bf16, >= 32k pixels) all-taps blocks, split-K slabs and direct
+    writes, accumulation into an existing gradient, and a layer the queue must refuse (odd channel count)."""
+    layers = [  # n, ci, h, w, co, k, s
+        (2, 16, 24, 24, 32, 3, 1), (8, 32, 72, 72, 32, 3, 1), (2, 64, 20, 20, 128, 1, 1), (1, 256, 8, 8, 256, 3, 1),
+        (2, 32, 40, 40, 64, 3, 2), (2, 64, 10, 10, 33, 1, 1),
+    ]
+    queue = ops.WgradQueue(torch.device("cuda", torch.cuda.current_device()))
+    pending = []
+    for i, (n, ci, h, w, co, k, s) in enumerate(layers):
+        pad = k // 2
+        ho, wo = ops.conv_out_hw(h, w, k, s, pad, 1)
+        x, gy = to_dev(ops, rnd((n, ci, h, w), 100 + i), dtype), to_dev(ops, rnd((n, co, ho, wo), 200 + i), dtype)
+        base = rnd((co, ci, k, k), 300 + i).cuda()
+        p = ops.conv_params(k, s, pad, 1, accumulate=True)
+        ref = base.clone()
+        ops.conv2d_wgrad(x, gy, ref, ci, p, oihw=True)
+        got = base.clone()
+        ops.conv2d_wgrad(x, gy, got, ci, p, oihw=True, queue=queue)
+        pending.append((got, ref, (n, ci, h, w, co, k, s)))
+    assert queue.n == len(layers) - 1, "the 33-channel layer must take the single-layer path"
+    queue.flush()
+    torch.cuda.synchronize()
+    for got, ref, shape in pending:
+        assert_close(got.cpu(), ref.cpu(), 1e-5 if dtype == torch.float32 else 1e-4, f"queued wgrad {shape}")
+    assert queue.n == 0 and not queue.keep
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 9, 7, 24), (4, 64, 20, 20, 64), (8, 16, 64, 64, 32)])
+def test_conv_bn_act_fused_statistics(ops, shape, dtype):
+    """dsn_conv2d_fwd_bnacc + dsn_bn_act_fwd_acc (statistics out of the conv epilogue, folded in the prologue of the BN + act
+    kernel) against conv -> BatchNorm2d(train) -> SiLU from ATen; accumulator slots come from the per-step arena."""
+    n, ci, h, w, co = shape
+    x, wt = rnd((n, ci, h, w), 30), rnd((co, ci, 3, 3), 31, -0.2, 0.2)
+    gamma, beta = rnd((co,), 32, 0.5, 1.5), rnd((co,), 33, -0.1, 0.1)
+    rm, rv = rnd((co,), 34, -0.1, 0.1), rnd((co,), 35, 0.5, 1.5)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.conv2d(q(x, dtype), q(wt, dtype), None, 1, 1)
+    z_ref = F.silu(F.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, True, 0.03, 1e-3))
+    ops.bn_arena_begin("cuda")
+    xd = to_dev(ops, x, dtype)
+    y, z = ops.new_act(n, co, h, w, dtype, "cuda"), ops.new_act(n, co, h, w, dtype, "cuda")
+    rmd, rvd = rm.cuda(), rv.cuda()
+    for _ in range(2):      # twice: consecutive slots of the arena, running statistics advance twice
+        scale, shift, mean, rstd = ops.conv2d_fwd_bnstats(xd, ops.pack_weight_fwd(wt.cuda(), dtype), y, ops.conv_params(3),
+                                                          gamma.cuda(), beta.cuda(), rmd, rvd, 0.03, 1e-3, ops.ACT_SILU,
+                                                          None, z)
+    F.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, True, 0.03, 1e-3)
+    assert_close(z.float().cpu(), z_ref, TOL[dtype], "conv+bn+silu")
+    assert_close(mean.cpu(), y_ref.mean((0, 2, 3)), 1e-3 if dtype == torch.float32 else 5e-3, "batch mean")
+    assert_close(rmd.cpu(), rm_ref, 1e-3 if dtype == torch.float32 else 5e-3, "running_mean after two steps")
+    assert_close(rvd.cpu(), rv_ref, 1e-3 if dtype == torch.float32 else 5e-3, "running_var after two steps")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool_multi_and_backward(ops, dtype):
+    """SPP's three pools in one launch (separable LDS kernel) and their gradients in one scatter pass, vs ATen."""
+    n, c, h, w = 2, 32, 20, 20
+    x = rnd((n, c, h, w), 40)
+    xq = q(x, dtype).requires_grad_(True)
+    ks = [5, 9, 13]
+    refs = [F.max_pool2d(xq, k, 1, k // 2) for k in ks]
+    gys = [rnd((n, c, h, w), 41 + i) for i in range(3)]
+    sum(((r * q(g, dtype)).sum() for r, g in zip(refs, gys))).backward()
+    xd = to_dev(ops, x, dtype)
+    ys = [ops.new_act(n, c, h, w, dtype, "cuda") for _ in ks]
+    idxs = [torch.empty((n, h, w, c), dtype=torch.int32, device="cuda") for _ in ks]
+    ops.maxpool_s1_multi(xd, ys, ks, idxs)
+    for y, r, k in zip(ys, refs, ks):
+        assert torch.equal(y.float().cpu(), r.detach()), f"maxpool k={k}"
+    dx = ops.new_act(n, c, h, w, dtype, "cuda")
+    ops.maxpool_s1_bwd_multi([to_dev(ops, g, dtype) for g in gys], idxs, ks, dx)
+    assert_close(dx.float().cpu(), xq.grad, TOL[dtype], "maxpool multi bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pack_weights(ops, dtype):
     wt, sc = rnd((24, 12, 3, 3), 12), rnd((24,), 13, 0.5, 1.5)
     wp = ops.pack_weight_fwd(wt.cuda(), dtype, sc.cuda(), ci_pad=16)
