@@ -20,6 +20,7 @@ struct WGeom {
     int32_t accumulate;
     int32_t CiLoad;       // channels x actually holds (>= Ci: zero-padded tail may be loaded, never stored)
     int32_t oihw;         // final output layout: 0 = packed [Co][tap][Cip], 1 = OIHW [Co][Ci][tap]
+    uint32_t x_bytes, dy_bytes;   // buffer-descriptor ranges of the vector-load paths (both tensors < 2 GiB there)
 };
 
 constexpr int TB = 64;    // tile edge (co and ci)
@@ -68,40 +69,83 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
     const int sv = tid & 7;         // first vector of the row
     u32x4 ra[RG][NV], rb[RG][NV];
 
-    auto load_vec = [&](const T* p, int c, int climit) -> u32x4 {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (VECLOAD) {
-            if (c < climit) v = *reinterpret_cast<const u32x4*>(p);
-        } else {
-            T tmp[VEC];
+    // Vector path: raw buffer loads with 32-bit byte offsets (masked lanes get an out-of-range offset and read 0) and a
+    // pixel cursor (p, ox, oy, n) per staged row that ADVANCES by PK per chunk instead of being re-derived with two integer
+    // divisions -- this kernel was VALU-bound on address arithmetic (SQ_INSTS_VALU: ~140 per chunk per wave for 4 MFMAs).
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    constexpr int ES = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, VECLOAD ? g.x_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, VECLOAD ? g.dy_bytes : 0, 0x00020000);
+    // (32-bit integer multiplies are quarter-rate: the offsets below ADVANCE by a constant per chunk.  For the same-size
+    // stride-1 convs -- all but six layers -- the input pixel of tap (ky,kx) is output pixel + a constant, so the x offset
+    // advances the same way and only the validity mask needs the cursor.)
+    const bool lin = g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo;
+    int cp[RG], cox[RG], coy[RG], cn[RG];
+    uint32_t aoff[RG], boff[RG];
+    const int tap_dy = ky * g.dil - g.pad, tap_dx = kx * g.dil - g.pad;
+    const uint32_t astep = (uint32_t)(PK * (int)g.yld) * ES, bstep = (uint32_t)(PK * (int)g.xld) * ES;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < climit) ? p[e] : from_f32<T>(0.f);
-            v = *reinterpret_cast<u32x4*>(tmp);
-        }
-        return v;
+    for (int rg = 0; rg < RG; ++rg) {
+        cp[rg] = p_begin + srow + 32 * rg;
+        const int pc = cp[rg] < g.P ? cp[rg] : g.P - 1;
+        cox[rg] = pc % g.Wo;
+        const int t = pc / g.Wo;
+        coy[rg] = t % g.Ho;
+        cn[rg] = t / g.Ho;
+        aoff[rg] = (uint32_t)(cp[rg] * (int)g.yld + co0) * ES;
+        boff[rg] = (uint32_t)((cp[rg] + tap_dy * g.Wi + tap_dx) * (int)g.xld + ci0) * ES;     // used when lin
+    }
+    auto load_vec = [&](const T* p, int c, int climit) -> u32x4 {
+        T tmp[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) tmp[e] = (c + e < climit) ? p[e] : from_f32<T>(0.f);
+        return *reinterpret_cast<u32x4*>(tmp);
     };
-    auto load_chunk = [&](int ch) {
+    auto load_chunk = [&](int ch) {      // called with ch = 0, 1, 2, ... in order (the cursor advances)
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) {
-            const int p = p_begin + ch * PK + srow + 32 * rg;
-            const bool pok = p < p_end;
-            int ox = 0, oy = 0, n = 0;
-            if (pok) {
-                ox = p % g.Wo;
-                const int t = p / g.Wo;
-                oy = t % g.Ho;
-                n = t / g.Ho;
-            }
-            const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
-            const bool xok = pok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            if constexpr (VECLOAD) {
+                const int p = cp[rg];
+                const bool pok = p < p_end;
+                const int iy = coy[rg] * g.stride + tap_dy, ix = cox[rg] * g.stride + tap_dx;
+                const bool xok = pok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                const uint32_t abase = aoff[rg];
+                const uint32_t bbase = lin ? boff[rg] : (uint32_t)(((cn[rg] * g.Hi + iy) * g.Wi + ix) * (int)g.xld + ci0) * ES;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int vc = (sv + 8 * i) * VEC;
-                ra[rg][i] = u32x4{0u, 0u, 0u, 0u};
-                rb[rg][i] = u32x4{0u, 0u, 0u, 0u};
-                if (pok) ra[rg][i] = load_vec(dy + (int64_t)p * g.yld + co0 + vc, co0 + vc, g.Co);
-                if (xok)
-                    rb[rg][i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.CiLoad);
+                for (int i = 0; i < NV; ++i) {
+                    const int vc = (sv + 8 * i) * VEC;
+                    ra[rg][i] = __builtin_amdgcn_raw_buffer_load_b128(yr, (pok && co0 + vc < g.Co) ? abase + vc * ES : OOB, 0, 0);
+                    rb[rg][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (xok && ci0 + vc < g.CiLoad) ? bbase + vc * ES : OOB, 0, 0);
+                }
+                aoff[rg] += astep;
+                boff[rg] += bstep;
+                cp[rg] = p + PK;
+                cox[rg] += PK;
+                while (cox[rg] >= g.Wo) {
+                    cox[rg] -= g.Wo;
+                    if (++coy[rg] >= g.Ho) { coy[rg] = 0; ++cn[rg]; }
+                }
+            } else {
+                const int p = p_begin + ch * PK + srow + 32 * rg;
+                const bool pok = p < p_end;
+                int ox = 0, oy = 0, n = 0;
+                if (pok) {
+                    ox = p % g.Wo;
+                    const int t = p / g.Wo;
+                    oy = t % g.Ho;
+                    n = t / g.Ho;
+                }
+                const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
+                const bool xok = pok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int vc = (sv + 8 * i) * VEC;
+                    ra[rg][i] = u32x4{0u, 0u, 0u, 0u};
+                    rb[rg][i] = u32x4{0u, 0u, 0u, 0u};
+                    if (pok) ra[rg][i] = load_vec(dy + (int64_t)p * g.yld + co0 + vc, co0 + vc, g.Co);
+                    if (xok)
+                        rb[rg][i] = load_vec(x + (((int64_t)n * g.Hi + iy) * g.Wi + ix) * g.xld + ci0 + vc, ci0 + vc, g.CiLoad);
+                }
             }
         }
     };
@@ -214,8 +258,7 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
 // same cache lines, 10 16-byte loads are in flight per thread, and every barrier is followed by 36 MFMAs per wave.
 template <int NT>
 __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                   float* __restrict__ out, const WGeom& g, uint32_t x_bytes,
-                                                   uint32_t dy_bytes, int bid) {
+                                                   float* __restrict__ out, const WGeom& g, int bid) {
     constexpr int PKA = 32, ROW = TB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);                    // [2][PKA*ROW]
@@ -231,35 +274,52 @@ __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x,
     const int p_begin = split * g.ppb;
     const int p_end = (p_begin + g.ppb < g.P) ? p_begin + g.ppb : g.P;
     const int nchunks = (p_end - p_begin + PKA - 1) / PKA;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.dy_bytes, 0x00020000);
     constexpr uint32_t OOB = 0xFFFFFFF0u;
 
     const int srow = tid >> 3, sv = tid & 7;     // staged pixel row, 16-byte vector (8 channels) of the row
     const int vc = sv * 8;
     u32x4 ra, rb[NT];
 
-    auto load_chunk = [&](int ch) {
-        const int p = p_begin + ch * PKA + srow;
-        const bool pok = p < p_end;
-        int ox = 0, oy = 0, n = 0;
-        if (pok) {
-            ox = p % g.Wo;
-            const int t = p / g.Wo;
-            oy = t % g.Ho;
-            n = t / g.Ho;
-        }
-        const uint32_t aoff = (pok && co0 + vc < g.Co) ? (uint32_t)(p * (int)g.yld + co0 + vc) * 2u : OOB;
-        ra = __builtin_amdgcn_raw_buffer_load_b128(yr, aoff, 0, 0);
-        const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
-        const int nb = n * g.Hi;
+    // pixel cursor + offsets that advance by a constant per chunk (no integer divisions or multiplies in the loop; see the
+    // per-tap kernel).  Same-size stride-1 convs: input pixel of tap (ky,kx) = output pixel + (ky*dil-pad)*Wi + (kx*dil-pad).
+    const bool lin = g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo;
+    int cp = p_begin + srow, cox, coy, cn;
+    {
+        const int pc = cp < g.P ? cp : g.P - 1;
+        cox = pc % g.Wo;
+        const int t = pc / g.Wo;
+        coy = t % g.Ho;
+        cn = t / g.Ho;
+    }
+    uint32_t aoff = (uint32_t)(cp * (int)g.yld + co0 + vc) * 2u;
+    uint32_t boff = (uint32_t)((cp - g.pad * g.Wi - g.pad) * (int)g.xld + ci0 + vc) * 2u;     // tap (0,0), lin only
+    const uint32_t astep = (uint32_t)(PKA * (int)g.yld) * 2u, bstep = (uint32_t)(PKA * (int)g.xld) * 2u;
+    const uint32_t brow = (uint32_t)(g.dil * g.Wi * (int)g.xld) * 2u, bcol = (uint32_t)(g.dil * (int)g.xld) * 2u;
+    const bool aok = co0 + vc < g.Co, bok = ci0 + vc < g.CiLoad;
+
+    auto load_chunk = [&](int) {           // called for chunk 0, 1, 2, ... in order
+        const bool pok = cp < p_end;
+        ra = __builtin_amdgcn_raw_buffer_load_b128(yr, (pok && aok) ? aoff : OOB, 0, 0);
+        const int iy0 = coy * g.stride - g.pad, ix0 = cox * g.stride - g.pad;
+        const int nb = cn * g.Hi;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int ky = t / 3, kx = t - ky * 3;        // NT == KH*KW with KW == 3 (checked on the host)
             const int iy = iy0 + ky * g.dil, ix = ix0 + kx * g.dil;
-            const bool ok = pok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi && ci0 + vc < g.CiLoad;
-            const uint32_t boff = ok ? (uint32_t)(((nb + iy) * g.Wi + ix) * (int)g.xld + ci0 + vc) * 2u : OOB;
-            rb[t] = __builtin_amdgcn_raw_buffer_load_b128(xr, boff, 0, 0);
+            const bool ok = pok && bok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const uint32_t o = lin ? boff + (uint32_t)ky * brow + (uint32_t)kx * bcol
+                                   : (uint32_t)(((nb + iy) * g.Wi + ix) * (int)g.xld + ci0 + vc) * 2u;
+            rb[t] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? o : OOB, 0, 0);
+        }
+        cp += PKA;
+        aoff += astep;
+        boff += bstep;
+        cox += PKA;
+        while (cox >= g.Wo) {
+            cox -= g.Wo;
+            if (++coy >= g.Ho) { coy = 0; ++cn; }
         }
     };
     auto store_chunk = [&](int buf) {
@@ -412,9 +472,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
 }
 template <int NT>
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                 float* __restrict__ out, const WGeom g, uint32_t x_bytes,
-                                                                 uint32_t dy_bytes) {
-    wgrad_alltaps_body<NT>(x, dy, out, g, x_bytes, dy_bytes, blockIdx.x);
+                                                                 float* __restrict__ out, const WGeom g) {
+    wgrad_alltaps_body<NT>(x, dy, out, g, blockIdx.x);
 }
 
 // ---- grouped kernels: the weight gradients of ALL layers of a backward pass in three launches ---------------------------------
@@ -429,7 +488,6 @@ struct WJob {
     float* out;            // slabs (S > 1) or dw
     float* dw;
     WGeom g;
-    uint32_t x_bytes, dy_bytes;
     int32_t kind;          // 0: per-tap blocks, 1: all-taps blocks
     int32_t dtype;
     int32_t blocks[3];     // blocks of this job in the per-tap / all-taps / reduce launch
@@ -454,8 +512,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WJob* __restri
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     const int l = find_job(jobs, n, blockIdx.x, 1);
     const WGeom g = jobs[l].g;
-    wgrad_alltaps_body<9>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, jobs[l].x_bytes,
-                          jobs[l].dy_bytes, blockIdx.x - jobs[l].start[1]);
+    wgrad_alltaps_body<9>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, blockIdx.x - jobs[l].start[1]);
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     __shared__ float part[16][65];
@@ -547,12 +604,13 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
         out = (float*)workspace;
     }
     const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
+    const int64_t xb = ((npix(x) - 1) * x->ldc + x->c) * es, yb = ((npix(dy) - 1) * dy->ldc + dy->c) * es;
     *vec_out = (g.Co % vec == 0) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
-               ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
+               ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0) && xb < (1ll << 31) && yb < (1ll << 31);
+    g.x_bytes = (uint32_t)(xb < (1ll << 31) ? xb : 0);
+    g.dy_bytes = (uint32_t)(yb < (1ll << 31) ? yb : 0);
     *job = WJob{};
     job->x = x->ptr; job->dy = dy->ptr; job->out = out; job->dw = dw; job->g = g;
-    job->x_bytes = (uint32_t)(((npix(x) - 1) * x->ldc + x->c) * es);      // only read by the all-taps kernel (use_alltaps
-    job->dy_bytes = (uint32_t)(((npix(dy) - 1) * dy->ldc + dy->c) * es);  // checked the sizes fit 32 bits)
     job->kind = alltaps ? 1 : 0;
     job->dtype = x->dtype;
     job->blocks[job->kind] = g.tiles_ci * g.tiles_co * (alltaps ? 1 : g.KH * g.KW) * g.S;
@@ -599,7 +657,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
         if (job.kind == 1) {
             alltaps_attr_once();
             hipLaunchKernelGGL(wgrad_alltaps_bf16_kernel<9>, grid, block, ALLTAPS_LDS, st, (const bf16_t*)x->ptr,
-                               (const bf16_t*)dy->ptr, out, g, job.x_bytes, job.dy_bytes);
+                               (const bf16_t*)dy->ptr, out, g);
         } else if (x->dtype == DSN_F32) {
             if (vl)
                 hipLaunchKernelGGL((wgrad_kernel<float, true, 32>), grid, block, 0, st, (const float*)x->ptr, (const float*)dy->ptr, out, g);
