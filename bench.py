@@ -195,7 +195,8 @@ def main():
         model.hyp = scale_hyp(6, a.img)
         broadcast_parameters(model)
         flat = FlatGradients(model.parameters())
-        opt = torch.optim.SGD(sgd_param_groups(model), lr=0.01, momentum=0.937, nesterov=True)
+        from desenet_amd.optim import FusedSGD
+        opt = FusedSGD(sgd_param_groups(model), lr=0.01, momentum=0.937, nesterov=True)     # torch.optim.SGD math, one launch
         compute_loss, compute_seg_loss = ComputeLoss(model), SegmentationLosses()
         x = synth_images(batch, a.img, 3 + rank).to(dev)
         det_t, seg_t = synth_targets(batch, a.img, 3 + rank)

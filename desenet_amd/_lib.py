@@ -21,6 +21,11 @@ class dsn_conv_params(C.Structure):
                 ("act", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class dsn_sgd_desc(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("numel", C.c_int64),
+                ("group", C.c_int32), ("first_chunk", C.c_int32)]
+
+
 class dsn_pack_desc(C.Structure):
     _fields_ = [("w_oihw", C.c_void_p), ("out_fwd", C.c_void_p), ("out_dgrad", C.c_void_p), ("co", C.c_int32),
                 ("ci", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("ci_pad", C.c_int32), ("reserved", C.c_int32)]
@@ -49,7 +54,9 @@ PROTOTYPES = {
     "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
     "dsn_pack_weight_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
-    "dsn_pack_chunk": (i32, []),
+    "dsn_sgd_chunk": (i32, []),
+    "dsn_sgd_step": (i32, [vp, i32, i32, vp, vp]),
+    "dsn_pack_tiles": (i32, [i32, i32, i32, i32]),
     "dsn_pack_weights_multi": (i32, [vp, vp, i32, i32, vp]),
     "dsn_unpack_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_bn_workspace_bytes": (i64, [i32]),

@@ -151,29 +151,94 @@ __global__ void copy_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t 
 }
 
 // ---- multi-tensor weight pack: ONE launch packs every conv weight of the model (forward + dgrad layouts) -------------------
-// work[b] = {tensor id, first element}; each block converts up to PACK_CHUNK elements of one tensor.
-constexpr int PACK_CHUNK = 2048;
+// work[b] = {tensor id, tile index}.  OIHW is a [co][J] matrix with J = ci*taps contiguous; a block moves one 32(o) x 64(j)
+// tile through LDS: coalesced 256-byte fp32 row reads, the dgrad layout [j][o] (= [ci][tap][co]) leaves as 64-byte segments
+// and the forward layout [o][tap][ci_pad] as contiguous channels for 1x1 convs (stride ci_pad for 3x3).  The previous
+// element-per-thread version gathered with stride `taps` and scattered 2-byte dgrad writes: 110 us for 29 MB.
+constexpr int PACK_TO = 32, PACK_TJ = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const dsn_pack_desc* __restrict__ descs,
                                                          const int2* __restrict__ work) {
+    __shared__ float tile[PACK_TO][PACK_TJ + 1];
     const int2 wk = work[blockIdx.x];
     const dsn_pack_desc d = descs[wk.x];
     const float* __restrict__ w = (const float*)d.w_oihw;
     T* __restrict__ of = (T*)d.out_fwd;
     T* __restrict__ od = (T*)d.out_dgrad;
     const int taps = d.kh * d.kw;
-    const int64_t n_fwd = (int64_t)d.co * taps * d.ci_pad;
-    const int64_t end = (wk.y + PACK_CHUNK < n_fwd) ? wk.y + PACK_CHUNK : n_fwd;
-    for (int64_t i = wk.y + threadIdx.x; i < end; i += 256) {
-        // i indexes the forward layout [co][tap][ci_pad]
-        const int c = (int)(i % d.ci_pad);
-        const int64_t t = i / d.ci_pad;
-        const int tap = (int)(t % taps);
-        const int o = (int)(t / taps);
-        float v = 0.f;
-        if (c < d.ci) v = w[((int64_t)o * d.ci + c) * taps + tap];
-        if (of) of[i] = from_f32<T>(v);
-        if (od && c < d.ci) od[((int64_t)c * taps + tap) * d.co + o] = from_f32<T>(v);
+    const int J = d.ci * taps;
+    const int tiles_j = (J + PACK_TJ - 1) / PACK_TJ;
+    const int o0 = (wk.y / tiles_j) * PACK_TO, j0 = (wk.y % tiles_j) * PACK_TJ;
+    for (int idx = threadIdx.x; idx < PACK_TO * PACK_TJ; idx += 256) {
+        const int r = idx / PACK_TJ, cj = idx % PACK_TJ;
+        const int o = o0 + r, j = j0 + cj;
+        tile[r][cj] = (o < d.co && j < J) ? w[(int64_t)o * J + j] : 0.f;
+    }
+    __syncthreads();
+    if (of) {
+        for (int idx = threadIdx.x; idx < PACK_TO * PACK_TJ; idx += 256) {
+            const int r = idx / PACK_TJ, cj = idx % PACK_TJ;
+            const int o = o0 + r, j = j0 + cj;
+            if (o < d.co && j < J) {
+                const int c = j / taps, tap = j - c * taps;
+                of[((int64_t)o * taps + tap) * d.ci_pad + c] = from_f32<T>(tile[r][cj]);
+            }
+        }
+    }
+    if (od) {
+        for (int idx = threadIdx.x; idx < PACK_TO * PACK_TJ; idx += 256) {
+            const int cj = idx / PACK_TO, r = idx % PACK_TO;
+            const int o = o0 + r, j = j0 + cj;
+            if (o < d.co && j < J) od[(int64_t)j * d.co + o] = from_f32<T>(tile[r][cj]);
+        }
+    }
+}
+
+// ---- multi-tensor SGD (momentum, Nesterov, weight decay): torch.optim.SGD's update for every parameter in ONE launch -------
+// p, g, buf are fp32.  hyper[group] = {lr, momentum, dampening, weight_decay, nesterov, first_step, 0, 0} lives in DEVICE
+// memory so that a captured graph picks up learning-rate changes (the scheduler writes it between replays).
+//   g' = g + wd*p ; buf = first ? g' : mom*buf + (1-damp)*g' ; step = nesterov ? g' + mom*buf : buf ; p -= lr*step
+constexpr int SGD_CHUNK = 1024;       // elements per block: 256 threads x float4
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const dsn_sgd_desc* __restrict__ descs, int n,
+                                                        const float* __restrict__ hyper) {
+    int lo = 0, hi = n - 1;           // largest tensor whose first chunk is <= blockIdx.x (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_chunk <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const dsn_sgd_desc d = descs[lo];
+    const float* h = hyper + 8 * d.group;
+    const float lr = h[0], mom = h[1], damp = h[2], wd = h[3];
+    const bool nesterov = h[4] != 0.f, first = h[5] != 0.f;
+    const int64_t i0 = ((int64_t)blockIdx.x - d.first_chunk) * SGD_CHUNK + threadIdx.x * 4;
+    float* __restrict__ p = (float*)d.param;
+    const float* __restrict__ g = (const float*)d.grad;
+    float* __restrict__ b = (float*)d.momentum_buf;
+    if (i0 + 4 <= d.numel && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)b) & 15) == 0) {
+        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i0);
+        f32x4 bv = (mom != 0.f && !first) ? *reinterpret_cast<const f32x4*>(b + i0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gg = gv[k] + wd * pv[k];
+            if (mom != 0.f) {
+                bv[k] = first ? gg : mom * bv[k] + (1.f - damp) * gg;
+                gg = nesterov ? gg + mom * bv[k] : bv[k];
+            }
+            pv[k] -= lr * gg;
+        }
+        *reinterpret_cast<f32x4*>(p + i0) = pv;
+        if (mom != 0.f) *reinterpret_cast<f32x4*>(b + i0) = bv;
+    } else {
+        for (int64_t i = i0; i < i0 + 4 && i < d.numel; ++i) {
+            float gg = g[i] + wd * p[i];
+            if (mom != 0.f) {
+                const float nb = first ? gg : mom * b[i] + (1.f - damp) * gg;
+                b[i] = nb;
+                gg = nesterov ? gg + mom * nb : nb;
+            }
+            p[i] -= lr * gg;
+        }
     }
 }
 
@@ -206,7 +271,9 @@ extern "C" int dsn_pack_weight_dgrad(const float* w, void* out, int32_t dtype, i
     return DSN_OK;
 }
 
-extern "C" int32_t dsn_pack_chunk(void) { return PACK_CHUNK; }
+extern "C" int32_t dsn_pack_tiles(int32_t co, int32_t ci, int32_t kh, int32_t kw) {
+    return ((co + PACK_TO - 1) / PACK_TO) * ((ci * kh * kw + PACK_TJ - 1) / PACK_TJ);
+}
 
 extern "C" int dsn_pack_weights_multi(const dsn_pack_desc* descs_dev, const int32_t* work_dev, int32_t n_work,
                                       int32_t dtype, void* stream) {
@@ -215,6 +282,16 @@ extern "C" int dsn_pack_weights_multi(const dsn_pack_desc* descs_dev, const int3
                        hipLaunchKernelGGL(pack_multi_kernel<T>, dim3(n_work), dim3(256), 0, (hipStream_t)stream, descs_dev,
                                           (const int2*)work_dev));
     DSN_LAUNCH_CHECK("pack_weights_multi");
+    return DSN_OK;
+}
+
+extern "C" int32_t dsn_sgd_chunk(void) { return SGD_CHUNK; }
+
+extern "C" int dsn_sgd_step(const dsn_sgd_desc* descs_dev, int32_t n_tensors, int32_t n_chunks, const float* hyper_dev,
+                            void* stream) {
+    DSN_CHECK_ARG(descs_dev && hyper_dev && n_tensors > 0 && n_chunks > 0, "sgd_step: bad args");
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, descs_dev, n_tensors, hyper_dev);
+    DSN_LAUNCH_CHECK("sgd_step");
     return DSN_OK;
 }
 

@@ -9,6 +9,8 @@
 //   bf16 : v_mfma_f32_16x16x32_bf16 takes 8 K-contiguous bf16 -> two ds_read_b64_tr_b16 (hardware transpose) per fragment
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -712,6 +714,9 @@ extern "C" int dsn_conv2d_wgrad_plan(const dsn_tensor* x, const dsn_tensor* dy, 
 extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* launch_out) {
     DSN_CHECK_ARG(jobs_host && n > 0 && launch_out, "conv wgrad plan_finish: bad arguments");
     WJob* jobs = (WJob*)jobs_host;
+    // longest blocks first: a block's life is its pixel range, and the hardware dispatches blocks in index order -- heavy
+    // jobs at the end of the grid would leave a tail of a few long blocks on an otherwise drained chip
+    std::stable_sort(jobs, jobs + n, [](const WJob& a, const WJob& b) { return a.g.ppb > b.g.ppb; });
     int64_t start[3] = {0, 0, 0};
     double flops = 0, bytes = 0, rbytes = 0;
     for (int i = 0; i < n; ++i) {

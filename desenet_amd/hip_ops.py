@@ -264,13 +264,12 @@ class WeightBank:
 
     def __init__(self, convs, ci_pads, dtype, device, need_dgrad=True):
         L = _lib.lib()
-        chunk = L.dsn_pack_chunk()
         es = 2 if dtype == torch.bfloat16 else 4
         self.dtype, self.convs = dtype, list(convs)
         sizes_f = [c.out_channels * c.kernel_size[0] * c.kernel_size[1] * cp for c, cp in zip(self.convs, ci_pads)]
         sizes_d = [c.weight.numel() for c in self.convs]
         al = lambda n: (n + 63) // 64 * 64
-        self.fwd_buf = torch.empty(sum(al(n) for n in sizes_f), dtype=dtype, device=device)
+        self.fwd_buf = torch.zeros(sum(al(n) for n in sizes_f), dtype=dtype, device=device)    # ci_pad lanes stay zero
         self.dg_buf = torch.empty(sum(al(n) for n in sizes_d), dtype=dtype, device=device) if need_dgrad else None
         descs = (_lib.dsn_pack_desc * len(self.convs))()
         work, self.fwd, self.dgrad = [], [], []
@@ -285,7 +284,7 @@ class WeightBank:
             assert w.dtype == torch.float32 and w.is_contiguous()
             descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dv.data_ptr() if need_dgrad else None, co, ci, kh,
                                           kw, cp, 0)
-            work += [(i, s0) for s0 in range(0, sizes_f[i], chunk)]
+            work += [(i, t) for t in range(L.dsn_pack_tiles(co, ci, kh, kw))]
             of += al(sizes_f[i])
             od += al(sizes_d[i])
         raw = bytes(descs)

@@ -1,0 +1,103 @@
+"""SGD with momentum / Nesterov / weight decay as ONE HIP launch per step (`dsn_sgd_step`).
+
+Drop-in for the reference's `optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)` with its three
+parameter groups (scripts/train.py:159-166): same constructor arguments, same `param_groups` / `state_dict` layout
+(`momentum_buffer` per parameter), same update as torch.optim.SGD.  torch's foreach implementation issues ~23 launches per
+step for DeSeNet-s (0.22 ms at batch 8); this one walks every parameter with one kernel driven by a device-side table.
+
+Hyper-parameters live in a small DEVICE tensor the kernel reads, so a captured hipGraph follows `lr` / `momentum` changes
+made by a scheduler: `step()` re-uploads them whenever the Python-side values changed (outside capture), and
+`sync_hyper()` does the same explicitly between graph replays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .hip_ops import stream_ptr
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        if lr < 0.0 or momentum < 0.0 or weight_decay < 0.0:
+            raise ValueError("invalid SGD hyper-parameter")
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                                      nesterov=nesterov))
+        self._table = None
+        self._uploaded = None
+        self._first = True
+
+    # ---- device-side tables ---------------------------------------------------------------------------------------------
+    def _build(self):
+        L = _lib.lib()
+        chunk = L.dsn_sgd_chunk()
+        entries = []
+        dev = None
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() \
+                        or not p.grad.is_contiguous() or not p.is_cuda:
+                    raise TypeError("FusedSGD updates contiguous fp32 CUDA parameters with fp32 gradients")
+                dev = p.device
+                st = self.state[p]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                entries.append((p, p.grad, st["momentum_buffer"], gi))
+        if not entries:
+            return None
+        descs = (_lib.dsn_sgd_desc * len(entries))()
+        first = 0
+        for i, (p, g, b, gi) in enumerate(entries):
+            descs[i] = _lib.dsn_sgd_desc(p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel(), gi, first)
+            first += (p.numel() + chunk - 1) // chunk
+        key = tuple((p.data_ptr(), g.data_ptr(), b.data_ptr()) for p, g, b, _ in entries)
+        return dict(key=key, n=len(entries), chunks=first, entries=entries,
+                    descs=torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev),
+                    hyper=torch.zeros(8 * len(self.param_groups), dtype=torch.float32, device=dev))
+
+    def _hyper_values(self):
+        vals = []
+        for g in self.param_groups:
+            vals += [float(g["lr"]), float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"]),
+                     1.0 if g["nesterov"] else 0.0, 1.0 if self._first else 0.0, 0.0, 0.0]
+        return vals
+
+    def sync_hyper(self):
+        """Upload lr / momentum / ... if they changed (call between graph replays when a scheduler moved them)."""
+        if self._table is None:
+            return
+        vals = self._hyper_values()
+        if vals != self._uploaded:
+            self._table["hyper"].copy_(torch.tensor(vals, dtype=torch.float32))
+            self._uploaded = vals
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._table is None or (not capturing and self._table["key"] != tuple(
+                (p.data_ptr(), p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr())
+                for p, _, _, _ in self._table["entries"] if p.grad is not None)):
+            if capturing and self._table is None:
+                raise RuntimeError("FusedSGD: take one eager step before capturing a graph (tables are built on first use)")
+            self._table = self._build()
+            self._uploaded = None
+        if self._table is None:
+            return loss
+        if not capturing:
+            self.sync_hyper()
+        t = self._table
+        _lib.check(_lib.lib().dsn_sgd_step(t["descs"].data_ptr(), t["n"], t["chunks"], t["hyper"].data_ptr(), stream_ptr()),
+                   "sgd_step")
+        if self._first and not capturing:
+            self._first = False        # momentum buffers now hold g': later steps blend (uploaded before the next launch)
+        return loss

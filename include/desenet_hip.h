@@ -112,16 +112,33 @@ int dsn_pack_weight_fwd(const float* w_oihw, const float* scale, void* out, int3
 int dsn_pack_weight_dgrad(const float* w_oihw, void* out, int32_t dtype, int32_t co, int32_t ci, int32_t kh,
                           int32_t kw, void* stream);
 /* One launch for ALL conv weights of a model (per optimizer step): descs/work live in device memory.
- * work = int32 pairs {tensor id, first element of a dsn_pack_chunk()-sized piece of that tensor's forward layout}. */
+ * work = int32 pairs {tensor id, tile index}, tile index < dsn_pack_tiles(co, ci, kh, kw) (32 x 64 tiles of the [co][ci*kh*kw]
+ * matrix).  ci_pad - ci padding lanes of out_fwd are never written: allocate it zero-filled. */
 typedef struct {
     const void* w_oihw;   /* fp32 [co][ci][kh][kw] */
     void*       out_fwd;  /* [co][kh][kw][ci_pad] or NULL */
     void*       out_dgrad;/* [ci][kh][kw][co]     or NULL */
     int32_t     co, ci, kh, kw, ci_pad, reserved;
 } dsn_pack_desc;
-int32_t dsn_pack_chunk(void);
+int32_t dsn_pack_tiles(int32_t co, int32_t ci, int32_t kh, int32_t kw);
 int dsn_pack_weights_multi(const dsn_pack_desc* descs_dev, const int32_t* work_dev, int32_t n_work, int32_t dtype,
                            void* stream);
+/* ---- optimizer step (scripts/train.py:159-166,376: optim.SGD(momentum, nesterov=True), three parameter groups) ----------
+ * ONE launch updates every parameter: descs (device array, sorted by first_chunk) name the fp32 param / grad / momentum
+ * buffers; tensor i owns chunks [first_chunk, first_chunk + ceil(numel / dsn_sgd_chunk())).  hyper (DEVICE memory, 8 floats
+ * per group: lr, momentum, dampening, weight_decay, nesterov, first_step, 0, 0) is read by the kernel, so a captured graph
+ * follows learning-rate schedules.  Math = torch.optim.SGD: g' = g + wd*p; buf = first ? g' : m*buf + (1-damp)*g';
+ * p -= lr * (nesterov ? g' + m*buf : buf). */
+typedef struct {
+    void*       param;
+    const void* grad;
+    void*       momentum_buf;
+    int64_t     numel;
+    int32_t     group, first_chunk;
+} dsn_sgd_desc;
+int32_t dsn_sgd_chunk(void);
+int dsn_sgd_step(const dsn_sgd_desc* descs_dev, int32_t n_tensors, int32_t n_chunks, const float* hyper_dev, void* stream);
+
 /* dw (packed [Co][KH][KW][Ci_pad] fp32) -> OIHW fp32 gradient, grad (+)= dw */
 int dsn_unpack_wgrad(const float* dw_packed, float* grad_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
                      int32_t ci_pad, int32_t accumulate, void* stream);

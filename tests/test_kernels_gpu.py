@@ -460,6 +460,32 @@ def test_nms_vs_oracle_random_large(ops):
         np.testing.assert_array_equal(out[i, :r.shape[0]].cpu().numpy(), r)
 
 
+def test_fused_sgd_matches_torch(ops):
+    """dsn_sgd_step (one launch for every parameter, three groups) against torch.optim.SGD(momentum, nesterov, weight decay)
+    over several steps, including a learning-rate change picked up from the device-side hyper table."""
+    from desenet_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    shapes = [(32, 12, 3, 3), (64,), (33, 128, 1, 1), (5,), (256, 256, 3, 3), (1,)]
+    ref = [torch.nn.Parameter(rnd(s, 50 + i).cuda()) for i, s in enumerate(shapes)]
+    got = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    groups = lambda ps: [dict(params=ps[1:2] + ps[3:4], weight_decay=0.0), dict(params=[ps[0], ps[2], ps[4]], weight_decay=5e-4),
+                         dict(params=ps[5:], weight_decay=0.0, lr=0.05)]
+    o_ref = torch.optim.SGD(groups(ref), lr=0.01, momentum=0.937, nesterov=True)
+    o_got = FusedSGD(groups(got), lr=0.01, momentum=0.937, nesterov=True)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref, got)):
+            g = rnd(a.shape, 500 + 10 * step + i).cuda()
+            a.grad, b.grad = g.clone(), g.clone()
+        if step == 2:
+            for o in (o_ref, o_got):
+                o.param_groups[1]["lr"] = 0.003
+        o_ref.step()
+        o_got.step()
+    for a, b, s_ in zip(ref, got, shapes):
+        assert_close(b.detach().cpu(), a.detach().cpu(), 1e-6, f"FusedSGD param {s_}")
+        assert_close(o_got.state[b]["momentum_buffer"].cpu(), o_ref.state[a]["momentum_buffer"].cpu(), 1e-6, f"momentum {s_}")
+
+
 def test_errors_are_reported_not_fatal(ops):
     x = ops.new_act(1, 8, 4, 4, torch.float32, "cuda")
     y = ops.new_act(1, 8, 5, 5, torch.float32, "cuda")
