@@ -171,11 +171,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (rehearsal on a one-GPU box: DSN_BENCH_BACKEND=gloo lets N ranks share the card; the driver's runs use RCCL, one GPU each)
+    backend = os.environ.get("DSN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import desenet_amd
     from desenet_amd import hip_ops as ops
@@ -225,7 +231,8 @@ def main():
                 from desenet_amd.graph import GraphedTrainStep
                 graphed = GraphedTrainStep(model, loss_and_grads, flat, opt, x)
                 step = lambda: graphed()
-                mode_note = "one hipGraph replay per step (pack + fwd + losses + bwd + SGD)"
+                mode_note = ("one hipGraph replay per step (pack + fwd + losses + bwd + SGD)" if world == 1 else
+                             "two hipGraph replays per step (pack + fwd + losses + bwd | SGD) around the eager all-reduce")
             except Exception as e:   # keep the bench alive, but say so loudly
                 log(f"hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
     else:
