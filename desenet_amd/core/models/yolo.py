@@ -322,7 +322,8 @@ class Model(HipModule):
             self.__dict__["_dsn_bank_pads"] = pads
             self.__dict__["_dsn_bank_version"] = None
         version = tuple(c.weight._version for c in convs)
-        if version != self.__dict__.get("_dsn_bank_version"):
+        # (while a graph is being captured the re-pack is ALWAYS recorded: every replay follows an optimizer step)
+        if version != self.__dict__.get("_dsn_bank_version") or torch.cuda.is_current_stream_capturing():
             bank.pack()
             self.__dict__["_dsn_bank_version"] = version
             for c, cp, f, d in zip(convs, self.__dict__["_dsn_bank_pads"], bank.fwd, bank.dgrad):

@@ -150,6 +150,20 @@ __device__ __forceinline__ void bn_acc_fold(const BnAcc& f, int c, double& s, do
 }
 #endif
 
+#if defined(__HIPCC__)
+// 32-bit fill as a KERNEL.  hipMemsetAsync nodes captured into a hipGraph were observed (ROCm 7.2, gfx950) not to take effect
+// reliably on replay for small, 4-byte-aligned ranges inside a larger workspace (stale contents -> garbage indices), so the
+// library never relies on memset nodes.
+static __global__ void dsn_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static inline void dsn_fill_u32(void* p, uint32_t v, int64_t n_words, hipStream_t st) {
+    if (n_words <= 0) return;
+    int64_t b = (n_words + 255) / 256;
+    hipLaunchKernelGGL(dsn_fill_u32_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(256), 0, st, (uint32_t*)p, v, n_words);
+}
+#endif
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #define DSN_DISPATCH_DTYPE(dt, T, ...)                 \

@@ -315,8 +315,7 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
     const int64_t cap = key_cap(n, nc, multi_label);
     int32_t* counts = (int32_t*)workspace;
     uint64_t* keys = (uint64_t*)((char*)workspace + (int64_t)((bs * 4 + 255) / 256) * 256);
-    hipError_t e = hipMemsetAsync(counts, 0, (size_t)bs * 4, st);
-    if (e != hipSuccess) DSN_FAIL((int)e, "nms: memset failed: %s", hipGetErrorString(e));
+    dsn_fill_u32(counts, 0u, bs, st);
     hipLaunchKernelGGL(nms_candidates_kernel, dim3(ew_grid((int64_t)bs * n)), dim3(256), 0, st, pred, bs, n, nc,
                        conf_thres, multi_label, classes_mask, keys, cap, counts);
     DSN_LAUNCH_CHECK("nms candidates");

@@ -328,8 +328,7 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
     char* w = (char*)workspace;
     float* acc = (float*)w;                 // [nl][4] + ncells[nl] + balance[nl]
     w += 256;
-    hipError_t e = hipMemsetAsync(acc, 0, 256, st);
-    if (e != hipSuccess) DSN_FAIL((int)e, "det_loss: memset failed");
+    dsn_fill_u32(acc, 0u, 64, st);
     DetMeta meta{};
     for (int i = 0; i < nl; ++i) {
         meta.ncells[i] = (float)((int64_t)bs * na * ny[i] * nx[i]);
@@ -346,8 +345,7 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
         int32_t* owner = (int32_t*)w;                    w += max_cells * 4;
         float* partial = (float*)w;                      w += 1024 * 4;
         const int64_t ncell = (int64_t)bs * na * ny[i] * nx[i];
-        e = hipMemsetAsync(owner, 0xFF, (size_t)ncell * 4, st);      // -1
-        if (e != hipSuccess) DSN_FAIL((int)e, "det_loss: memset failed");
+        dsn_fill_u32(owner, 0xFFFFFFFFu, ncell, st);                 // -1
         if (nt > 0)
             hipLaunchKernelGGL(det_match_kernel, dim3(1), dim3(LT), 0, st, p[i], targets, q, cands, dcls, owner, acc + i * 4);
         const int ob = lgrid(ncell, 1024);

@@ -647,8 +647,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     hipStream_t st = (hipStream_t)stream;
     // packed layout with a padded channel axis: the reduction also visits the padding lanes, which no tile writes
     if (g.S > 1 && !g.oihw && g.Cip != g.Ci) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)g.S * job.n_out * sizeof(float), st);
-        if (e != hipSuccess) DSN_FAIL((int)e, "conv wgrad: memset failed");
+        dsn_fill_u32(out, 0u, (int64_t)g.S * job.n_out, st);
     }
     static int pk_bf16 = [] { const char* e = getenv("DSN_WGRAD_PK"); int v = e ? atoi(e) : 32; return (v == 64 || v == 128) ? v : 32; }();
     const int PK = (x->dtype == DSN_F32 || job.kind == 1) ? 32 : pk_bf16;     // (ppb is a multiple of 32; 64/128 only for tuning runs

@@ -207,7 +207,9 @@ class WgradQueue:
             if not pool["capture"]:
                 raise RuntimeError("WgradQueue: out of pinned job tables for hipGraph capture")
             self.slot = None
-            return pool["capture"].pop()        # owned by the captured graph from now on (never reused)
+            t = pool["capture"].pop()
+            pool.setdefault("owned", []).append(t)     # read by the graph's memcpy node at EVERY replay: never freed or reused
+            return t
         i = pool["next"]
         pool["next"] = (i + 1) % self.RING
         ev = pool["events"][i]

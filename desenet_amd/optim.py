@@ -98,6 +98,9 @@ class FusedSGD(torch.optim.Optimizer):
         t = self._table
         _lib.check(_lib.lib().dsn_sgd_step(t["descs"].data_ptr(), t["n"], t["chunks"], t["hyper"].data_ptr(), stream_ptr()),
                    "sgd_step")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that everything keyed on
+        # them (packed-weight caches, saved-tensor checks) sees the update
+        torch.autograd.graph.increment_version([p for p, _, _, _ in t["entries"]])
         if self._first and not capturing:
             self._first = False        # momentum buffers now hold g': later steps blend (uploaded before the next launch)
         return loss

@@ -40,6 +40,8 @@ def compute_dtype():
 # dW = wgrad(x, dy) feeds nothing but the optimizer, so it is taken off the critical path of backward: it runs on a second
 # HIP stream, forked after dy is ready and joined once at the end of the backward pass.  Under hipGraph capture this
 # becomes a parallel branch of the graph (the layers are small: concurrent kernels fill CUs that would idle otherwise).
+import os as _os
+_no_queue = bool(int(_os.environ.get("DSN_NO_WGRAD_QUEUE", "0")))     # debugging switch: launch every wgrad immediately
 _side_streams = {}
 _use_side_stream = False    # measured: no gain under hipGraph replay on ROCm 7.2 (branches are not overlapped); opt-in
 
@@ -78,7 +80,7 @@ class Tape:
     def wgrad_queue(self, device):
         """Queue that collects this backward pass's weight-gradient jobs (launched together by join()); None when the
         side-stream variant is selected instead."""
-        if _use_side_stream:
+        if _use_side_stream or _no_queue:
             return None
         q = getattr(self, "wq", None)
         if q is None:

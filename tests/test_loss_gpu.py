@@ -83,3 +83,39 @@ def test_seg_ce_vs_aten(shape, ignore_frac):
     (loss * 2.0).backward()
     assert_close(loss.cpu(), ref.detach(), 1e-5, "CE")
     assert_close(ld.grad.cpu(), logits.grad, 1e-4, "dCE")
+
+
+def test_losses_replay_in_a_graph():
+    """The loss launches captured in a hipGraph give the eager numbers on EVERY replay, with unrelated allocations in
+    between (regression: hipMemsetAsync nodes inside the capture left the objectness-owner table stale on replay, i.e.
+    garbage indices; the library now clears with fill kernels)."""
+    from desenet_amd import hip_ops as ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    bs, size, nc = 2, 128, 6
+    det_t, seg_t = synth_targets(bs, size, 21)
+    det_t, seg_t = det_t.to(dev), seg_t.to(dev)
+    g = torch.Generator().manual_seed(0)
+    p = [torch.randn(bs, 3, size // s, size // s, 5 + nc, generator=g).to(dev) for s in (8, 16, 32)]
+    logits = torch.randn(bs, 2, size, size, generator=g).to(dev)
+
+    def body():
+        out, dp = ops.det_loss(p, det_t, [float(v) for v in ANCHORS.reshape(-1)], [4.0, 1.0, 0.4], 0.05, 1.0, 0.5, 1.0, 1.0, 4.0,
+                               1.0, 0.0, nc, 1.0)
+        sout, dl = ops.seg_ce(logits, seg_t, -1, True)
+        return torch.stack([out[0], sout[0], sum(d.abs().sum() for d in dp), dl.abs().sum()])
+
+    want = body().cpu()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        res = body()
+    keep = []
+    for i in range(3):
+        graph.replay()
+        assert_close(res.cpu(), want, 1e-6, f"replay {i}")
+        keep.append([torch.randn(n, device=dev) for n in (7, 1000, 100000, 3000000)])

@@ -231,7 +231,8 @@ def test_direct_accumulation_into_flat_gradients(net):
     assert int(direct.state_dict()["model.0.conv.bn.num_batches_tracked"]) == 1
 
 
-def test_graph_replay_equals_eager_training(net):
+@pytest.mark.parametrize("fused", [False, True])
+def test_graph_replay_equals_eager_training(net, fused):
     """desenet_amd.graph.GraphedTrainStep (one hipGraph per step: pack + forward + HIP losses + backward + SGD) must walk
     the same trajectory as the eager autograd path: 4 SGD steps from the same initial weights, fp32 (tolerance 5e-2: the
     tiny batch-statistics network amplifies rounding differences step over step)."""
@@ -239,7 +240,9 @@ def test_graph_replay_equals_eager_training(net):
     from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN, scale_hyp
     from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
     from desenet_amd.graph import GraphedTrainStep
+    from desenet_amd.optim import FusedSGD
     from desenet_amd.parallel import FlatGradients, sgd_param_groups
+    from desenet_amd import hip_ops as ops
     _, m = net
     x = synth_images(2, 128, 21).cuda()
     det_t, seg_t = synth_targets(2, 128, 21)
@@ -249,7 +252,7 @@ def test_graph_replay_equals_eager_training(net):
         mm = copy.deepcopy(m).train()
         mm.hyp = scale_hyp(6, 128)
         flat = FlatGradients(mm.parameters())
-        opt = torch.optim.SGD(sgd_param_groups(mm), lr=0.01, momentum=0.937, nesterov=True)
+        opt = (FusedSGD if fused else torch.optim.SGD)(sgd_param_groups(mm), lr=0.01, momentum=0.937, nesterov=True)
         return mm, flat, opt, ComputeLoss(mm), SegmentationLosses()
 
     me, flat, opt, cl, sl = setup()
@@ -275,3 +278,12 @@ def test_graph_replay_equals_eager_training(net):
             assert rel_err(sd_g[k].cpu(), sd_e[k].cpu()) < 5e-2, k   # chaotic 128x128 batch-stat net, float atomics in det_scatter, gain folded differently
         else:
             assert torch.equal(sd_g[k].cpu(), sd_e[k].cpu()), k
+    # every replay must re-pack the weights the previous replay's optimizer step produced (a stale bank would train on old
+    # bf16/fp32 copies forever): the bank after replay n+1 is exactly pack(master weights after replay n)
+    convs = [c for c in mg.modules() if isinstance(c, torch.nn.Conv2d)]
+    snap = [c.weight.detach().clone() for c in convs]
+    step()
+    bank = mg.__dict__["_dsn_bank"]
+    for c, w0, f, cp in list(zip(convs, snap, bank.fwd, mg.__dict__["_dsn_bank_pads"]))[::7]:
+        assert torch.equal(f, ops.pack_weight_fwd(w0, f.dtype, None, cp)), "weight bank is stale after a replay"
+        assert not torch.equal(c.weight.detach(), w0), "the optimizer step inside the graph did not update the weights"
