@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict_
     float* hv = smp + (size_t)HW * V;                  // [V][HW] horizontal max
     int* hc = reinterpret_cast<int*>(hv + (size_t)HW * V);   // [V][HW] its column
     const int ncv = C / V;
-    const int n = blockIdx.x / ncv, cv = blockIdx.x % ncv;
+    const int tile = blockIdx.x / out.n, b0 = blockIdx.x % out.n;      // one pool size per block: 3x the blocks, the tile
+    const int n = tile / ncv, cv = tile % ncv;                          // (a few KB out of L2) is simply loaded again
     for (int p = threadIdx.x; p < HW; p += 256) {
         float v[V];
         VecIO<T, V>::load(x + ((int64_t)n * HW + p) * xld + cv * V, v);
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict_
         for (int k = 0; k < V; ++k) sx[k * HW + p] = v[k];
     }
     __syncthreads();
-    for (int b = 0; b < out.n; ++b) {
+    for (int b = b0; b <= b0; ++b) {
         const int r = out.k[b] / 2;
         for (int p = threadIdx.x; p < HW; p += 256) {
             const int row = p / W, w = p - row * W;
@@ -294,6 +295,84 @@ __global__ void bilinear_bwd_kernel(const void* __restrict__ dyv, int64_t yld, T
         T* o = dx + (((int64_t)n * Hi + hi) * Wi + wi) * xld + c;
         if (accumulate) s += to_f32<T>(*o);
         *o = from_f32<T>(s);
+    }
+}
+
+// 16-byte channel vectors (NHWC in, NHWC out): one thread = one output pixel x V channels, four 16-byte taps
+template <typename T, int V>
+__global__ void bilinear_vec_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y, int64_t yld, int N, int Hi, int Wi,
+                                    int Ho, int Wo, int C, float sh, float sw) {
+    const int ncv = C / V;
+    const int64_t total = (int64_t)N * Ho * Wo * ncv;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % ncv);
+        int64_t t = i / ncv;
+        const int w = (int)(t % Wo); t /= Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const Lerp a = lerp_coord(h, sh, Hi), b = lerp_coord(w, sw, Wi);
+        const T* base = x + (int64_t)n * Hi * Wi * xld + cv * V;
+        float v00[V], v01[V], v10[V], v11[V], o[V];
+        VecIO<T, V>::load(base + ((int64_t)a.i0 * Wi + b.i0) * xld, v00);
+        VecIO<T, V>::load(base + ((int64_t)a.i0 * Wi + b.i1) * xld, v01);
+        VecIO<T, V>::load(base + ((int64_t)a.i1 * Wi + b.i0) * xld, v10);
+        VecIO<T, V>::load(base + ((int64_t)a.i1 * Wi + b.i1) * xld, v11);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = a.l0 * (b.l0 * v00[k] + b.l1 * v01[k]) + a.l1 * (b.l0 * v10[k] + b.l1 * v11[k]);
+        VecIO<T, V>::store(y + (((int64_t)n * Ho + h) * Wo + w) * yld + cv * V, o);
+    }
+}
+
+// gather form with 16-byte channel vectors (NHWC dy)
+template <typename T, int V>
+__global__ void bilinear_bwd_vec_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld, int N, int Hi,
+                                        int Wi, int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+    const int ncv = C / V;
+    const int64_t total = (int64_t)N * Hi * Wi * ncv;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % ncv);
+        int64_t t = i / ncv;
+        const int wi = (int)(t % Wi); t /= Wi;
+        const int hi = (int)(t % Hi);
+        const int n = (int)(t / Hi);
+        int h_lo = 0, h_hi = Ho - 1, w_lo = 0, w_hi = Wo - 1;
+        if (sh > 0.f) {
+            h_lo = (int)floorf((float)(hi - 1) / sh) - 1;
+            h_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
+            h_lo = h_lo < 0 ? 0 : h_lo;
+            h_hi = h_hi > Ho - 1 ? Ho - 1 : h_hi;
+        }
+        if (sw > 0.f) {
+            w_lo = (int)floorf((float)(wi - 1) / sw) - 1;
+            w_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
+            w_lo = w_lo < 0 ? 0 : w_lo;
+            w_hi = w_hi > Wo - 1 ? Wo - 1 : w_hi;
+        }
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
+        for (int ho = h_lo; ho <= h_hi; ++ho) {
+            const Lerp a = lerp_coord(ho, sh, Hi);
+            const float wh = (a.i0 == hi ? a.l0 : 0.f) + (a.i1 == hi ? a.l1 : 0.f);
+            if (wh == 0.f) continue;
+            for (int wo = w_lo; wo <= w_hi; ++wo) {
+                const Lerp b = lerp_coord(wo, sw, Wi);
+                const float ww = (b.i0 == wi ? b.l0 : 0.f) + (b.i1 == wi ? b.l1 : 0.f);
+                if (ww == 0.f) continue;
+                float g[V];
+                VecIO<T, V>::load(dy + (((int64_t)n * Ho + ho) * Wo + wo) * yld + cv * V, g);
+#pragma unroll
+                for (int k = 0; k < V; ++k) s[k] += wh * ww * g[k];
+            }
+        }
+        T* o = dx + (((int64_t)n * Hi + hi) * Wi + wi) * xld + cv * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += old[k];
+        }
+        VecIO<T, V>::store(o, s);
     }
 }
 
@@ -586,6 +665,13 @@ inline bool same_nhwc(const dsn_tensor* a, const dsn_tensor* b) {
 
 }  // namespace
 
+namespace {
+inline bool vec16(const dsn_tensor* t) {
+    const int vw = t->dtype == DSN_F32 ? 4 : 8;
+    return t->c % vw == 0 && t->ldc % vw == 0 && ((uintptr_t)t->ptr % 16) == 0;
+}
+}  // namespace
+
 extern "C" int dsn_focus_s2d(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
                              void* stream) {
     DSN_CHECK_ARG(x && tensor_ok(y) && n > 0 && c > 0, "focus_s2d: invalid arguments");
@@ -598,13 +684,6 @@ extern "C" int dsn_focus_s2d(const float* x, int32_t n, int32_t c, int32_t h, in
     DSN_LAUNCH_CHECK("focus_s2d");
     return DSN_OK;
 }
-
-namespace {
-inline bool vec16(const dsn_tensor* t) {
-    const int vw = t->dtype == DSN_F32 ? 4 : 8;
-    return t->c % vw == 0 && t->ldc % vw == 0 && ((uintptr_t)t->ptr % 16) == 0;
-}
-}  // namespace
 
 extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, void* const* idxs, const int32_t* ks,
                                     int32_t n_out, void* stream) {
@@ -626,7 +705,7 @@ extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, v
         for (int i = 0; i < n_out; ++i) {
             out.y[i] = ys[i].ptr; out.ld[i] = ys[i].ldc; out.idx[i] = idxs ? (int32_t*)idxs[i] : nullptr; out.k[i] = ks[i];
         }
-        const dim3 grid(x->n * (x->c / V));
+        const dim3 grid(x->n * (x->c / V) * n_out);
         if (x->dtype == DSN_F32)
             hipLaunchKernelGGL((maxpool_multi_kernel<float, 4>), grid, dim3(256), lds, st, (const float*)x->ptr, x->ldc, out,
                                x->h, x->w, x->c);
@@ -727,6 +806,18 @@ extern "C" int dsn_bilinear_ac(const dsn_tensor* x, const dsn_tensor* y, int32_t
     const float sh = ac_scale(x->h, y->h), sw = ac_scale(x->w, y->w);
     const int64_t total = (int64_t)y->n * y->h * y->w * y->c;
     hipStream_t st = (hipStream_t)stream;
+    if (!out_nchw && vec16(x) && vec16(y)) {
+        const int V = x->dtype == DSN_F32 ? 4 : 8;
+        const int64_t tv = total / V;
+        if (x->dtype == DSN_F32)
+            hipLaunchKernelGGL((bilinear_vec_kernel<float, 4>), dim3(ew_grid(tv)), dim3(256), 0, st, (const float*)x->ptr, x->ldc,
+                               (float*)y->ptr, y->ldc, x->n, x->h, x->w, y->h, y->w, x->c, sh, sw);
+        else
+            hipLaunchKernelGGL((bilinear_vec_kernel<bf16_t, 8>), dim3(ew_grid(tv)), dim3(256), 0, st, (const bf16_t*)x->ptr, x->ldc,
+                               (bf16_t*)y->ptr, y->ldc, x->n, x->h, x->w, y->h, y->w, x->c, sh, sw);
+        DSN_LAUNCH_CHECK("bilinear_ac");
+        return DSN_OK;
+    }
     DSN_DISPATCH_DTYPE(x->dtype, T, {
         if (out_nchw)
             hipLaunchKernelGGL((bilinear_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x->ptr,
@@ -762,6 +853,19 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
                                (const float*)workspace, g.S, nseg, dx->c, (T*)dx->ptr, dx->ldc, accumulate);
         });
         DSN_LAUNCH_CHECK("bilinear_ac_bwd (split)");
+        return DSN_OK;
+    }
+    if (!dy_nchw && vec16(dx) && vec16(dy)) {
+        const int V = dx->dtype == DSN_F32 ? 4 : 8;
+        if (dx->dtype == DSN_F32)
+            hipLaunchKernelGGL((bilinear_bwd_vec_kernel<float, 4>), dim3(ew_grid(total / V)), dim3(256), 0, st,
+                               (const float*)dy->ptr, dy->ldc, (float*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dy->h, dy->w, dx->c,
+                               sh, sw, accumulate);
+        else
+            hipLaunchKernelGGL((bilinear_bwd_vec_kernel<bf16_t, 8>), dim3(ew_grid(total / V)), dim3(256), 0, st,
+                               (const bf16_t*)dy->ptr, dy->ldc, (bf16_t*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dy->h, dy->w,
+                               dx->c, sh, sw, accumulate);
+        DSN_LAUNCH_CHECK("bilinear_ac_bwd");
         return DSN_OK;
     }
     DSN_DISPATCH_DTYPE(dx->dtype, T, {
