@@ -561,10 +561,10 @@ struct WRGeom {
     int64_t xld, yld;
 };
 
-template <typename T, int MODE>
+template <typename T, int MODE, int V>
 __global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
                                                             float* __restrict__ partial, const WRGeom g) {
-    __shared__ float red[256];
+    __shared__ float red[256 * V];
     const int s = blockIdx.x % g.S;
     const int seg = blockIdx.x / g.S;
     const int kw = seg % g.KW, kh = (seg / g.KW) % g.KH, n = seg / (g.KW * g.KH);
@@ -585,13 +585,16 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict_
         }
     }
     const int ww = w1 - w0;
-    const int TX = g.C < 256 ? g.C : 256, TY = 256 / TX;
+    const int ncv = g.C / V;                      // V channels per thread (16-byte loads when V > 1)
+    const int TX = ncv < 256 ? ncv : 256, TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     float* out = partial + (int64_t)blockIdx.x * g.C;
-    for (int c0 = 0; c0 < g.C; c0 += TX) {
-        const int c = c0 + tx;
-        float acc = 0.f;
-        if (ty < TY && c < g.C) {
+    for (int cv0 = 0; cv0 < ncv; cv0 += TX) {
+        const int cv = cv0 + tx;
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        if (ty < TY && cv < ncv) {
             for (int hh = h0 + s; hh < h1; hh += g.S) {
                 float wh = 1.f;
                 if (MODE == WR_BILINEAR_BWD) {
@@ -607,19 +610,30 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict_
                         wgt *= (b.i0 == kw ? b.l0 : 0.f) + (b.i1 == kw ? b.l1 : 0.f);
                     }
                     const int64_t p = ((int64_t)n * g.H + hh) * g.W + wq;
-                    float v = to_f32<T>(x[p * g.xld + c]);
-                    if (MODE == WR_FFM_ATT) v *= to_f32<T>(y[p * g.yld + c]);
-                    acc += wgt * v;
+                    float v[V];
+                    VecIO<T, V>::load(x + p * g.xld + cv * V, v);
+                    if (MODE == WR_FFM_ATT) {
+                        float u[V];
+                        VecIO<T, V>::load(y + p * g.yld + cv * V, u);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) v[k] *= u[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < V; ++k) acc[k] += wgt * v[k];
                 }
             }
         }
         __syncthreads();
-        if (ty < TY) red[ty * TX + tx] = acc;
+        if (ty < TY) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) red[(ty * TX + tx) * V + k] = acc[k];
+        }
         __syncthreads();
-        if (ty == 0 && c < g.C) {
+        const int cnum = ((ncv - cv0 < TX) ? (ncv - cv0) : TX) * V;
+        for (int c = threadIdx.x; c < cnum; c += 256) {
             float tot = 0.f;
-            for (int t = 0; t < TY; ++t) tot += red[t * TX + tx];
-            out[c] = tot * inv;
+            for (int t = 0; t < TY; ++t) tot += red[t * TX * V + c];
+            out[cv0 * V + c] = tot * inv;
         }
     }
 }
@@ -847,8 +861,12 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
         if (workspace_bytes < nseg * g.S * dx->c * (int64_t)sizeof(float))
             DSN_FAIL(DSN_EWORKSPACE, "bilinear_ac_bwd: workspace too small");
         DSN_DISPATCH_DTYPE(dx->dtype, T, {
-            hipLaunchKernelGGL((window_reduce_kernel<T, WR_BILINEAR_BWD>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
-                               (const T*)dy->ptr, (const T*)nullptr, (float*)workspace, g);
+            if (vec16(dy))
+                hipLaunchKernelGGL((window_reduce_kernel<T, WR_BILINEAR_BWD, VW<T>::N>), dim3((unsigned)(nseg * g.S)), dim3(256), 0,
+                                   st, (const T*)dy->ptr, (const T*)nullptr, (float*)workspace, g);
+            else
+                hipLaunchKernelGGL((window_reduce_kernel<T, WR_BILINEAR_BWD, 1>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                                   (const T*)dy->ptr, (const T*)nullptr, (float*)workspace, g);
             hipLaunchKernelGGL(window_finalize_kernel<T>, dim3((unsigned)(nseg * ((dx->c + 31) / 32))), dim3(256), 0, st,
                                (const float*)workspace, g.S, nseg, dx->c, (T*)dx->ptr, dx->ldc, accumulate);
         });
@@ -895,8 +913,12 @@ extern "C" int dsn_adaptive_avgpool(const dsn_tensor* x, const dsn_tensor* y, vo
         DSN_FAIL(DSN_EWORKSPACE, "adaptive_avgpool: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     DSN_DISPATCH_DTYPE(x->dtype, T, {
-        hipLaunchKernelGGL((window_reduce_kernel<T, WR_AVGPOOL>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
-                           (const T*)x->ptr, (const T*)nullptr, (float*)workspace, g);
+        if (vec16(x))
+            hipLaunchKernelGGL((window_reduce_kernel<T, WR_AVGPOOL, VW<T>::N>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                               (const T*)x->ptr, (const T*)nullptr, (float*)workspace, g);
+        else
+            hipLaunchKernelGGL((window_reduce_kernel<T, WR_AVGPOOL, 1>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                               (const T*)x->ptr, (const T*)nullptr, (float*)workspace, g);
         hipLaunchKernelGGL(window_finalize_kernel<T>, dim3((unsigned)(nseg * ((x->c + 31) / 32))), dim3(256), 0, st,
                            (const float*)workspace, g.S, nseg, x->c, (T*)y->ptr, y->ldc, 0);
     });
@@ -971,8 +993,12 @@ extern "C" int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat,
     if (!workspace || workspace_bytes < nseg * g.S * feat->c * (int64_t)sizeof(float))
         DSN_FAIL(DSN_EWORKSPACE, "ffm_scale_bwd: workspace too small");
     DSN_DISPATCH_DTYPE(feat->dtype, T, {
-        hipLaunchKernelGGL((window_reduce_kernel<T, WR_FFM_ATT>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
-                           (const T*)dout->ptr, (const T*)feat->ptr, (float*)workspace, g);
+        if (vec16(dout) && vec16(feat))
+            hipLaunchKernelGGL((window_reduce_kernel<T, WR_FFM_ATT, VW<T>::N>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                               (const T*)dout->ptr, (const T*)feat->ptr, (float*)workspace, g);
+        else
+            hipLaunchKernelGGL((window_reduce_kernel<T, WR_FFM_ATT, 1>), dim3((unsigned)(nseg * g.S)), dim3(256), 0, st,
+                               (const T*)dout->ptr, (const T*)feat->ptr, (float*)workspace, g);
         hipLaunchKernelGGL(window_finalize_kernel<T>, dim3((unsigned)(nseg * ((feat->c + 31) / 32))), dim3(256), 0, st,
                            (const float*)workspace, g.S, nseg, feat->c, (T*)datt->ptr, datt->ldc, 0);
         hipLaunchKernelGGL(ffm_scale_bwd_feat_kernel<T>, dim3(ew_grid(P * feat->c)), dim3(256), 0, st,
