@@ -150,6 +150,27 @@ __global__ void copy_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t 
     }
 }
 
+template <typename T, int V>
+__global__ void copy_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t npx, int c, int64_t xld, int64_t yld,
+                                int accumulate) {
+    const int ncv = c / V;
+    const int64_t total = npx * ncv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / ncv;
+        const int cv = (int)(i - p * ncv);
+        float v[V];
+        VecIO<T, V>::load(x + p * xld + cv * V, v);
+        T* o = y + p * yld + cv * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] += old[k];
+        }
+        VecIO<T, V>::store(o, v);
+    }
+}
+
 // ---- multi-tensor weight pack: ONE launch packs every conv weight of the model (forward + dgrad layouts) -------------------
 // work[b] = {tensor id, tile index}.  OIHW is a [co][J] matrix with J = ci*taps contiguous; a block moves one 32(o) x 64(j)
 // tile through LDS: coalesced 256-byte fp32 row reads, the dgrad layout [j][o] (= [ci][tap][co]) leaves as 64-byte segments
@@ -319,6 +340,17 @@ extern "C" int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumu
     DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(y) && x->dtype == y->dtype, "copy: invalid tensors");
     DSN_CHECK_ARG(x->n == y->n && x->h == y->h && x->w == y->w && x->c == y->c, "copy: shape mismatch");
     const int64_t total = npix(x) * x->c;
+    const int vw = x->dtype == DSN_F32 ? 4 : 8;
+    if (x->c % vw == 0 && x->ldc % vw == 0 && y->ldc % vw == 0 && ((uintptr_t)x->ptr % 16) == 0 && ((uintptr_t)y->ptr % 16) == 0) {
+        if (x->dtype == DSN_F32)
+            hipLaunchKernelGGL((copy_vec_kernel<float, 4>), dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)x->ptr, (float*)y->ptr, npix(x), x->c, x->ldc, y->ldc, accumulate);
+        else
+            hipLaunchKernelGGL((copy_vec_kernel<bf16_t, 8>), dim3(grid_for(total / 8)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)x->ptr, (bf16_t*)y->ptr, npix(x), x->c, x->ldc, y->ldc, accumulate);
+        DSN_LAUNCH_CHECK("copy");
+        return DSN_OK;
+    }
     DSN_DISPATCH_DTYPE(x->dtype, T,
                        hipLaunchKernelGGL(copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                                           (const T*)x->ptr, (T*)y->ptr, npix(x), x->c, x->ldc, y->ldc, accumulate));

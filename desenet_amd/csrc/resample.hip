@@ -34,6 +34,42 @@ __global__ void focus_s2d_kernel(const float* __restrict__ x, T* __restrict__ y,
     }
 }
 
+// One thread per OUTPUT pixel: 2 x C float2 loads (lanes walk w: fully coalesced), the cy channels leave as 16-byte vectors.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <typename T, int V, int MAXCY>
+__global__ void focus_s2d_px_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W, int cy,
+                                    int64_t yld) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo;
+    GRID_STRIDE(p, total) {
+        const int w = (int)(p % Wo);
+        const int64_t t = p / Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float o[MAXCY];
+#pragma unroll
+        for (int k = 0; k < MAXCY; ++k) o[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= C) break;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const f32x2_t v = *reinterpret_cast<const f32x2_t*>(x + (((int64_t)n * C + c) * H + 2 * h + r) * W + 2 * w);
+                o[r * C + c] = v[0];              // g = r      (column 2w)
+                o[(r + 2) * C + c] = v[1];        // g = r + 2  (column 2w + 1)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXCY; k += V) {
+            if (k >= cy) break;
+            float part[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) part[e] = o[k + e];
+            VecIO<T, V>::store(y + p * yld + k, part);
+        }
+    }
+}
+
 // ---- stride-1 max pool with -inf padding; first maximum in row-major window order (ATen max_pool2d) ----------------------
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y, int64_t yld,
@@ -181,6 +217,51 @@ __global__ void up2_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__
         const int h = (int)(t % Ho);
         const int n = (int)(t / Ho);
         y[p * yld + c] = x[(((int64_t)n * H + (h >> 1)) * W + (w >> 1)) * xld + c];
+    }
+}
+template <typename T, int V>
+__global__ void up2_vec_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y, int64_t yld, int N, int H, int W, int C) {
+    const int Ho = 2 * H, Wo = 2 * W, ncv = C / V;
+    const int64_t total = (int64_t)N * Ho * Wo * ncv;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % ncv);
+        const int64_t p = i / ncv;
+        const int w = (int)(p % Wo);
+        const int64_t t = p / Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        *reinterpret_cast<u32x4*>(y + p * yld + cv * V) =
+            *reinterpret_cast<const u32x4*>(x + (((int64_t)n * H + (h >> 1)) * W + (w >> 1)) * xld + cv * V);
+    }
+}
+template <typename T, int V>
+__global__ void up2_bwd_vec_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld, int N, int H, int W,
+                                   int C, int accumulate) {
+    const int Wo = 2 * W, ncv = C / V;
+    const int64_t total = (int64_t)N * H * W * ncv;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % ncv);
+        const int64_t p = i / ncv;
+        const int w = (int)(p % W);
+        const int64_t t = p / W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const int64_t q = ((int64_t)n * 2 * H + 2 * h) * Wo + 2 * w;
+        float a[V], b[V], c[V], d[V];
+        VecIO<T, V>::load(dy + q * yld + cv * V, a);
+        VecIO<T, V>::load(dy + (q + 1) * yld + cv * V, b);
+        VecIO<T, V>::load(dy + (q + Wo) * yld + cv * V, c);
+        VecIO<T, V>::load(dy + (q + Wo + 1) * yld + cv * V, d);
+        T* o = dx + p * xld + cv * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) a[k] += old[k];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] += b[k] + c[k] + d[k];
+        VecIO<T, V>::store(o, a);
     }
 }
 template <typename T>
@@ -691,6 +772,17 @@ extern "C" int dsn_focus_s2d(const float* x, int32_t n, int32_t c, int32_t h, in
     DSN_CHECK_ARG(x && tensor_ok(y) && n > 0 && c > 0, "focus_s2d: invalid arguments");
     DSN_CHECK_ARG(h % 2 == 0 && w % 2 == 0, "focus_s2d: H and W must be even (got %dx%d)", h, w);
     DSN_CHECK_ARG(y->n == n && y->h == h / 2 && y->w == w / 2 && y->c >= 4 * c, "focus_s2d: output shape mismatch");
+    if (c <= 4 && w % 2 == 0 && ((uintptr_t)x % 8) == 0 && vec16(y) && y->c <= 16) {
+        const int64_t px = npix(y);
+        if (y->dtype == DSN_F32)
+            hipLaunchKernelGGL((focus_s2d_px_kernel<float, 4, 16>), dim3(ew_grid(px)), dim3(256), 0, (hipStream_t)stream, x,
+                               (float*)y->ptr, n, c, h, w, y->c, y->ldc);
+        else
+            hipLaunchKernelGGL((focus_s2d_px_kernel<bf16_t, 8, 16>), dim3(ew_grid(px)), dim3(256), 0, (hipStream_t)stream, x,
+                               (bf16_t*)y->ptr, n, c, h, w, y->c, y->ldc);
+        DSN_LAUNCH_CHECK("focus_s2d");
+        return DSN_OK;
+    }
     const int64_t total = npix(y) * y->c;
     DSN_DISPATCH_DTYPE(y->dtype, T,
                        hipLaunchKernelGGL(focus_s2d_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x,
@@ -792,6 +884,16 @@ extern "C" int dsn_upsample_nearest2x(const dsn_tensor* x, const dsn_tensor* y, 
                       y->w == 2 * x->w && y->c == x->c,
                   "upsample_nearest2x: shape mismatch");
     const int64_t total = npix(y) * y->c;
+    if (vec16(x) && vec16(y)) {
+        if (x->dtype == DSN_F32)
+            hipLaunchKernelGGL((up2_vec_kernel<float, 4>), dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)x->ptr, x->ldc, (float*)y->ptr, y->ldc, x->n, x->h, x->w, x->c);
+        else
+            hipLaunchKernelGGL((up2_vec_kernel<bf16_t, 8>), dim3(ew_grid(total / 8)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)x->ptr, x->ldc, (bf16_t*)y->ptr, y->ldc, x->n, x->h, x->w, x->c);
+        DSN_LAUNCH_CHECK("upsample_nearest2x");
+        return DSN_OK;
+    }
     DSN_DISPATCH_DTYPE(x->dtype, T,
                        hipLaunchKernelGGL(up2_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                                           (const T*)x->ptr, x->ldc, (T*)y->ptr, y->ldc, x->n, x->h, x->w, x->c));
@@ -804,6 +906,17 @@ extern "C" int dsn_upsample_nearest2x_bwd(const dsn_tensor* dy, const dsn_tensor
                       dy->w == 2 * dx->w && dy->c == dx->c,
                   "upsample_nearest2x_bwd: shape mismatch");
     const int64_t total = npix(dx) * dx->c;
+    if (vec16(dx) && vec16(dy)) {
+        if (dx->dtype == DSN_F32)
+            hipLaunchKernelGGL((up2_bwd_vec_kernel<float, 4>), dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)dy->ptr, dy->ldc, (float*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dx->c, accumulate);
+        else
+            hipLaunchKernelGGL((up2_bwd_vec_kernel<bf16_t, 8>), dim3(ew_grid(total / 8)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)dy->ptr, dy->ldc, (bf16_t*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dx->c,
+                               accumulate);
+        DSN_LAUNCH_CHECK("upsample_nearest2x_bwd");
+        return DSN_OK;
+    }
     DSN_DISPATCH_DTYPE(dx->dtype, T,
                        hipLaunchKernelGGL(up2_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                                           (const T*)dy->ptr, dy->ldc, (T*)dx->ptr, dx->ldc, dx->n, dx->h, dx->w, dx->c,
