@@ -28,7 +28,7 @@ class dsn_sgd_desc(C.Structure):
 
 class dsn_pack_desc(C.Structure):
     _fields_ = [("w_oihw", C.c_void_p), ("out_fwd", C.c_void_p), ("out_dgrad", C.c_void_p), ("co", C.c_int32),
-                ("ci", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("ci_pad", C.c_int32), ("reserved", C.c_int32)]
+                ("ci", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("ci_pad", C.c_int32), ("co_pad", C.c_int32)]
 
 
 TP = C.POINTER(dsn_tensor)
@@ -53,7 +53,7 @@ PROTOTYPES = {
     "dsn_conv2d_wgrad_workspace_bytes": (i64, [TP, TP, CP, i32]),
     "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
     "dsn_pack_weight_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_sgd_chunk": (i32, []),
     "dsn_sgd_step": (i32, [vp, i32, i32, vp, vp]),
     "dsn_pack_tiles": (i32, [i32, i32, i32, i32]),
@@ -81,7 +81,7 @@ PROTOTYPES = {
     "dsn_ffm_scale": (i32, [TP, TP, TP, vp]),
     "dsn_ffm_scale_bwd": (i32, [TP, TP, TP, TP, TP, i32, vp, i64, vp]),
     "dsn_detect_decode": (i32, [TP, vp, vp, i64, i64, i32, i32, f32, vp, vp]),
-    "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, vp]),
+    "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, i32, vp]),
     "dsn_nms_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "dsn_nms": (i32, [vp, i32, i32, i32, f32, f32, i32, i32, u64, i32, vp, vp, vp, i64, vp]),
     "dsn_det_loss_workspace_bytes": (i64, [i32, i32, i32, i32, i64]),

@@ -72,13 +72,15 @@ def packed_fwd(conv: nn.Conv2d, dtype, ci_pad: Optional[int] = None, bn: Optiona
     return w, bias
 
 
-def packed_dgrad(conv: nn.Conv2d, dtype):
-    key = ("dgrad", dtype)
+def packed_dgrad(conv: nn.Conv2d, dtype, co_pad: Optional[int] = None):
+    """[Ci][KH][KW][co_pad] (co_pad > Co: zero-padded K axis for a dy with zero-padded rows; see Detect.bwd)."""
+    co_pad = co_pad if co_pad is not None else conv.out_channels
+    key = ("dgrad", dtype) if co_pad == conv.out_channels else ("dgrad", dtype, co_pad)
     ver = _ver(conv.weight)
     hit = _cache(conv).get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
-    w = ops.pack_weight_dgrad(conv.weight, dtype)
+    w = ops.pack_weight_dgrad(conv.weight, dtype, co_pad)
     _cache(conv)[key] = (ver, w)
     return w
 
@@ -171,7 +173,10 @@ def _channel_sum(t):
 
 
 def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
-    """Backward of conv_block_fwd.  dz: gradient of the block output (the caller routes dz to a shortcut itself)."""
+    """Backward of conv_block_fwd.  dz: gradient of the block output (the caller routes dz to a shortcut itself).
+    A dz whose rows are padded with ZEROS up to a multiple of the vector width (ops.new_act(ldc_align=...), padding cleared by
+    its producer -- Detect.bwd does this for its 33-channel heads) takes the 16-byte paths: the weight gradient ignores the
+    padding lanes, the input gradient runs over the padded K axis with zero-padded weights."""
     rec = tape.pop()
     conv, bn, act, x, y = rec["conv"], rec["bn"], rec["act"], rec["x"], rec["y"]
     k, s, p, d = rec["geom"]
@@ -218,5 +223,11 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
     if dx is None:
         dx = ops.new_act(*x.shape, dtype, x.device)
         acc = False
-    ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc))
+    vec = 4 if dtype == torch.float32 else 8
+    ldc = ops._nhwc_ldc(dy)
+    if rec["plain"] and dy.shape[1] % vec != 0 and ldc is not None and ldc % vec == 0 and ldc - dy.shape[1] < vec \
+            and getattr(dy, "_dsn_zero_padded", False):
+        ops.conv2d_dgrad(ops.padded_view(dy), packed_dgrad(conv, dtype, ldc), dx, ops.conv_params(k, s, p, d, accumulate=acc))
+    else:
+        ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc))
     return dx

@@ -144,8 +144,12 @@ class Detect(HipModule):
         accs = list(acc) if isinstance(acc, (list, tuple)) else [acc] * self.nl
         for i in reversed(range(self.nl)):
             (n, _, ny, nx), dt = metas[i]
-            dtl = ops.detect_raw_bwd(draws[i], ops.new_act(n, self.na * self.no, ny, nx, dt, draws[i].device), self.na,
-                                     self.no)
+            # rows padded to a multiple of the 16-byte vector (33 -> 40 channels), padding written as zeros: the head's weight
+            # and input gradients then take the vector paths instead of the scalar-load ones
+            vec = 4 if dt == torch.float32 else 8
+            dtl = ops.detect_raw_bwd(draws[i], ops.new_act(n, self.na * self.no, ny, nx, dt, draws[i].device, ldc_align=vec),
+                                     self.na, self.no, zero_padding=True)
+            dtl._dsn_zero_padded = True
             dxs[i] = conv_block_bwd(tape, dtl, dxs[i], accs[i], need_dx)
         return dxs
 
@@ -318,7 +322,9 @@ class Model(HipModule):
             vec = 4 if dtype == torch.float32 else 8
             focus_convs = {m.conv.conv for m in self.modules() if isinstance(m, Focus)}
             pads = [((c.in_channels + vec - 1) // vec * vec) if c in focus_convs else c.in_channels for c in convs]
-            bank = self.__dict__["_dsn_bank"] = ops.WeightBank(convs, pads, dtype, device)
+            det_convs = {c for m in self.modules() if isinstance(m, Detect) for c in m.m}
+            co_pads = [((c.out_channels + vec - 1) // vec * vec) if c in det_convs else c.out_channels for c in convs]
+            bank = self.__dict__["_dsn_bank"] = ops.WeightBank(convs, pads, dtype, device, co_pads=co_pads)
             self.__dict__["_dsn_bank_pads"] = pads
             self.__dict__["_dsn_bank_version"] = None
         version = tuple(c.weight._version for c in convs)
@@ -332,7 +338,8 @@ class Model(HipModule):
                 cache[("fwd", dtype, cp, False)] = (_ver(c.weight, c.bias), f, bias)
                 if cp == c.in_channels:
                     cache[("fwd", dtype, None, False)] = cache[("fwd", dtype, cp, False)]
-                cache[("dgrad", dtype)] = (_ver(c.weight), d)
+                cop = d.shape[-1]          # > out_channels for the row-padded Detect heads
+                cache[("dgrad", dtype) if cop == c.out_channels else ("dgrad", dtype, cop)] = (_ver(c.weight), d)
         # BatchNorm `num_batches_tracked`: every counter is a view of one int64 vector -> a single add per step
         bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None
                and not getattr(m, "_dsn_never_runs", False)]

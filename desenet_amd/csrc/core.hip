@@ -104,15 +104,16 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, const float* __rest
 
 // out[ci][kh][kw][co] = w[co][ci][kh][kw]
 template <typename T>
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int co, int ci, int kh, int kw) {
-    const int64_t total = (int64_t)co * kh * kw * ci;
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int co, int ci, int kh, int kw,
+                                  int co_pad) {
+    const int64_t total = (int64_t)co_pad * kh * kw * ci;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int o = (int)(i % co);
-        int64_t t = i / co;
+        const int o = (int)(i % co_pad);
+        int64_t t = i / co_pad;
         const int x = (int)(t % kw); t /= kw;
         const int y = (int)(t % kh);
         const int c = (int)(t / kh);
-        out[i] = from_f32<T>(w[(((int64_t)o * ci + c) * kh + y) * kw + x]);
+        out[i] = from_f32<T>(o < co ? w[(((int64_t)o * ci + c) * kh + y) * kw + x] : 0.f);
     }
 }
 
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const dsn_pack_desc* __
         for (int idx = threadIdx.x; idx < PACK_TO * PACK_TJ; idx += 256) {
             const int cj = idx / PACK_TO, r = idx % PACK_TO;
             const int o = o0 + r, j = j0 + cj;
-            if (o < d.co && j < J) od[(int64_t)j * d.co + o] = from_f32<T>(tile[r][cj]);
+            if (o < d.co && j < J) od[(int64_t)j * (d.co_pad > d.co ? d.co_pad : d.co) + o] = from_f32<T>(tile[r][cj]);
         }
     }
 }
@@ -282,12 +283,12 @@ extern "C" int dsn_pack_weight_fwd(const float* w, const float* scale, void* out
 }
 
 extern "C" int dsn_pack_weight_dgrad(const float* w, void* out, int32_t dtype, int32_t co, int32_t ci, int32_t kh,
-                                     int32_t kw, void* stream) {
-    DSN_CHECK_ARG(w && out && co > 0 && ci > 0 && kh > 0 && kw > 0, "pack_weight_dgrad: bad args");
-    const int64_t total = (int64_t)co * kh * kw * ci;
+                                     int32_t kw, int32_t co_pad, void* stream) {
+    DSN_CHECK_ARG(w && out && co > 0 && ci > 0 && kh > 0 && kw > 0 && co_pad >= co, "pack_weight_dgrad: bad args");
+    const int64_t total = (int64_t)co_pad * kh * kw * ci;
     DSN_DISPATCH_DTYPE(dtype, T,
                        hipLaunchKernelGGL(pack_dgrad_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
-                                          (hipStream_t)stream, w, (T*)out, co, ci, kh, kw));
+                                          (hipStream_t)stream, w, (T*)out, co, ci, kh, kw, co_pad));
     DSN_LAUNCH_CHECK("pack_weight_dgrad");
     return DSN_OK;
 }

@@ -59,18 +59,19 @@ __global__ void detect_decode_kernel(const T* __restrict__ t, int64_t tld, float
 
 template <typename T>
 __global__ void detect_raw_bwd_kernel(const float* __restrict__ draw, T* __restrict__ dt, int64_t tld, int N, int ny,
-                                      int nx, int na, int no) {
+                                      int nx, int na, int no, int Cw) {
     const int C = na * no;
-    const int64_t total = (int64_t)N * ny * nx * C;
+    // channels C .. Cw-1 (row padding the caller asked to clear) become zero
+    const int64_t total = (int64_t)N * ny * nx * Cw;
     GRID_STRIDE(i, total) {
-        const int ch = (int)(i % C);
-        int64_t p = i / C;
+        const int ch = (int)(i % Cw);
+        int64_t p = i / Cw;
         const int x = (int)(p % nx);
         int64_t q = p / nx;
         const int y = (int)(q % ny);
         const int n = (int)(q / ny);
         const int a = ch / no, o = ch - a * no;
-        dt[p * tld + ch] = from_f32<T>(draw[((((int64_t)n * na + a) * ny + y) * nx + x) * no + o]);
+        dt[p * tld + ch] = from_f32<T>(ch < C ? draw[((((int64_t)n * na + a) * ny + y) * nx + x) * no + o] : 0.f);
     }
 }
 
@@ -284,12 +285,14 @@ extern "C" int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, i
     return DSN_OK;
 }
 
-extern "C" int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, void* stream) {
+extern "C" int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, int32_t zero_pad_to,
+                                  void* stream) {
     DSN_CHECK_ARG(tensor_ok(dt) && draw && na > 0 && no > 0 && dt->c == na * no, "detect_raw_bwd: invalid arguments");
-    const int64_t total = npix(dt) * dt->c;
+    DSN_CHECK_ARG(zero_pad_to == 0 || (zero_pad_to >= dt->c && zero_pad_to <= dt->ldc), "detect_raw_bwd: bad zero_pad_to");
+    const int cw = zero_pad_to > dt->c ? zero_pad_to : dt->c;
     DSN_DISPATCH_DTYPE(dt->dtype, T,
-                       hipLaunchKernelGGL(detect_raw_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
-                                          (hipStream_t)stream, draw, (T*)dt->ptr, dt->ldc, dt->n, dt->h, dt->w, na, no));
+                       hipLaunchKernelGGL(detect_raw_bwd_kernel<T>, dim3(ew_grid(npix(dt) * cw)), dim3(256), 0,
+                                          (hipStream_t)stream, draw, (T*)dt->ptr, dt->ldc, dt->n, dt->h, dt->w, na, no, cw));
     DSN_LAUNCH_CHECK("detect_raw_bwd");
     return DSN_OK;
 }

@@ -606,8 +606,14 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
         out = (float*)workspace;
     }
     const int es = x->dtype == DSN_F32 ? 4 : 2, vec = 16 / es;
-    const int64_t xb = ((npix(x) - 1) * x->ldc + x->c) * es, yb = ((npix(dy) - 1) * dy->ldc + dy->c) * es;
-    *vec_out = (g.Co % vec == 0) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
+    // dy may carry a channel count that is not a multiple of the vector width when its rows are padded (ldc rounded up,
+    // Detect: 33 -> 40): the last vector of a row then reads padding lanes, which only feed gradient rows >= Co that are
+    // never stored (any value, even NaN, is harmless there)
+    const int co_up = (g.Co + vec - 1) / vec * vec;
+    const bool dy_padded = g.Co % vec != 0 && co_up <= g.yld;
+    const int64_t xb = ((npix(x) - 1) * x->ldc + x->c) * es;
+    const int64_t yb = dy_padded ? npix(dy) * dy->ldc * es : ((npix(dy) - 1) * dy->ldc + dy->c) * es;
+    *vec_out = (g.Co % vec == 0 || dy_padded) && (g.CiLoad % vec == 0) && (g.yld % vec == 0) && (g.xld % vec == 0) &&
                ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0) && xb < (1ll << 31) && yb < (1ll << 31);
     g.x_bytes = (uint32_t)(xb < (1ll << 31) ? xb : 0);
     g.dy_bytes = (uint32_t)(yb < (1ll << 31) ? yb : 0);

@@ -28,10 +28,19 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def new_act(n: int, c: int, h: int, w: int, dtype, device, zero: bool = False) -> torch.Tensor:
-    """Logical NCHW tensor backed by a fresh dense NHWC buffer."""
-    buf = (torch.zeros if zero else torch.empty)((n, h, w, c), dtype=dtype, device=device)
-    return buf.permute(0, 3, 1, 2)
+def new_act(n: int, c: int, h: int, w: int, dtype, device, zero: bool = False, ldc_align: int = 1) -> torch.Tensor:
+    """Logical NCHW tensor backed by a fresh dense NHWC buffer.  ldc_align > 1 rounds the pixel stride up (row padding after
+    the c channels, e.g. 33 -> 40) so that 16-byte channel vectors stay aligned; the padding lanes are uninitialised."""
+    ldc = (c + ldc_align - 1) // ldc_align * ldc_align
+    buf = (torch.zeros if zero else torch.empty)((n, h, w, ldc), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :c] if ldc != c else buf.permute(0, 3, 1, 2)
+
+
+def padded_view(t: torch.Tensor) -> torch.Tensor:
+    """The [N, ldc, H, W] view over ALL channel lanes of a row-padded activation (`new_act(..., ldc_align=k)`)."""
+    ldc = _nhwc_ldc(t)
+    n, c, h, w = t.shape
+    return t if ldc == c else t.as_strided((n, ldc, h, w), t.stride())
 
 
 def _nhwc_ldc(t: torch.Tensor) -> Optional[int]:
@@ -264,28 +273,30 @@ class WgradQueue:
 class WeightBank:
     """All conv weights of a model packed by ONE kernel launch per optimizer step (forward + dgrad layouts)."""
 
-    def __init__(self, convs, ci_pads, dtype, device, need_dgrad=True):
+    def __init__(self, convs, ci_pads, dtype, device, need_dgrad=True, co_pads=None):
         L = _lib.lib()
         es = 2 if dtype == torch.bfloat16 else 4
         self.dtype, self.convs = dtype, list(convs)
         sizes_f = [c.out_channels * c.kernel_size[0] * c.kernel_size[1] * cp for c, cp in zip(self.convs, ci_pads)]
-        sizes_d = [c.weight.numel() for c in self.convs]
+        co_pads = list(co_pads) if co_pads is not None else [c.out_channels for c in self.convs]
+        self.co_pads = co_pads
+        sizes_d = [c.weight.numel() // c.out_channels * cop for c, cop in zip(self.convs, co_pads)]
         al = lambda n: (n + 63) // 64 * 64
         self.fwd_buf = torch.zeros(sum(al(n) for n in sizes_f), dtype=dtype, device=device)    # ci_pad lanes stay zero
-        self.dg_buf = torch.empty(sum(al(n) for n in sizes_d), dtype=dtype, device=device) if need_dgrad else None
+        self.dg_buf = torch.zeros(sum(al(n) for n in sizes_d), dtype=dtype, device=device) if need_dgrad else None    # co_pad lanes stay zero
         descs = (_lib.dsn_pack_desc * len(self.convs))()
         work, self.fwd, self.dgrad = [], [], []
         of = od = 0
         for i, (c, cp) in enumerate(zip(self.convs, ci_pads)):
             co, ci, kh, kw = c.weight.shape
             fv = self.fwd_buf[of:of + sizes_f[i]].view(co, kh, kw, cp)
-            dv = self.dg_buf[od:od + sizes_d[i]].view(ci, kh, kw, co) if need_dgrad else None
+            dv = self.dg_buf[od:od + sizes_d[i]].view(ci, kh, kw, co_pads[i]) if need_dgrad else None
             self.fwd.append(fv)
             self.dgrad.append(dv)
             w = c.weight
             assert w.dtype == torch.float32 and w.is_contiguous()
             descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dv.data_ptr() if need_dgrad else None, co, ci, kh,
-                                          kw, cp, 0)
+                                          kw, cp, co_pads[i])
             work += [(i, t) for t in range(L.dsn_pack_tiles(co, ci, kh, kw))]
             of += al(sizes_f[i])
             od += al(sizes_d[i])
@@ -315,14 +326,15 @@ def pack_weight_fwd(w_oihw: torch.Tensor, dtype, scale: Optional[torch.Tensor] =
     return out
 
 
-def pack_weight_dgrad(w_oihw: torch.Tensor, dtype):
+def pack_weight_dgrad(w_oihw: torch.Tensor, dtype, co_pad: Optional[int] = None):
     co, ci, kh, kw = w_oihw.shape
+    co_pad = co if co_pad is None else co_pad
     w = w_oihw.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
-    out = torch.empty((ci, kh, kw, co), dtype=dtype, device=w.device)
-    _lib.check(_lib.lib().dsn_pack_weight_dgrad(w.data_ptr(), out.data_ptr(), _DT[dtype], co, ci, kh, kw, stream_ptr()),
-               "pack_weight_dgrad")
+    out = torch.empty((ci, kh, kw, co_pad), dtype=dtype, device=w.device)
+    _lib.check(_lib.lib().dsn_pack_weight_dgrad(w.data_ptr(), out.data_ptr(), _DT[dtype], co, ci, kh, kw, co_pad,
+                                                stream_ptr()), "pack_weight_dgrad")
     return out
 
 
@@ -577,10 +589,12 @@ def detect_decode(t, raw, pred, row_offset, na, no, stride, anchors_px):
                                             float(stride), _p(anchors_px), stream_ptr()), "detect_decode")
 
 
-def detect_raw_bwd(draw, dt, na, no):
+def detect_raw_bwd(draw, dt, na, no, zero_padding=False):
+    """zero_padding: dt is a row-padded activation (new_act ldc_align) whose padding lanes must read as zeros."""
     d = desc(dt)
     g = draw if (draw.is_contiguous() and draw.dtype == torch.float32) else draw.float().contiguous()
-    _lib.check(_lib.lib().dsn_detect_raw_bwd(g.data_ptr(), C.byref(d), na, no, stream_ptr()), "detect_raw_bwd")
+    _lib.check(_lib.lib().dsn_detect_raw_bwd(g.data_ptr(), C.byref(d), na, no, int(d.ldc) if zero_padding else 0,
+                                             stream_ptr()), "detect_raw_bwd")
     return dt
 
 

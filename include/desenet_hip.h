@@ -109,8 +109,10 @@ int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const double* launch, 
  * scale (may be NULL) multiplies output channel co: BN folding W' = diag(g/sqrt(var+eps)) W (torch_utils.py:196-216). */
 int dsn_pack_weight_fwd(const float* w_oihw, const float* scale, void* out, int32_t dtype, int32_t co, int32_t ci,
                         int32_t kh, int32_t kw, int32_t ci_pad, void* stream);
+/* co_pad >= co zero-pads the dgrad layout's K axis ([Ci][KH][KW][co_pad]): Detect's 33 output channels -> 40, so that the
+ * input-gradient GEMM reads 16-byte vectors (its dy carries the same zero padding). */
 int dsn_pack_weight_dgrad(const float* w_oihw, void* out, int32_t dtype, int32_t co, int32_t ci, int32_t kh,
-                          int32_t kw, void* stream);
+                          int32_t kw, int32_t co_pad, void* stream);
 /* One launch for ALL conv weights of a model (per optimizer step): descs/work live in device memory.
  * work = int32 pairs {tensor id, tile index}, tile index < dsn_pack_tiles(co, ci, kh, kw) (32 x 64 tiles of the [co][ci*kh*kw]
  * matrix).  ci_pad - ci padding lanes of out_fwd are never written: allocate it zero-filled. */
@@ -118,7 +120,7 @@ typedef struct {
     const void* w_oihw;   /* fp32 [co][ci][kh][kw] */
     void*       out_fwd;  /* [co][kh][kw][ci_pad] or NULL */
     void*       out_dgrad;/* [ci][kh][kw][co]     or NULL */
-    int32_t     co, ci, kh, kw, ci_pad, reserved;
+    int32_t     co, ci, kh, kw, ci_pad, co_pad;   /* co_pad: row length of out_dgrad (0 or co = unpadded) */
 } dsn_pack_desc;
 int32_t dsn_pack_tiles(int32_t co, int32_t ci, int32_t kh, int32_t kw);
 int dsn_pack_weights_multi(const dsn_pack_desc* descs_dev, const int32_t* work_dev, int32_t n_work, int32_t dtype,
@@ -231,7 +233,9 @@ int dsn_ffm_scale_bwd(const dsn_tensor* dout, const dsn_tensor* feat, const dsn_
 int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, int64_t pred_total_rows, int64_t row_offset,
                       int32_t na, int32_t no, float stride, const float* anchors_px /* [na][2] device */,
                       void* stream);
-int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, void* stream);
+/* zero_pad_to (0 or in [c, ldc]): channels c .. zero_pad_to-1 of every pixel row are written as zeros (row padding that
+ * lets the consumers read 16-byte vectors; never set it on a channel SLICE of a wider tensor). */
+int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, int32_t zero_pad_to, void* stream);
 
 /* ---- NMS (general.py:659-750 + torchvision.ops.nms) ------------------------------------------------------------
  * pred: fp32 [bs, n, 5+nc].  For every image: candidate filter (obj > conf), conf = obj*cls, best-class or
