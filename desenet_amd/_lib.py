@@ -27,7 +27,8 @@ class dsn_sgd_desc(C.Structure):
 
 
 class dsn_pack_desc(C.Structure):
-    _fields_ = [("w_oihw", C.c_void_p), ("out_fwd", C.c_void_p), ("out_dgrad", C.c_void_p), ("co", C.c_int32),
+    _fields_ = [("w_oihw", C.c_void_p), ("out_fwd", C.c_void_p), ("out_dgrad", C.c_void_p), ("out_dgrad_s2", C.c_void_p),
+                ("co", C.c_int32),
                 ("ci", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("ci_pad", C.c_int32), ("co_pad", C.c_int32)]
 
 
@@ -41,6 +42,7 @@ PROTOTYPES = {
     "dsn_last_error": (C.c_char_p, []),
     "dsn_conv2d_fwd": (i32, [TP, vp, vp, TP, TP, CP, vp]),
     "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
+    "dsn_conv2d_dgrad_s2": (i32, [TP, vp, TP, CP, vp]),
     "dsn_conv2d_stats_rows": (i32, [i64]),
     "dsn_conv2d_fwd_stats": (i32, [TP, vp, TP, CP, vp, vp, vp]),
     "dsn_wgrad_job_bytes": (i64, []),

@@ -229,5 +229,10 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
             and getattr(dy, "_dsn_zero_padded", False):
         ops.conv2d_dgrad(ops.padded_view(dy), packed_dgrad(conv, dtype, ldc), dx, ops.conv_params(k, s, p, d, accumulate=acc))
     else:
-        ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc))
+        s2 = _cache(conv).get(("dgrad_s2", dtype)) if (k, s, p, d) == (3, 2, 1, 1) else None
+        if s2 is not None and s2[0] == _ver(conv.weight) and dy.shape[1] % vec == 0 and dx.shape[1] % vec == 0:
+            # stride-2 3x3: one 2x2 stride-1 conv over dy + depth-to-space store (weights packed by the model's WeightBank)
+            ops.conv2d_dgrad_s2(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc))
+        else:
+            ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc))
     return dx

@@ -332,12 +332,14 @@ class Model(HipModule):
         if version != self.__dict__.get("_dsn_bank_version") or torch.cuda.is_current_stream_capturing():
             bank.pack()
             self.__dict__["_dsn_bank_version"] = version
-            for c, cp, f, d in zip(convs, self.__dict__["_dsn_bank_pads"], bank.fwd, bank.dgrad):
+            for c, cp, f, d, s2 in zip(convs, self.__dict__["_dsn_bank_pads"], bank.fwd, bank.dgrad, bank.dgrad_s2):
                 bias = c.bias.detach() if c.bias is not None else None
                 cache = _cache(c)
                 cache[("fwd", dtype, cp, False)] = (_ver(c.weight, c.bias), f, bias)
                 if cp == c.in_channels:
                     cache[("fwd", dtype, None, False)] = cache[("fwd", dtype, cp, False)]
+                if s2 is not None:
+                    cache[("dgrad_s2", dtype)] = (_ver(c.weight), s2)
                 cop = d.shape[-1]          # > out_channels for the row-padded Detect heads
                 cache[("dgrad", dtype) if cop == c.out_channels else ("dgrad", dtype, cop)] = (_ver(c.weight), d)
         # BatchNorm `num_batches_tracked`: every counter is a view of one int64 vector -> a single add per step

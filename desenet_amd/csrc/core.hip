@@ -214,6 +214,18 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const dsn_pack_desc* __
             if (o < d.co && j < J) od[(int64_t)j * (d.co_pad > d.co ? d.co_pad : d.co) + o] = from_f32<T>(tile[r][cj]);
         }
     }
+    T* __restrict__ o2 = (T*)d.out_dgrad_s2;
+    if (o2) {     // 3x3 stride-2 convs: W2[(py,px,ci)][ty][tx][co], (ky -> py,ty): 1 -> (0,0), 2 -> (1,0), 0 -> (1,1); same for kx
+        for (int idx = threadIdx.x; idx < PACK_TO * PACK_TJ; idx += 256) {
+            const int cj = idx / PACK_TO, r = idx % PACK_TO;
+            const int o = o0 + r, j = j0 + cj;
+            if (o < d.co && j < J) {
+                const int c = j / 9, tap = j - c * 9, ky = tap / 3, kx = tap - ky * 3;
+                const int py = ky == 1 ? 0 : 1, ty = ky == 0 ? 1 : 0, px = kx == 1 ? 0 : 1, tx = kx == 0 ? 1 : 0;
+                o2[((((int64_t)(py * 2 + px) * d.ci + c) * 2 + ty) * 2 + tx) * d.co + o] = from_f32<T>(tile[r][cj]);
+            }
+        }
+    }
 }
 
 // ---- multi-tensor SGD (momentum, Nesterov, weight decay): torch.optim.SGD's update for every parameter in ONE launch -------

@@ -38,6 +38,9 @@ struct Geom {
     int32_t tiles_m, tiles_n;
     int32_t is_dgrad;
     int32_t fits32;       // every source element offset fits a signed 32-bit integer
+    // depth-to-space store (stride-2 dgrad as a 2x2 stride-1 conv over dy): GEMM column (cls, ci), cls = py*2 + px, of GEMM
+    // row (n, y, x) lands at destination pixel (n, 2y + py, 2x + px), channel ci.  d2s_c = channels per sub-pixel (0 = off).
+    int32_t d2s_c, Hout, Wout;
     uint32_t src_bytes, w_bytes;   // buffer-descriptor ranges: out-of-range lanes of a buffer_load return 0 (free zero padding)
     // stride-2 dgrad by destination-pixel parity class (py, px): only the taps that can reach a class are visited
     // (1 + 2 + 2 + 4 of the 9 taps of a 3x3 instead of 9 masked ones for every pixel).  Class c = py*2 + px.
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         constexpr int VPR = BN / VEC;               // vectors per tile row
         for (int idx = tid; idx < BM * VPR; idx += 256) {
             const int rl = idx / VPR, cv = idx - rl * VPR;
-            const int col = n0 + cv * VEC;
+            int col = n0 + cv * VEC;
             int row = m0 + rl;
             if (PAR) {
                 int y, x, n;
@@ -379,6 +382,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
                 row = (n * g.Hd + y) * g.Wd + x;
             }
             if (row >= g.M || col >= g.Cd) continue;
+            if (g.d2s_c > 0) {
+                const int cls = col / g.d2s_c;
+                col -= cls * g.d2s_c;
+                const int x = row % g.Wd, t = row / g.Wd;
+                const int Y = 2 * (t % g.Hd) + (cls >> 1), X = 2 * x + (cls & 1);
+                if (Y >= g.Hout || X >= g.Wout) continue;
+                row = ((t / g.Hd) * g.Hout + Y) * g.Wout + X;
+            }
             float vals[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; e += 4) {
@@ -508,7 +519,7 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
             return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);
         return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 64x32
     }
-    if (tiles64 >= 1536 && g.Ktot >= 1024)
+    if (tiles64 >= 1536 && g.Ktot >= 1024 && g.Cd >= 128)
         return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 128x128
     if (tiles64 < 256)
         return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 32x64
@@ -578,6 +589,36 @@ extern "C" int dsn_conv2d_fwd_bnacc(const dsn_tensor* x, const void* w, const ds
     if (acc_bytes < bn_acc_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "conv2d_fwd_bnacc: accumulator buffer too small");
     BnAcc f{(double*)acc, y->c, (double)npix(y)};
     return conv_fwd_impl(x, w, nullptr, nullptr, y, p, nullptr, nullptr, stream, &f);
+}
+
+// Stride-2 3x3 (pad 1) input gradient as ONE stride-1 2x2 convolution over dy with 4*Ci output columns + depth-to-space store:
+//   dx[n, 2y+py, 2x+px, ci] = sum_{ty,tx in {0,1}} sum_co dy[n, y+ty, x+tx, co] * W2[(py,px,ci)][ty][tx][co]
+// with W2 = w[co][ci][ky][kx] for (py,ty) -> ky in {(0,0)->1, (1,0)->2, (1,1)->0} (same for x), zero otherwise
+// (dsn_pack_desc.out_dgrad_s2).  Versus the parity-class form: every block runs the full 4-tap K loop (no 1-chunk tiles),
+// M is the dy grid (4x fewer, 4x wider tiles) and each (n, y) writes two FULL destination rows (2x+px adjacent) instead of
+// every other pixel.  16/9 of the MACs -- irrelevant, these layers are latency/traffic-bound.
+extern "C" int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
+                                   void* stream) {
+    int rc = check_common(dy, w_s2, dx, p);
+    if (rc) return rc;
+    DSN_CHECK_ARG(p->kh == 3 && p->kw == 3 && p->stride == 2 && p->pad == 1 && p->dil == 1,
+                  "conv dgrad_s2: 3x3 / stride 2 / pad 1 only");
+    const int ho = (dx->h + 2 - 3) / 2 + 1, wo = (dx->w + 2 - 3) / 2 + 1;
+    DSN_CHECK_ARG(ho == dy->h && wo == dy->w, "conv dgrad_s2: dy is %dx%d, expected %dx%d", dy->h, dy->w, ho, wo);
+    const int vecw = dy->dtype == DSN_F32 ? 4 : 8;
+    DSN_CHECK_ARG(dx->c % vecw == 0 && dx->ldc % vecw == 0 && ((uintptr_t)dx->ptr % 16) == 0 && dy->c % vecw == 0,
+                  "conv dgrad_s2: channel counts / alignment need the 16-byte paths");
+    Geom g{};
+    g.M = (int32_t)npix(dy); g.Hd = dy->h; g.Wd = dy->w;           // GEMM rows = dy pixels
+    g.Hs = dy->h; g.Ws = dy->w; g.Cs = dy->c; g.Cd = 4 * dx->c;
+    g.KH = 2; g.KW = 2; g.Ktot = 4 * dy->c;
+    g.a = 1; g.b = 0; g.d = 1; g.q = 1;
+    g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
+    g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
+    g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
+    if (dy->dtype == DSN_F32)
+        return launch<float>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+    return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,

@@ -137,6 +137,14 @@ def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_
     return out[0], out[1], out[2], out[3]
 
 
+def conv2d_dgrad_s2(dy, w_s2, dx, p: dsn_conv_params):
+    """Input gradient of a 3x3 / stride-2 / pad-1 conv through the 2x2 + depth-to-space form (weights: WeightBank.dgrad_s2)."""
+    L = _lib.lib()
+    a, b = desc(dy), desc(dx)
+    _lib.check(L.dsn_conv2d_dgrad_s2(C.byref(a), w_s2.data_ptr(), C.byref(b), C.byref(p), stream_ptr()), "conv2d_dgrad_s2")
+    return dx
+
+
 def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params):
     L = _lib.lib()
     a, b = desc(dy), desc(dx)
@@ -285,21 +293,29 @@ class WeightBank:
         self.fwd_buf = torch.zeros(sum(al(n) for n in sizes_f), dtype=dtype, device=device)    # ci_pad lanes stay zero
         self.dg_buf = torch.zeros(sum(al(n) for n in sizes_d), dtype=dtype, device=device) if need_dgrad else None    # co_pad lanes stay zero
         descs = (_lib.dsn_pack_desc * len(self.convs))()
-        work, self.fwd, self.dgrad = [], [], []
-        of = od = 0
+        work, self.fwd, self.dgrad, self.dgrad_s2 = [], [], [], []
+        vec = 16 // es
+        is_s2 = [need_dgrad and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1)
+                 and c.in_channels % vec == 0 and c.out_channels % vec == 0 for c in self.convs]
+        sizes_2 = [16 * c.in_channels * c.out_channels if f else 0 for c, f in zip(self.convs, is_s2)]
+        self.s2_buf = torch.zeros(max(1, sum(al(n) for n in sizes_2)), dtype=dtype, device=device)   # unused blocks stay zero
+        of = od = o2 = 0
         for i, (c, cp) in enumerate(zip(self.convs, ci_pads)):
             co, ci, kh, kw = c.weight.shape
             fv = self.fwd_buf[of:of + sizes_f[i]].view(co, kh, kw, cp)
             dv = self.dg_buf[od:od + sizes_d[i]].view(ci, kh, kw, co_pads[i]) if need_dgrad else None
+            sv = self.s2_buf[o2:o2 + sizes_2[i]].view(4 * ci, 2, 2, co) if is_s2[i] else None
             self.fwd.append(fv)
             self.dgrad.append(dv)
+            self.dgrad_s2.append(sv)
             w = c.weight
             assert w.dtype == torch.float32 and w.is_contiguous()
-            descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dv.data_ptr() if need_dgrad else None, co, ci, kh,
-                                          kw, cp, co_pads[i])
+            descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dv.data_ptr() if need_dgrad else None,
+                                          sv.data_ptr() if sv is not None else None, co, ci, kh, kw, cp, co_pads[i])
             work += [(i, t) for t in range(L.dsn_pack_tiles(co, ci, kh, kw))]
             of += al(sizes_f[i])
             od += al(sizes_d[i])
+            o2 += al(sizes_2[i])
         raw = bytes(descs)
         self.descs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.work_dev = torch.tensor(work, dtype=torch.int32).to(device)

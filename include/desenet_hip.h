@@ -72,6 +72,10 @@ int dsn_conv2d_fwd(const dsn_tensor* x, const void* w_packed, const float* bias,
                    const dsn_tensor* y, const dsn_conv_params* p, void* stream);
 int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w_packed, const dsn_tensor* dx, const dsn_conv_params* p,
                      void* stream);
+/* Input gradient of a 3x3 / stride 2 / pad 1 conv as one 2x2 stride-1 conv over dy + depth-to-space store (weights in the
+ * dsn_pack_desc.out_dgrad_s2 layout).  Same result as dsn_conv2d_dgrad; needs 16-byte-aligned channel counts. */
+int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
+                        void* stream);
 /* Training forward: plain conv whose epilogue ALSO writes per-tile BatchNorm partial sums (sum, sum of squares per output
  * channel, taken from the fp32 accumulators) -> no separate statistics pass over y.  stats: dsn_conv2d_stats_rows(N*Ho*Wo)
  * * 2 * Co floats; *rows_out = rows written; feed both to dsn_bn_finalize. */
@@ -120,6 +124,8 @@ typedef struct {
     const void* w_oihw;   /* fp32 [co][ci][kh][kw] */
     void*       out_fwd;  /* [co][kh][kw][ci_pad] or NULL */
     void*       out_dgrad;/* [ci][kh][kw][co]     or NULL */
+    void*       out_dgrad_s2; /* 3x3 stride-2 convs only, or NULL: [4*ci][2][2][co] for dsn_conv2d_dgrad_s2 (zero-filled by
+                               * the caller: 7 of the 16 (sub-pixel, tap) blocks stay zero) */
     int32_t     co, ci, kh, kw, ci_pad, co_pad;   /* co_pad: row length of out_dgrad (0 or co = unpadded) */
 } dsn_pack_desc;
 int32_t dsn_pack_tiles(int32_t co, int32_t ci, int32_t kh, int32_t kw);

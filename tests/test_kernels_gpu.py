@@ -213,6 +213,35 @@ def test_maxpool_multi_and_backward(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 24, 24, 32), (1, 64, 17, 23, 32), (8, 32, 64, 64, 64), (2, 256, 10, 10, 512)])
+def test_stride2_dgrad_depth_to_space(ops, shape, dtype):
+    """dsn_conv2d_dgrad_s2 (one 2x2 stride-1 conv over dy + depth-to-space store, weights from the WeightBank's out_dgrad_s2
+    layout) against ATen's conv input gradient -- even and odd map sizes, plain and accumulating stores."""
+    n, ci, h, w, co = shape
+    conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(rnd((co, ci, 3, 3), 70, -0.2, 0.2))
+    bank = ops.WeightBank([conv], [ci], dtype, "cuda")
+    bank.pack()
+    assert bank.dgrad_s2[0] is not None
+    ho, wo = ops.conv_out_hw(h, w, 3, 2, 1, 1)
+    gy = rnd((n, co, ho, wo), 71)
+    xr = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(xr, q(conv.weight.detach().cpu(), dtype), None, 2, 1).backward(q(gy, dtype))
+    gyd = to_dev(ops, gy, dtype)
+    dx = ops.new_act(n, ci, h, w, dtype, "cuda")
+    ops.conv2d_dgrad_s2(gyd, bank.dgrad_s2[0], dx, ops.conv_params(3, 2, 1, 1))
+    assert_close(dx.float().cpu(), xr.grad, TOL[dtype], "dgrad_s2")
+    ref = ops.new_act(n, ci, h, w, dtype, "cuda")
+    ops.conv2d_dgrad(gyd, bank.dgrad[0], ref, ops.conv_params(3, 2, 1, 1))
+    assert_close(dx.float().cpu(), ref.float().cpu(), 1e-5 if dtype == torch.float32 else 1e-2, "dgrad_s2 vs parity-class dgrad")
+    base = rnd((n, ci, h, w), 72)
+    acc = to_dev(ops, base, dtype)
+    ops.conv2d_dgrad_s2(gyd, bank.dgrad_s2[0], acc, ops.conv_params(3, 2, 1, 1, accumulate=True))
+    assert_close(acc.float().cpu(), xr.grad + q(base, dtype), 2 * TOL[dtype], "dgrad_s2 accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pack_weights(ops, dtype):
     wt, sc = rnd((24, 12, 3, 3), 12), rnd((24,), 13, 0.5, 1.5)
     wp = ops.pack_weight_fwd(wt.cuda(), dtype, sc.cuda(), ci_pad=16)
