@@ -86,7 +86,7 @@ template <int BM, int BN> constexpr int smem_bytes() {
     return loop > epi ? loop : epi;
 }
 
-template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD, bool PAR>
+template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD, bool PAR, int NST = 3>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
                                                     T* __restrict__ dst, float* __restrict__ stats, const BnAcc fin, const Geom g) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 
     // three register stages: chunks i+1, i+2, i+3 are in flight while chunk i is on the matrix cores (the loads of a
     // chunk get two full iterations to land; one stage left every iteration waiting ~0.5 us for L2)
-    u32x4 ra0[AR], rb0[BR], ra1[AR], rb1[BR], ra2[AR], rb2[BR];
+    u32x4 rga[NST][AR], rgb[NST][BR];      // NST register stages (6 was measured: slower everywhere -- the registers cost occupancy)
 
     // source address of destination row i for tap (ky, kx); nullptr when the tap falls outside the map
     auto src_row = [&](int i, int ky, int kx) -> const T* {
@@ -296,25 +296,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
         }
     };
 
-    // ---- main loop: 3 register stages feeding 2 LDS buffers, one barrier per chunk ---------------------------------------
-#define DSN_STEP(RA_FREE, RB_FREE, RA_NEXT, RB_NEXT, IT)                                   \
-    if ((IT) < nchunks) {                                                                  \
-        if ((IT) + 3 < nchunks) load_chunk((IT) + 3, RA_FREE, RB_FREE);                    \
-        compute((IT) & 1);                                                                 \
-        if ((IT) + 1 < nchunks) store_chunk(((IT) + 1) & 1, RA_NEXT, RB_NEXT);             \
-        __syncthreads();                                                                   \
-    }
-    if (nchunks > 0) load_chunk(0, ra0, rb0);
-    if (nchunks > 1) load_chunk(1, ra1, rb1);
-    if (nchunks > 2) load_chunk(2, ra2, rb2);
-    if (nchunks > 0) store_chunk(0, ra0, rb0);
+    // ---- main loop: NST register stages feeding 2 LDS buffers, one barrier per chunk ------------------------------------
+    // step i: loads of chunk i+NST go into the stage that held chunk i (already in LDS), chunk i runs on the matrix cores,
+    // chunk i+1 moves from its stage into the other LDS buffer.
+#pragma unroll
+    for (int s = 0; s < NST; ++s)
+        if (nchunks > s) load_chunk(s, rga[s], rgb[s]);
+    if (nchunks > 0) store_chunk(0, rga[0], rgb[0]);
     __syncthreads();
-    for (int it = 0; it < nchunks; it += 3) {
-        DSN_STEP(ra0, rb0, ra1, rb1, it)
-        DSN_STEP(ra1, rb1, ra2, rb2, it + 1)
-        DSN_STEP(ra2, rb2, ra0, rb0, it + 2)
+    for (int it = 0; it < nchunks; it += NST) {
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            const int i = it + s;
+            if (i < nchunks) {
+                if (i + NST < nchunks) load_chunk(i + NST, rga[s], rgb[s]);
+                compute(i & 1);
+                if (i + 1 < nchunks) store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST]);
+                __syncthreads();
+            }
+        }
     }
-#undef DSN_STEP
 
     // ---- epilogue: stage act(acc + bias) as fp32 [BM][BN + CPAD] ------------------------------------------------
     constexpr int LDC = BN + CPAD;
