@@ -543,9 +543,9 @@ inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
 
 inline int choose_split(const WGeom& g, bool alltaps = false) {
     const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
-    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
     static const int scap = [] { const char* e = getenv("DSN_WGRAD_SCAP"); return e ? atoi(e) : 256; }();
-    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 512; }();
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 1024; }();
     const int tgt = alltaps ? target / 2 : target, cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
     int64_t s = (tgt + base - 1) / base;
     const int64_t smax = (g.P + minpx - 1) / minpx;
