@@ -76,14 +76,41 @@ struct Cand {                      // one (offset, anchor, target) candidate
     float dbox[4];                 // d(1 - ciou)/d(raw x,y,w,h)
 };
 
-// per-level accumulators: [0] n active, [1] sum(1 - ciou), [2] sum class BCE, [3] sum objectness BCE
-__global__ __launch_bounds__(LT) void det_match_kernel(const float* __restrict__ p, const float* __restrict__ targets,
-                                                       DetParams q, Cand* __restrict__ cands, float* __restrict__ dcls,
-                                                       int32_t* __restrict__ owner, float* __restrict__ acc) {
+// All pyramid levels run in ONE launch per stage (blockIdx.y = level): 5 launches per step instead of 14.
+constexpr int MAX_MB = 16;         // match blocks per level
+struct DetLevel {
+    const float* p;                // raw predictions of the level
+    float* dp;                     // their gradient
+    Cand* cands;
+    float* dcls;
+    int32_t* owner;
+    float* partial;                // [<= 1024] objectness block sums
+    float* mpart;                  // [MAX_MB][3] match block sums (n active, sum(1 - ciou), sum class BCE)
+    float* acc;                    // [4]: n active, sum(1 - ciou), sum class BCE, sum objectness BCE
+    DetParams q;
+    float obj_coef;
+    int32_t ob, mb, sb;            // blocks of the obj / match / scatter stages
+};
+struct DetLevels { DetLevel l[5]; int32_t nl; float box_coef, cls_coef; };
+
+__global__ __launch_bounds__(LT) void det_clear_kernel(const DetLevels L) {
+    const DetLevel& v = L.l[blockIdx.y];
+    const int64_t ncell = (int64_t)v.q.bs * v.q.na * v.q.ny * v.q.nx;
+    for (int64_t i = blockIdx.x * (int64_t)LT + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * LT) v.owner[i] = -1;
+}
+
+__global__ __launch_bounds__(LT) void det_match_kernel(const DetLevels L, const float* __restrict__ targets) {
+    const DetLevel& v = L.l[blockIdx.y];
+    if ((int)blockIdx.x >= v.mb) return;
+    const float* __restrict__ p = v.p;
+    const DetParams q = v.q;
+    Cand* __restrict__ cands = v.cands;
+    float* __restrict__ dcls = v.dcls;
+    int32_t* __restrict__ owner = v.owner;
     __shared__ float red[3][LT];
     const int ncand = 5 * q.na * q.nt;
     float n_act = 0.f, s_box = 0.f, s_cls = 0.f;
-    for (int id = blockIdx.x * LT + threadIdx.x; id < ncand; id += gridDim.x * LT) {
+    for (int id = blockIdx.x * LT + threadIdx.x; id < ncand; id += v.mb * LT) {
         const int o = id / (q.na * q.nt), rem = id - o * (q.na * q.nt);
         const int a = rem / q.nt, t = rem - a * q.nt;
         const float* tg = targets + (int64_t)t * 6;
@@ -156,17 +183,24 @@ __global__ __launch_bounds__(LT) void det_match_kernel(const float* __restrict__
             for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { acc[0] = red[0][0]; acc[1] = red[1][0]; acc[2] = red[2][0]; }   // launched with ONE block
+    if (threadIdx.x == 0) { v.mpart[blockIdx.x * 3] = red[0][0]; v.mpart[blockIdx.x * 3 + 1] = red[1][0]; v.mpart[blockIdx.x * 3 + 2] = red[2][0]; }
 }
 
 // objectness BCE over every cell + dense gradient initialisation; partial[blockIdx] = sum of the block's cells
-__global__ __launch_bounds__(LT) void det_obj_kernel(const float* __restrict__ p, DetParams q,
-                                                     const Cand* __restrict__ cands, const int32_t* __restrict__ owner,
-                                                     float* __restrict__ dp, float obj_coef, float* __restrict__ partial) {
+__global__ __launch_bounds__(LT) void det_obj_kernel(const DetLevels L) {
+    const DetLevel& v = L.l[blockIdx.y];
+    if ((int)blockIdx.x >= v.ob) return;
+    const float* __restrict__ p = v.p;
+    const DetParams q = v.q;
+    const Cand* __restrict__ cands = v.cands;
+    const int32_t* __restrict__ owner = v.owner;
+    float* __restrict__ dp = v.dp;
+    const float obj_coef = v.obj_coef;
+    float* __restrict__ partial = v.partial;
     __shared__ float red[LT];
     const int64_t ncell = (int64_t)q.bs * q.na * q.ny * q.nx;
     float s = 0.f;
-    for (int64_t cell = blockIdx.x * (int64_t)LT + threadIdx.x; cell < ncell; cell += (int64_t)gridDim.x * LT) {
+    for (int64_t cell = blockIdx.x * (int64_t)LT + threadIdx.x; cell < ncell; cell += (int64_t)v.ob * LT) {
         const int own = owner[cell];
         const float tobj = own >= 0 ? fmaxf(cands[own].iou, 0.f) : 0.f;
         float dx;
@@ -184,16 +218,21 @@ __global__ __launch_bounds__(LT) void det_obj_kernel(const float* __restrict__ p
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// add the (scaled) box / class gradients of active candidates; also folds the objectness partial sums (block 0)
-__global__ __launch_bounds__(LT) void det_scatter_kernel(DetParams q, const Cand* __restrict__ cands,
-                                                         const float* __restrict__ dcls, float* __restrict__ dp,
-                                                         float box_coef, float cls_coef, float* __restrict__ acc,
-                                                         const float* __restrict__ partial, int npartial) {
+// add the (scaled) box / class gradients of active candidates; block 0 of a level also folds its partial sums into acc
+__global__ __launch_bounds__(LT) void det_scatter_kernel(const DetLevels L) {
+    const DetLevel& v = L.l[blockIdx.y];
+    if ((int)blockIdx.x >= v.sb) return;
+    const DetParams q = v.q;
+    const Cand* __restrict__ cands = v.cands;
+    const float* __restrict__ dcls = v.dcls;
+    float* __restrict__ dp = v.dp;
+    float n = 0.f, sbox = 0.f, scls = 0.f;
+    if (q.nt > 0)
+        for (int b = 0; b < v.mb; ++b) { n += v.mpart[b * 3]; sbox += v.mpart[b * 3 + 1]; scls += v.mpart[b * 3 + 2]; }   // fixed order
     const int ncand = 5 * q.na * q.nt;
-    const float n = acc[0];
-    const float kb = n > 0.f ? box_coef / n : 0.f;
-    const float kc = (n > 0.f && q.nc > 1) ? cls_coef / (n * (float)q.nc) : 0.f;
-    for (int id = blockIdx.x * LT + threadIdx.x; id < ncand; id += gridDim.x * LT) {
+    const float kb = n > 0.f ? L.box_coef / n : 0.f;
+    const float kc = (n > 0.f && q.nc > 1) ? L.cls_coef / (n * (float)q.nc) : 0.f;
+    for (int id = blockIdx.x * LT + threadIdx.x; id < ncand; id += v.sb * LT) {
         const Cand c = cands[id];
         if (c.cell < 0) continue;
         float* d = dp + (int64_t)c.cell * q.no;
@@ -203,10 +242,10 @@ __global__ __launch_bounds__(LT) void det_scatter_kernel(DetParams q, const Cand
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         double s = 0.0;
-        for (int i = threadIdx.x; i < npartial; i += 64) s += (double)partial[i];
+        for (int i = threadIdx.x; i < v.ob; i += 64) s += (double)v.partial[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-        if (threadIdx.x == 0) acc[3] = (float)s;
+        if (threadIdx.x == 0) { v.acc[0] = n; v.acc[1] = sbox; v.acc[2] = scls; v.acc[3] = (float)s; }
     }
 }
 
@@ -326,35 +365,43 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
     const int no = nc + 5;
     const int64_t ncand = (int64_t)5 * na * (nt > 0 ? nt : 1);
     char* w = (char*)workspace;
-    float* acc = (float*)w;                 // [nl][4] + ncells[nl] + balance[nl]
+    float* acc = (float*)w;                 // [nl][4]
     w += 256;
-    dsn_fill_u32(acc, 0u, 64, st);
     DetMeta meta{};
+    DetLevels L{};
+    L.nl = nl; L.box_coef = h_box * (float)bs; L.cls_coef = h_cls * (float)bs;
+    int max_ob = 1, max_mb = 1, max_sb = 1, max_cb = 1;
     for (int i = 0; i < nl; ++i) {
         meta.ncells[i] = (float)((int64_t)bs * na * ny[i] * nx[i]);
         meta.balance[i] = balance[i];
-    }
-    // small constant tables go through kernel arguments of the finalize launch below (no H2D copy: capture-safe)
-    for (int i = 0; i < nl; ++i) {
-        DetParams q{};
+        DetLevel& v = L.l[i];
+        DetParams& q = v.q;
         q.bs = bs; q.na = na; q.no = no; q.nc = nc; q.ny = ny[i]; q.nx = nx[i]; q.nt = nt;
         q.anchor_t = anchor_t; q.cls_pw = cls_pw; q.obj_pw = obj_pw; q.cp = cp; q.cn = cn;
         for (int k = 0; k < 2 * na; ++k) q.anchors[k] = anchors[i * na * 2 + k];
-        Cand* cands = (Cand*)w;                          w += ncand * sizeof(Cand);
-        float* dcls = (float*)w;                         w += ncand * nc * 4;
-        int32_t* owner = (int32_t*)w;                    w += max_cells * 4;
-        float* partial = (float*)w;                      w += 1024 * 4;
+        v.p = p[i]; v.dp = dp[i]; v.acc = acc + i * 4;
+        v.cands = (Cand*)w;                              w += ncand * sizeof(Cand);
+        v.dcls = (float*)w;                              w += ncand * nc * 4;
+        v.owner = (int32_t*)w;                           w += max_cells * 4;
+        v.partial = (float*)w;                           w += 1024 * 4;      // [0, 960): objectness block sums, [960, 1008): match sums
         const int64_t ncell = (int64_t)bs * na * ny[i] * nx[i];
-        dsn_fill_u32(owner, 0xFFFFFFFFu, ncell, st);                 // -1
-        if (nt > 0)
-            hipLaunchKernelGGL(det_match_kernel, dim3(1), dim3(LT), 0, st, p[i], targets, q, cands, dcls, owner, acc + i * 4);
-        const int ob = lgrid(ncell, 1024);
-        const float obj_coef = h_obj * balance[i] * (float)bs / (float)ncell;
-        hipLaunchKernelGGL(det_obj_kernel, dim3(ob), dim3(LT), 0, st, p[i], q, cands, owner, dp[i], obj_coef, partial);
-        hipLaunchKernelGGL(det_scatter_kernel, dim3(nt > 0 ? lgrid(ncand, 64) : 1), dim3(LT), 0, st, q, cands, dcls, dp[i],
-                           h_box * (float)bs, h_cls * (float)bs, acc + i * 4, partial, ob);
-        DSN_LAUNCH_CHECK("det_loss level");
+        v.ob = lgrid(ncell, 960);
+        v.mpart = v.partial + 960;                       // 64 floats at the tail of the 1024-float block: MAX_MB*3 = 48
+        v.mb = nt > 0 ? lgrid(ncand, MAX_MB) : 0;
+        v.sb = nt > 0 ? lgrid(ncand, 64) : 1;
+        v.obj_coef = h_obj * balance[i] * (float)bs / (float)ncell;
+        max_ob = v.ob > max_ob ? v.ob : max_ob;
+        max_mb = v.mb > max_mb ? v.mb : max_mb;
+        max_sb = v.sb > max_sb ? v.sb : max_sb;
+        const int cb = lgrid(ncell, 64);
+        max_cb = cb > max_cb ? cb : max_cb;
     }
+    // (no memset nodes: see common.h dsn_fill_u32) owner = -1 for every level, then match -> obj -> scatter, levels in gridDim.y
+    hipLaunchKernelGGL(det_clear_kernel, dim3(max_cb, nl), dim3(LT), 0, st, L);
+    if (nt > 0) hipLaunchKernelGGL(det_match_kernel, dim3(max_mb, nl), dim3(LT), 0, st, L, targets);
+    hipLaunchKernelGGL(det_obj_kernel, dim3(max_ob, nl), dim3(LT), 0, st, L);
+    hipLaunchKernelGGL(det_scatter_kernel, dim3(max_sb, nl), dim3(LT), 0, st, L);
+    DSN_LAUNCH_CHECK("det_loss");
     hipLaunchKernelGGL(det_finalize_kernel, dim3(1), dim3(1), 0, st, acc, nl, meta, h_box, h_obj, h_cls, nc, bs, out);
     DSN_LAUNCH_CHECK("det_loss finalize");
     return DSN_OK;
