@@ -287,3 +287,58 @@ def test_graph_replay_equals_eager_training(net, fused):
     for c, w0, f, cp in list(zip(convs, snap, bank.fwd, mg.__dict__["_dsn_bank_pads"]))[::7]:
         assert torch.equal(f, ops.pack_weight_fwd(w0, f.dtype, None, cp)), "weight bank is stale after a replay"
         assert not torch.equal(c.weight.detach(), w0), "the optimizer step inside the graph did not update the weights"
+
+
+def test_config5_desenet_m_train_step_vs_oracle():
+    """BASELINE.json config 5's graph (DeSeNet-m: the same yaml at width x1.0 / depth x1.0 -- channels up to 1024, K up to
+    9216, 24 bottlenecks) through one fp32 training step against the CPU oracle on the same hash-filled weights: forward
+    outputs (batch statistics), both losses and every parameter gradient.  128x128 / batch 2 keeps the oracle to seconds;
+    the 1280x1280 / batch 4 shapes of the config only change the map sizes, which the kernel tests sweep."""
+    import os
+    import yaml
+    from desenet_amd import hip_ops  # noqa: F401  (fails loudly without the .so)
+    from desenet_amd.core.models.yolo import Model
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from desenet_amd.synth import hash_fill_state_dict
+    from oracle import desenet_ref as R
+    from oracle import loss_ref
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "desenet_amd", "cfg", "desenet_m.yaml")
+    cfg = yaml.safe_load(open(path))
+    m = Model(path, ch=3, nc=6)
+    sd = m.state_dict()
+    hash_fill_state_dict(sd)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    size, bs = 128, 2
+    m.hyp = dict(loss_ref.scale_hyp(6, size), label_smoothing=0.0)
+    x = synth_images(bs, size, 31)
+    det_t, seg_t = synth_targets(bs, size, 31)
+    # oracle
+    is_p = lambda k: "running" not in k and "num_batches" not in k and "anchor" not in k
+    sdo = {k: v.detach().cpu().clone().requires_grad_(is_p(k) and v.dtype.is_floating_point) for k, v in sd.items()}
+    raws, seg, _ = R.forward(cfg, sdo, x, training=True)
+    total, *_ = loss_ref.step_loss(raws, seg, det_t, seg_t, sdo["model.25.anchors"], 6, size)
+    total.backward()
+    # HIP
+    det_pred, seg_pred = m(x.cuda())
+    det_loss, _ = ComputeLoss(m)(det_pred, det_t.cuda())
+    seg_loss = SegmentationLosses()(seg_pred, seg_t.cuda())
+    loss = det_loss * 0.14 + seg_loss * 1.0
+    loss.backward()
+    for a, b in zip(det_pred, raws):
+        assert_close(a.detach().cpu(), b.detach(), 2e-3, "raw detect output")
+    assert_close(seg_pred.detach().cpu(), seg.detach(), 2e-3, "seg logits")
+    assert_close(loss.detach().cpu().reshape(-1), total.detach().reshape(-1), 2e-3, "total loss")
+    bad = []
+    gn_h = gn_o = 0.0
+    for k, p in m.named_parameters():
+        go = sdo[k].grad
+        if go is None and p.grad is None:
+            continue
+        gh = torch.zeros_like(p) if p.grad is None else p.grad
+        go = torch.zeros_like(sdo[k]) if go is None else go
+        gn_h += float(gh.double().pow(2).sum()); gn_o += float(go.double().pow(2).sum())
+        if go.abs().max() > 1e-6 and rel_err(gh.cpu(), go) > 5e-2:
+            bad.append((k, rel_err(gh.cpu(), go)))
+    assert abs(gn_h ** 0.5 - gn_o ** 0.5) <= 2e-2 * gn_o ** 0.5, (gn_h, gn_o)
+    assert len(bad) <= 3, bad[:10]          # tiny batch-statistics maps (4x4, 2 images) amplify fp32 rounding on a few tensors
