@@ -52,16 +52,17 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 8 train / 16 infer)")
     ap.add_argument("--img", type=int, default=640)
+    ap.add_argument("--model", choices=["s", "m"], default="s", help="s = DeSeNet-s (configs 1-4, the headline), m = config 5's graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--eager", action="store_true", help="train: launch every kernel from Python instead of hipGraph replay")
     return ap.parse_args()
 
 
-def build_model(device):
+def build_model(device, which="s"):
     from desenet_amd.core.models.yolo import Model
     from desenet_amd.synth import synthetic_checkpoint
-    m = Model("desenet_s.yaml", ch=3, nc=6)
+    m = Model(f"desenet_{which}.yaml", ch=3, nc=6)
     sd = m.state_dict()
     synthetic_checkpoint(sd)
     m.load_state_dict(sd)
@@ -191,7 +192,7 @@ def main():
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype or ("bf16" if train else "fp32")]
     batch = a.batch or (8 if train else 16)
     desenet_amd.set_compute_dtype(dtype)
-    model = build_model(dev)
+    model = build_model(dev, a.model)
 
     if train:
         from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
@@ -293,12 +294,12 @@ def main():
             log(f"CPU baseline on {host_threads()} threads ...")
             cpu = cpu_baseline_train(a.img) if train else cpu_baseline_infer(a.img)
         if train:
-            metric = "images/sec (640x640) train fwd+bwd"
-            workload = (f"config {'3' if world == 1 else '4'}: DeSeNet-s training step (fwd + det/seg loss + bwd + "
+            metric = f"images/sec ({a.img}x{a.img}) train fwd+bwd"
+            workload = (f"config {('3' if world == 1 else '4') if a.model == 's' else '5'}: DeSeNet-{a.model} training step (fwd + det/seg loss + bwd + "
                         f"{'RCCL flat all-reduce + ' if world > 1 else ''}SGD), batch {batch}/GPU, {a.img}x{a.img}, "
                         f"{mode_note}")
         else:
-            metric = "images/sec (640x640) inference fwd+NMS"
+            metric = f"images/sec ({a.img}x{a.img}) inference fwd+NMS"
             workload = f"config 2: DeSeNet-s fused inference (fwd + Detect decode + NMS), batch {batch}, {a.img}x{a.img}"
         out = {
             "metric": metric, "value": world * batch * a.steps / elapsed, "unit": "images/sec", "n_gpus": world,

@@ -85,7 +85,7 @@ def load_bn_calibration(sd: dict, path: str = BN_CALIB) -> dict:
     """
     with np.load(path) as z:
         for k in z.files:
-            if k in sd:
+            if k in sd and tuple(sd[k].shape) == tuple(z[k].shape):     # (other widths, e.g. DeSeNet-m, keep the hash fill)
                 with torch.no_grad():
                     sd[k].copy_(torch.from_numpy(z[k]))
     return sd
