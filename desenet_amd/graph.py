@@ -37,12 +37,13 @@ class GraphedTrainStep:
         self.pool = torch.cuda.graph_pool_handle()
         self.ga, self.gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.multi else None)
         with torch.no_grad():
-            with torch.cuda.graph(self.ga, pool=self.pool):
+            # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
+            with torch.cuda.graph(self.ga, pool=self.pool, capture_error_mode="thread_local"):
                 self.loss = self._body()
                 if not self.multi:
                     self.opt.step()
             if self.multi:
-                with torch.cuda.graph(self.gb, pool=self.pool):
+                with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
                     self.opt.step()
         torch.cuda.synchronize(dev)
 
