@@ -56,6 +56,8 @@ PROTOTYPES = {
     "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
     "dsn_pack_weight_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dsn_box_iou": (i32, [vp, i32, vp, i32, vp, vp]),
+    "dsn_seg_eval_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "dsn_sgd_chunk": (i32, []),
     "dsn_sgd_step": (i32, [vp, i32, i32, vp, vp]),
     "dsn_pack_tiles": (i32, [i32, i32, i32, i32]),

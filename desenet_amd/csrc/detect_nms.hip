@@ -269,6 +269,66 @@ inline int64_t key_cap(int32_t n, int32_t nc, int32_t multi_label) {
     return next_pow2((int64_t)n * (multi_label ? nc : 1));
 }
 
+
+// ---- evaluation arithmetic (scripts/val.py:101-122, core/utils/metrics.py:247-269,350-388) -----------------------------------
+// IoU matrix of xyxy boxes, same operation order as the reference's box_iou (this file is compiled with -ffp-contract=off):
+// area = (x2-x1)*(y2-y1); inter = clamp(min(x2)-max(x1), 0) * clamp(min(y2)-max(y1), 0); iou = inter / (a1 + a2 - inter)
+__global__ void box_iou_kernel(const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, int N, int M) {
+    const int64_t total = (int64_t)N * M;
+    GRID_STRIDE(i, total) {
+        const int n = (int)(i / M), m = (int)(i - (int64_t)n * M);
+        const float ax1 = b1[n * 4], ay1 = b1[n * 4 + 1], ax2 = b1[n * 4 + 2], ay2 = b1[n * 4 + 3];
+        const float bx1 = b2[m * 4], by1 = b2[m * 4 + 1], bx2 = b2[m * 4 + 2], by2 = b2[m * 4 + 3];
+        const float a1 = (ax2 - ax1) * (ay2 - ay1), a2 = (bx2 - bx1) * (by2 - by1);
+        const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+        const float inter = w * h;
+        out[i] = inter / (a1 + a2 - inter);
+    }
+}
+
+// Segmentation counters over a batch of NCHW logits: predict = first arg-max over the class axis; out (int64):
+// [0] pixels with target > 0 and predict == target, [1] pixels with target > 0, then for the nclass-1 bins of
+// np.histogram(range=(1, nclass)) -- value v in [1, nclass], v == nclass falling into the last bin -- [2 + b] intersection
+// (predict == target == v), [2 + nb + b] prediction area, [2 + 2nb + b] label area.
+constexpr int SEG_MAXBINS = 64;
+__global__ __launch_bounds__(256) void seg_eval_counts_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                              int C, int64_t HW, int64_t total, int nclass,
+                                                              unsigned long long* __restrict__ out) {
+    __shared__ unsigned int h[2 + 3 * SEG_MAXBINS];
+    const int nb = nclass - 1;
+    for (int i = threadIdx.x; i < 2 + 3 * nb; i += 256) h[i] = 0u;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / HW, px = i - n * HW;
+        const float* l = logits + n * C * HW + px;
+        float best = l[0];
+        int pred = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = l[c * HW];
+            if (v > best) { best = v; pred = c; }
+        }
+        const int64_t t = target[i];
+        if (t > 0) {
+            atomicAdd(&h[1], 1u);
+            if (pred == t) atomicAdd(&h[0], 1u);
+        }
+        if (nb > 0) {
+            if (pred >= 1 && pred <= nclass) {
+                const int b = pred - 1 < nb ? pred - 1 : nb - 1;
+                atomicAdd(&h[2 + nb + b], 1u);
+                if (pred == t) atomicAdd(&h[2 + b], 1u);
+            }
+            if (t >= 1 && t <= nclass) {
+                const int b = (int)(t - 1 < nb ? t - 1 : nb - 1);
+                atomicAdd(&h[2 + 2 * nb + b], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 + 3 * nb; i += 256)
+        if (h[i]) atomicAdd(&out[i], (unsigned long long)h[i]);
+}
+
 }  // namespace
 
 extern "C" int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, int64_t pred_rows, int64_t row_off,
@@ -327,5 +387,30 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(256), (size_t)max_det * 5 * sizeof(float), st, pred, n, nc,
                        keys, cap, counts, iou_thres, agnostic, max_det, out, out_count);
     DSN_LAUNCH_CHECK("nms greedy");
+    return DSN_OK;
+}
+
+extern "C" int dsn_box_iou(const float* boxes1, int32_t n, const float* boxes2, int32_t m, float* out, void* stream) {
+    DSN_CHECK_ARG(n >= 0 && m >= 0 && (n == 0 || boxes1) && (m == 0 || boxes2) && ((int64_t)n * m == 0 || out),
+                  "box_iou: invalid arguments");
+    if ((int64_t)n * m == 0) return DSN_OK;
+    hipLaunchKernelGGL(box_iou_kernel, dim3(ew_grid((int64_t)n * m)), dim3(256), 0, (hipStream_t)stream, boxes1, boxes2, out, n, m);
+    DSN_LAUNCH_CHECK("box_iou");
+    return DSN_OK;
+}
+
+// out: int64[2 + 3*(nclass-1)], overwritten.
+extern "C" int dsn_seg_eval_counts(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
+                                   int32_t nclass, int64_t* out, void* stream) {
+    DSN_CHECK_ARG(logits && target && out && n > 0 && c > 0 && h > 0 && w > 0 && nclass >= 1 && nclass - 1 <= SEG_MAXBINS,
+                  "seg_eval_counts: invalid arguments (at most %d classes)", SEG_MAXBINS + 1);
+    hipStream_t st = (hipStream_t)stream;
+    const int words = 2 * (2 + 3 * (nclass - 1));
+    dsn_fill_u32(out, 0u, words, st);
+    const int64_t HW = (int64_t)h * w, total = (int64_t)n * HW;
+    int64_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(seg_eval_counts_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, st, logits, target, c, HW, total,
+                       nclass, (unsigned long long*)out);
+    DSN_LAUNCH_CHECK("seg_eval_counts");
     return DSN_OK;
 }

@@ -708,3 +708,29 @@ def seg_ce(logits, target, ignore_index=-1, want_grad=True):
     _lib.check(L.dsn_seg_ce(lg.data_ptr(), tg.data_ptr(), n, c, h, w, int(ignore_index), out.data_ptr(), _p(dl),
                             ws.data_ptr(), nbytes, stream_ptr()), "seg_ce")
     return out, dl
+
+
+# ------------------------------------------------------------------------------------------------ evaluation arithmetic
+def box_iou(box1: torch.Tensor, box2: torch.Tensor) -> torch.Tensor:
+    """IoU matrix [N, M] of fp32 xyxy boxes on the device (reference operation order)."""
+    _require_gpu(box1)
+    a = box1 if (box1.dtype == torch.float32 and box1.is_contiguous()) else box1.float().contiguous()
+    b = box2 if (box2.dtype == torch.float32 and box2.is_contiguous()) else box2.float().contiguous()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().dsn_box_iou(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), stream_ptr()),
+               "box_iou")
+    return out
+
+
+def seg_eval_counts(logits: torch.Tensor, target: torch.Tensor, nclass: int):
+    """(correct, labelled, inter[nclass-1], pred[nclass-1], lab[nclass-1]) -- ints / int64 numpy arrays (one host sync)."""
+    _require_gpu(logits)
+    lg = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
+    tg = target if (target.dtype == torch.int64 and target.is_contiguous()) else target.long().contiguous()
+    n, c, h, w = lg.shape
+    nb = nclass - 1
+    out = torch.empty(2 + 3 * nb, dtype=torch.int64, device=lg.device)
+    _lib.check(_lib.lib().dsn_seg_eval_counts(lg.data_ptr(), tg.to(lg.device).data_ptr(), n, c, h, w, nclass, out.data_ptr(),
+                                              stream_ptr()), "seg_eval_counts")
+    v = out.cpu().numpy()
+    return int(v[0]), int(v[1]), v[2:2 + nb].copy(), v[2 + nb:2 + 2 * nb].copy(), v[2 + 2 * nb:2 + 3 * nb].copy()

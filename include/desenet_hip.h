@@ -271,6 +271,15 @@ int64_t dsn_seg_ce_workspace_bytes(void);
 int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
                int32_t ignore_index, float* out, float* dlogits, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- evaluation arithmetic (scripts/val.py:101-122; core/utils/metrics.py:247-269,350-388) ----------------------------
+ * dsn_box_iou: out[n][m] = IoU of xyxy boxes, the reference's operation order (bit-exact matching in process_batch).
+ * dsn_seg_eval_counts: over NCHW fp32 logits and int64 targets: out (int64[2 + 3*(nclass-1)]) = {correct, labelled,
+ *   intersection[b], prediction area[b], label area[b]} with predict = first arg-max over classes and the nclass-1 bins of
+ *   np.histogram(range=(1, nclass)) -- what batch_pix_accuracy / batch_intersection_union count on the host. */
+int dsn_box_iou(const float* boxes1, int32_t n, const float* boxes2, int32_t m, float* out, void* stream);
+int dsn_seg_eval_counts(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
+                        int32_t nclass, int64_t* out, void* stream);
+
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 /* dst[i] = (dtype) src[i]  (flat fp32 master -> bf16 copy) */
 int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream);

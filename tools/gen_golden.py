@@ -427,8 +427,71 @@ def gen_nms():
     np.savez_compressed(os.path.join(OUT, "nms.npz"), **s)
 
 
+def gen_metrics():
+    """Reference evaluation arithmetic: val.py process_batch, metrics.py ap_per_class / compute_ap and
+    the two segmentation counters, run on seeded synthetic predictions / labels."""
+    import importlib
+    for name in ["pycocotools", "pycocotools.coco", "pycocotools.cocoeval"]:
+        sys.modules.setdefault(name, um.MagicMock())
+    from core.utils import metrics as M          # (general was imported first above: the two import each other)
+    V = importlib.import_module("scripts.val")
+    s = {}
+    rng = np.random.RandomState(11)
+    iouv = torch.linspace(0.5, 0.95, 10)
+
+    def boxes(n, lo=0.0, hi=600.0):
+        xy = rng.uniform(lo, hi, (n, 2))
+        wh = rng.uniform(10, 120, (n, 2))
+        return np.concatenate([xy, xy + wh], 1).astype(np.float32)
+
+    def det_case(nd, nl, jitter):
+        lab_box = boxes(nl)
+        lab_cls = rng.randint(0, 6, (nl, 1)).astype(np.float32)
+        labels = np.concatenate([lab_cls, lab_box], 1)
+        idx = rng.randint(0, max(nl, 1), nd) if nl else np.zeros(nd, int)
+        db = (lab_box[idx] + rng.normal(0, jitter, (nd, 4))).astype(np.float32) if nl else boxes(nd)
+        dc = np.where(rng.rand(nd) < 0.8, lab_cls[idx, 0] if nl else 0, rng.randint(0, 6, nd)).astype(np.float32)
+        conf = rng.uniform(0.01, 1.0, nd).astype(np.float32)
+        return np.concatenate([db, conf[:, None], dc[:, None]], 1), labels
+
+    stats = []
+    for i, (nd, nl, jit) in enumerate([(40, 12, 6.0), (300, 30, 15.0), (7, 1, 2.0), (25, 9, 0.0), (60, 20, 30.0)]):
+        det, lab = det_case(nd, nl, jit)
+        if i == 3:
+            det[5:10] = det[0:5]          # exact duplicates: equal IoUs for the same label
+        correct = V.process_batch(torch.from_numpy(det), torch.from_numpy(lab), iouv)
+        s[f"pb{i}/det"], s[f"pb{i}/lab"], s[f"pb{i}/correct"] = det, lab, npy(correct)
+        stats.append((npy(correct), det[:, 4], det[:, 5], lab[:, 0]))
+    tp, conf, pcls, tcls = [np.concatenate(x, 0) for x in zip(*stats)]
+    p, r, ap, f1, cls = M.ap_per_class(tp, conf, pcls, tcls, plot=False, names={i: str(i) for i in range(6)})
+    s["ap/tp"], s["ap/conf"], s["ap/pcls"], s["ap/tcls"] = tp, conf, pcls, tcls
+    s["ap/p"], s["ap/r"], s["ap/ap"], s["ap/f1"], s["ap/cls"] = p, r, ap, f1, cls
+    # a class with labels but no predictions and one with predictions but no labels
+    tcls2 = np.concatenate([tcls, np.full(5, 7.0)])
+    pcls2 = np.where(pcls == 2, 9.0, pcls)
+    p, r, ap, f1, cls = M.ap_per_class(tp, conf, pcls2, tcls2, plot=False, names={i: str(i) for i in range(10)})
+    s["ap2/pcls"], s["ap2/tcls"] = pcls2, tcls2
+    s["ap2/p"], s["ap2/r"], s["ap2/ap"], s["ap2/f1"], s["ap2/cls"] = p, r, ap, f1, cls
+    for j, (rec, prec) in enumerate([(np.array([0.1, 0.4, 0.4, 0.8]), np.array([1.0, 0.5, 0.66, 0.4])),
+                                     (np.array([]), np.array([])), (np.array([1.0]), np.array([1.0]))]):
+        a, mpre, mrec = M.compute_ap(rec, prec)
+        s[f"cap{j}/rec"], s[f"cap{j}/prec"], s[f"cap{j}/ap"] = rec, prec, np.array(a)
+    for j, (shape, ncls) in enumerate([((2, 3, 24, 32), 3), ((1, 2, 17, 9), 2), ((3, 5, 16, 16), 5)]):
+        logits = torch.from_numpy(rng.normal(0, 1, shape).astype(np.float32))
+        if j == 0:
+            logits[:, 1] = logits[:, 2]     # exact ties between classes: torch.max keeps the first
+        target = torch.from_numpy(rng.randint(0, ncls, (shape[0],) + shape[2:]).astype(np.int64))
+        correct, labeled = M.batch_pix_accuracy(logits, target)
+        inter, union = M.batch_intersection_union(logits, target, ncls)
+        s[f"seg{j}/logits"], s[f"seg{j}/target"], s[f"seg{j}/ncls"] = npy(logits), npy(target), np.array(ncls)
+        s[f"seg{j}/correct"], s[f"seg{j}/labeled"] = np.array(correct), np.array(labeled)
+        s[f"seg{j}/inter"], s[f"seg{j}/union"] = np.asarray(inter), np.asarray(union)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **s)
+    print("metrics:", len(s), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["calib", "modules", "net", "train", "nms"]
+    which = sys.argv[1:] or ["calib", "modules", "net", "train", "nms", "metrics"]
     if "calib" in which:
         gen_calibration()
     if "modules" in which:
@@ -440,3 +503,5 @@ if __name__ == "__main__":
         gen_train(m)
     if "nms" in which:
         gen_nms()
+    if "metrics" in which:
+        gen_metrics()
