@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--model", choices=["s", "m"], default="s", help="s = DeSeNet-s (configs 1-4, the headline), m = config 5's graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-ema", action="store_true", help="train: leave out the rank-0 ModelEMA update (train.py:374)")
     ap.add_argument("--eager", action="store_true", help="train: launch every kernel from Python instead of hipGraph replay")
     return ap.parse_args()
 
@@ -205,8 +206,13 @@ def main():
         from desenet_amd.optim import FusedSGD
         opt = FusedSGD(sgd_param_groups(model), lr=0.01, momentum=0.937, nesterov=True)     # torch.optim.SGD math, one launch
         compute_loss, compute_seg_loss = ComputeLoss(model), SegmentationLosses()
-        x = synth_images(batch, a.img, 3 + rank).to(dev)
+        # the loader's product: a uint8 NCHW batch on the device; its `.float() / 255` (train.py:329) is folded into Focus
+        x = (synth_images(batch, a.img, 3 + rank) * 255.0).round().to(torch.uint8).to(dev)
         det_t, seg_t = synth_targets(batch, a.img, 3 + rank)
+        ema = None
+        if rank == 0 and not a.no_ema:           # train.py:179: ModelEMA on rank 0 only, updated after every optimizer step
+            from desenet_amd.core.utils.torch_utils import ModelEMA
+            ema = ModelEMA(model)
         det_t, seg_t = det_t.to(dev), seg_t.to(dev)
 
         def loss_fn(det_pred, seg_pred):
@@ -224,16 +230,18 @@ def main():
             loss_fn(det_pred, seg_pred).backward()
             flat.all_reduce()
             opt.step()
+            if ema is not None:
+                ema.update(model)
 
         step = eager_step
         mode_note = "eager launches"
         if not a.eager:
             try:
                 from desenet_amd.graph import GraphedTrainStep
-                graphed = GraphedTrainStep(model, loss_and_grads, flat, opt, x)
+                graphed = GraphedTrainStep(model, loss_and_grads, flat, opt, x, ema=ema)
                 step = lambda: graphed()
-                mode_note = ("one hipGraph replay per step (pack + fwd + losses + bwd + SGD)" if world == 1 else
-                             "two hipGraph replays per step (pack + fwd + losses + bwd | SGD) around the eager all-reduce")
+                mode_note = ("one hipGraph replay per step (u8 input /255 + pack + fwd + losses + bwd + SGD + EMA)" if world == 1 else
+                             "two hipGraph replays per step (u8 input /255 + pack + fwd + losses + bwd | SGD (+ EMA on rank 0)) around the eager all-reduce")
             except Exception as e:   # keep the bench alive, but say so loudly
                 log(f"hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
     else:

@@ -26,6 +26,11 @@ class dsn_sgd_desc(C.Structure):
                 ("group", C.c_int32), ("first_chunk", C.c_int32)]
 
 
+class dsn_ema_desc(C.Structure):
+    _fields_ = [("ema", C.c_void_p), ("model", C.c_void_p), ("numel", C.c_int64), ("first_chunk", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
 class dsn_pack_desc(C.Structure):
     _fields_ = [("w_oihw", C.c_void_p), ("out_fwd", C.c_void_p), ("out_dgrad", C.c_void_p), ("out_dgrad_s2", C.c_void_p),
                 ("co", C.c_int32),
@@ -60,15 +65,18 @@ PROTOTYPES = {
     "dsn_seg_eval_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "dsn_sgd_chunk": (i32, []),
     "dsn_sgd_step": (i32, [vp, i32, i32, vp, vp]),
+    "dsn_ema_step": (i32, [vp, i32, i32, vp, vp]),
     "dsn_pack_tiles": (i32, [i32, i32, i32, i32]),
     "dsn_pack_weights_multi": (i32, [vp, vp, i32, i32, vp]),
     "dsn_unpack_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_bn_workspace_bytes": (i64, [i32]),
     "dsn_bn_stats": (i32, [TP, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i64, vp]),
+    "dsn_channel_sum": (i32, [TP, vp, i32, vp, i64, vp]),
     "dsn_bn_act_fwd": (i32, [TP, vp, vp, i32, TP, TP, vp]),
     "dsn_bn_act_bwd": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, vp]),
     "dsn_act_bwd": (i32, [TP, TP, i32, TP, vp]),
     "dsn_focus_s2d": (i32, [vp, i32, i32, i32, i32, TP, vp]),
+    "dsn_focus_s2d_u8": (i32, [vp, i32, i32, i32, i32, TP, vp]),
     "dsn_maxpool_s1": (i32, [TP, TP, vp, i32, vp]),
     "dsn_maxpool_s1_bwd": (i32, [TP, vp, TP, i32, i32, vp]),
     "dsn_upsample_nearest2x": (i32, [TP, TP, vp]),

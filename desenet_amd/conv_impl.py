@@ -165,13 +165,6 @@ def _grad_slot(p):
     return g
 
 
-def _channel_sum(t):
-    """Per-channel sum over N,H,W of an NHWC activation (fp32 [C]) via the BN statistics kernel (mean * count)."""
-    c = t.shape[1]
-    _, _, mean, _ = ops.bn_stats(t, None, None, None, None, 0.0, 1.0)
-    return mean * float(t.shape[0] * t.shape[2] * t.shape[3])
-
-
 def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
     """Backward of conv_block_fwd.  dz: gradient of the block output (the caller routes dz to a shortcut itself).
     A dz whose rows are padded with ZEROS up to a multiple of the vector width (ops.new_act(ldc_align=...), padding cleared by
@@ -212,9 +205,9 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
         if conv.bias is not None and conv.bias.requires_grad:
             slot = _grad_slot(conv.bias)
             if slot is not None:
-                slot.add_(_channel_sum(dy))
+                ops.channel_sum(dy, out=slot, accumulate=True)
             else:
-                tape.add_grad(conv.bias, _channel_sum(dy))
+                tape.add_grad(conv.bias, ops.channel_sum(dy))
     if side is not None:
         dy.record_stream(side)     # dy is freed when this function returns; the side stream may still be reading it
         x.record_stream(side)

@@ -15,6 +15,11 @@ import torch
 from ... import hip_ops as ops
 
 
+def one_cycle(y1=0.0, y2=1.0, steps=100):
+    """Sinusoidal ramp from y1 to y2 (general.py:421-423): the lr lambda of scripts/train.py:173."""
+    return lambda x: ((1 - math.cos(x * math.pi / steps)) / 2) * (y2 - y1) + y1
+
+
 def make_divisible(x, divisor):
     return math.ceil(x / divisor) * divisor
 

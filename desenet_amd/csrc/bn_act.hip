@@ -341,6 +341,19 @@ __global__ __launch_bounds__(256) void bn_acc_finalize_kernel(const BnAcc a, con
     }
 }
 
+// Per-channel sums (conv bias gradients): out[c] (+)= sum over pixels; restores the zeros like bn_acc_finalize_kernel.
+__global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const BnAcc a, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    double s, ss;
+    bn_acc_fold(a, c, s, ss);
+    for (int r = 0; r < BN_NREP; ++r) {
+        a.acc[(size_t)r * 2 * a.C + c] = 0.0;
+        a.acc[(size_t)r * 2 * a.C + a.C + c] = 0.0;
+    }
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
 // ---- host helpers ---------------------------------------------------------------------------------------------------------
 inline bool vec_ok(const dsn_tensor* t) {
     const int vw = t->dtype == DSN_F32 ? 4 : 8;
@@ -439,6 +452,21 @@ extern "C" int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float
     hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3(cdiv(y->c, 256)), dim3(256), 0, st, f, gamma, beta, running_mean,
                        running_var, momentum, eps, scale, shift, mean, rstd);
     DSN_LAUNCH_CHECK("bn_stats finalize");
+    return DSN_OK;
+}
+
+// out[c] (+)= sum_{n,h,w} t[n,h,w,c]: the bias gradient of a biased convolution (Detect heads, seg classifier), two launches
+// and no host-framework kernels.  workspace as dsn_bn_stats.
+extern "C" int dsn_channel_sum(const dsn_tensor* t, float* out, int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+    DSN_CHECK_ARG(tensor_ok(t) && out && workspace, "channel_sum: null argument");
+    if (workspace_bytes < dsn_bn_workspace_bytes(t->c)) DSN_FAIL(DSN_EWORKSPACE, "channel_sum: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    BnAcc f{(double*)workspace, t->c, (double)npix(t)};
+    DSN_DISPATCH_DTYPE(t->dtype, T, (launch_reduce<T, false, StatsF>(vec_ok(t), t, nullptr, f, st)));
+    DSN_LAUNCH_CHECK("channel_sum reduce");
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(cdiv(t->c, 256)), dim3(256), 0, st, f, out, accumulate);
+    DSN_LAUNCH_CHECK("channel_sum finalize");
     return DSN_OK;
 }
 

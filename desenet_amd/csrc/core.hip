@@ -276,6 +276,34 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const dsn_sgd_desc* __re
     }
 }
 
+// ---- multi-tensor EMA: ModelEMA.update (torch_utils.py:330-342) for every floating-point state_dict entry in ONE launch -----
+// The reference runs `v *= d; v += (1. - d) * m` per tensor: three separately rounded fp32 operations (no FMA), with d and
+// (1 - d) computed in double on the host and cast to fp32 -- reproduced exactly (__fmul_rn / __fadd_rn never contract).
+// coef (DEVICE memory) = {(float)d, (float)(1 - d)} so a captured graph follows the decay ramp.
+__global__ __launch_bounds__(256) void ema_multi_kernel(const dsn_ema_desc* __restrict__ descs, int n,
+                                                        const float* __restrict__ coef) {
+#pragma clang fp contract(off)      // plain operators below, never fused (HIP's __fmul_rn / __fadd_rn inline as contractable ops)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_chunk <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const dsn_ema_desc d = descs[lo];
+    const float dk = coef[0], omd = coef[1];
+    const int64_t i0 = ((int64_t)blockIdx.x - d.first_chunk) * SGD_CHUNK + threadIdx.x * 4;
+    float* __restrict__ e = (float*)d.ema;
+    const float* __restrict__ m = (const float*)d.model;
+    if (i0 + 4 <= d.numel && (((uintptr_t)e | (uintptr_t)m) & 15) == 0) {
+        f32x4 ev = *reinterpret_cast<const f32x4*>(e + i0);
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(m + i0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ev[k] = ev[k] * dk + omd * mv[k];
+        *reinterpret_cast<f32x4*>(e + i0) = ev;
+    } else {
+        for (int64_t i = i0; i < i0 + 4 && i < d.numel; ++i) e[i] = e[i] * dk + omd * m[i];
+    }
+}
+
 inline int grid_for(int64_t total, int threads = 256) {
     int64_t b = (total + threads - 1) / threads;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -368,5 +396,13 @@ extern "C" int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumu
                        hipLaunchKernelGGL(copy_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                                           (const T*)x->ptr, (T*)y->ptr, npix(x), x->c, x->ldc, y->ldc, accumulate));
     DSN_LAUNCH_CHECK("copy");
+    return DSN_OK;
+}
+
+extern "C" int dsn_ema_step(const dsn_ema_desc* descs_dev, int32_t n_tensors, int32_t n_chunks, const float* coef_dev,
+                            void* stream) {
+    DSN_CHECK_ARG(descs_dev && coef_dev && n_tensors > 0 && n_chunks > 0, "ema_step: bad args");
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, descs_dev, n_tensors, coef_dev);
+    DSN_LAUNCH_CHECK("ema_step");
     return DSN_OK;
 }

@@ -86,13 +86,20 @@ template <int BM, int BN> constexpr int smem_bytes() {
     return loop > epi ? loop : epi;
 }
 
-template <typename T, int MI, int NI, int WGM, int WGN, bool VECLOAD, bool PAR, int NST = 3>
-__global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
+// LD: how a thread finds the 16 bytes it stages.  0 = per-element tap decode (channel counts that rule out vectors),
+// 1 = 16-byte vectors with a per-thread incremental (tap, channel) decode (a chunk may span taps: Cs = 16 / 32),
+// 2 = uniform tap: Cs is a multiple of the chunk, so the tap of a chunk is the same for the whole block -- tap stepping runs
+//     on the scalar unit, border handling is one bit test against a per-row tap mask built once, and an address is
+//     base + (uniform offset): ~4 VALU per load instead of ~35 (at 1.5 blocks per CU nothing hides the address arithmetic).
+template <typename T, int MI, int NI, int WGM, int WGN, int LD, bool PAR, int NST = 3>
+__global__ __launch_bounds__(256, (MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : MI * NI <= 8 ? 3 : 2)) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
                                                     T* __restrict__ dst, float* __restrict__ stats, const BnAcc fin, const Geom g) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int VEC = Mma<T>::VEC;
+    constexpr bool VECLOAD = LD >= 1, UNI = LD == 2;
+    static_assert(!(UNI && PAR), "uniform-tap staging has no parity-class form");
     constexpr int KC = ROWB / (int)sizeof(T);                  // k per chunk: 32 fp32 / 64 bf16
     constexpr int AR = (BM + 31) / 32, BR = (BN + 31) / 32;    // staged rows per thread (8 threads per row)
     __shared__ __attribute__((aligned(16))) unsigned char smem[smem_bytes<BM, BN>()];
@@ -181,9 +188,58 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 #pragma unroll
     for (int i = 0; i < AR; ++i) base_off[i] = (int32_t)((nbase[i] + (int64_t)py[i] * g.Ws + px[i]) * g.sld);
 
+    // uniform-tap staging state (LD == 2): chunks are requested in order, so (tap, chunk-in-tap) advance on the scalar unit
+    uint32_t tapmask[AR], voffA[AR], voffB[BR];
+    bool bok[BR];
+    int u_cc = 0, u_tap = 0, u_ky = 0, u_kx = 0;
+    uint32_t u_offA = 0, u_offB = 0;
+    const int u_cpt = g.Cs / KC;                                // chunks per tap
+    if (UNI) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            uint32_t mk = 0;
+            if (rowok[i]) {
+                int t = 0;
+                for (int ky = 0; ky < g.KH; ++ky)
+                    for (int kx = 0; kx < g.KW; ++kx, ++t)
+                        if ((unsigned)(py[i] + ky * g.d) < (unsigned)g.Hs && (unsigned)(px[i] + kx * g.d) < (unsigned)g.Ws)
+                            mk |= 1u << t;
+            }
+            tapmask[i] = mk;
+            voffA[i] = (uint32_t)(base_off[i] + v * VEC) * (uint32_t)sizeof(T);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int r = r0 + 32 * i, n = n0 + r;
+            bok[i] = r < BN && n < g.Cd;
+            voffB[i] = (uint32_t)(n * g.Ktot + v * VEC) * (uint32_t)sizeof(T);
+        }
+    }
+
     auto load_chunk = [&](int ch, u32x4 (&ra)[AR], u32x4 (&rb)[BR]) {
         const int k0 = ch * KC + v * VEC;
-        if (VECLOAD) {
+        if (UNI) {
+            constexpr uint32_t OOB = 0xFFFFFFF0u;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const uint32_t off = ((tapmask[i] >> u_tap) & 1u) ? voffA[i] + u_offA : OOB;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                const uint32_t off = bok[i] ? voffB[i] + u_offB : OOB;
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
+            }
+            u_offB += ROWB;
+            if (++u_cc == u_cpt) {
+                u_cc = 0;
+                ++u_tap;
+                if (++u_kx == g.KW) { u_kx = 0; ++u_ky; }
+                u_offA = (uint32_t)((u_ky * g.d * g.Ws + u_kx * g.d) * (int32_t)g.sld) * (uint32_t)sizeof(T);
+            } else {
+                u_offA += ROWB;
+            }
+        } else if (VECLOAD) {
             const bool kok = k0 < Kc;
             int tap, c, ky, kx;
             if (PAR) {
@@ -258,12 +314,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int r = r0 + 32 * i;
-            if (r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = ra[i];
+            if (BM % 32 == 0 || r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int r = r0 + 32 * i;
-            if (r < BN) *reinterpret_cast<u32x4*>(sB + (buf * BN + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = rb[i];
+            if (BN % 32 == 0 || r < BN) *reinterpret_cast<u32x4*>(sB + (buf * BN + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = rb[i];
         }
     };
 
@@ -478,12 +534,16 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd;
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
                    elems * sizeof(T), st);
+    static const bool no_uni = getenv("DSN_IGEMM_NOUNI") != nullptr;                                          // tuning knob
+    const bool uni = vec && !par && g.q == 1 && g.Cs % (ROWB / (int)sizeof(T)) == 0 && g.KH * g.KW <= 32 && !no_uni;
     if (par)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
+    else if (uni)
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
     else if (vec)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, true, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, false, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 0, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
     DSN_LAUNCH_CHECK("igemm");
     return DSN_OK;
 }

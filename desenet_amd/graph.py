@@ -18,9 +18,11 @@ from .runtime import Tape
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_and_grads: Callable, flat, optimizer, example_input: torch.Tensor, warmup: int = 3):
-        """loss_and_grads(det_out, seg_out) -> (loss tensor, d_det, d_seg): HIP kernels only (capturable)."""
-        self.model, self.loss_and_grads, self.flat, self.opt = model, loss_and_grads, flat, optimizer
+    def __init__(self, model, loss_and_grads: Callable, flat, optimizer, example_input: torch.Tensor, warmup: int = 3,
+                 ema=None):
+        """loss_and_grads(det_out, seg_out) -> (loss tensor, d_det, d_seg): HIP kernels only (capturable).
+        ema: optional desenet_amd ModelEMA, updated right after the optimizer step (scripts/train.py:374-375) inside the graph."""
+        self.model, self.loss_and_grads, self.flat, self.opt, self.ema = model, loss_and_grads, flat, optimizer, ema
         self.x = example_input.clone()
         dev = self.x.device
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -31,6 +33,8 @@ class GraphedTrainStep:
                 self._body()
                 self.flat.all_reduce()
                 self.opt.step()
+                if self.ema is not None:     # the warm-up steps are real training steps: the EMA follows them
+                    self.ema.update(model)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
 
@@ -42,9 +46,13 @@ class GraphedTrainStep:
                 self.loss = self._body()
                 if not self.multi:
                     self.opt.step()
+                    if self.ema is not None:
+                        self.ema.update(self.model)
             if self.multi:
                 with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
                     self.opt.step()
+                    if self.ema is not None:
+                        self.ema.update(self.model)
         torch.cuda.synchronize(dev)
 
     def _body(self):
@@ -65,6 +73,8 @@ class GraphedTrainStep:
     def __call__(self, x: torch.Tensor = None):
         if x is not None and x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x)
+        if self.ema is not None:
+            self.ema.tick()                      # updates += 1, decay for this step -> device
         self.ga.replay()
         if self.multi:
             self.flat.all_reduce()

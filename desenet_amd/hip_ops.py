@@ -436,6 +436,19 @@ def bn_stats(y, gamma, beta, running_mean, running_var, momentum, eps):
     return out[0], out[1], out[2], out[3]
 
 
+def channel_sum(t, out=None, accumulate=False):
+    """out[c] (+)= sum over N,H,W of an NHWC activation (fp32 [C]): bias gradients."""
+    _require_gpu(t)
+    c = t.shape[1]
+    if out is None:
+        out, accumulate = torch.empty(c, dtype=torch.float32, device=t.device), False
+    ws, nbytes = _bn_ws(c, t.device)
+    d = desc(t)
+    _lib.check(_lib.lib().dsn_channel_sum(C.byref(d), out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
+               "channel_sum")
+    return out
+
+
 def bn_act_fwd(y, scale, shift, act, residual, z):
     a, b = desc(y), desc(z)
     r = desc(residual) if residual is not None else None
@@ -461,12 +474,19 @@ def act_bwd(dz, y, act, dy):
 
 # ------------------------------------------------------------------------------------------------ data movement
 def focus_s2d(x_nchw: torch.Tensor, y):
+    """Focus slicing of an NCHW image batch.  fp32 input: already normalised; uint8 input (what the reference's loader
+    yields): `imgs.float() / 255.0` (train.py:329) is folded into the same launch."""
     _require_gpu(x_nchw)
     x = x_nchw
+    d = desc(y)
+    if x.dtype == torch.uint8:
+        x = x if x.is_contiguous() else x.contiguous()
+        n, c, h, w = x.shape
+        _lib.check(_lib.lib().dsn_focus_s2d_u8(x.data_ptr(), n, c, h, w, C.byref(d), stream_ptr()), "focus_s2d_u8")
+        return y
     if x.dtype != torch.float32 or not x.is_contiguous():
         x = x.float().contiguous()
     n, c, h, w = x.shape
-    d = desc(y)
     _lib.check(_lib.lib().dsn_focus_s2d(x.data_ptr(), n, c, h, w, C.byref(d), stream_ptr()), "focus_s2d")
     return y
 

@@ -19,6 +19,23 @@ from . import _lib
 from .hip_ops import stream_ptr
 
 
+def warmup_schedule(optimizer, ni: int, nw: int, hyp: dict, lf, epoch: int, nbs: int = 64, batch_size: int = 64) -> int:
+    """The warm-up block of scripts/train.py:332-340, verbatim arithmetic: for integrated batch index ni <= nw, group 2
+    (biases) falls from hyp['warmup_bias_lr'] to lr0*lf(epoch) while the other groups rise from 0, momentum ramps from
+    hyp['warmup_momentum'] to hyp['momentum'].  Returns `accumulate` (train.py:337).  With FusedSGD the new values reach the
+    device on the next step()/sync_hyper() -- a captured graph follows them."""
+    import numpy as np
+    accumulate = max(round(nbs / batch_size), 1)
+    if ni <= nw:
+        xi = [0, nw]
+        accumulate = max(1, np.interp(ni, xi, [1, nbs / batch_size]).round())
+        for j, x in enumerate(optimizer.param_groups):
+            x["lr"] = np.interp(ni, xi, [hyp["warmup_bias_lr"] if j == 2 else 0.0, x["initial_lr"] * lf(epoch)])
+            if "momentum" in x:
+                x["momentum"] = np.interp(ni, xi, [hyp["warmup_momentum"], hyp["momentum"]])
+    return int(accumulate)
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
         if lr < 0.0 or momentum < 0.0 or weight_decay < 0.0:

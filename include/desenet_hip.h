@@ -147,6 +147,18 @@ typedef struct {
 int32_t dsn_sgd_chunk(void);
 int dsn_sgd_step(const dsn_sgd_desc* descs_dev, int32_t n_tensors, int32_t n_chunks, const float* hyper_dev, void* stream);
 
+/* ---- ModelEMA.update (core/utils/torch_utils.py:330-342): ema = d*ema + (1-d)*model over every floating-point state_dict
+ * entry in ONE launch; chunking as dsn_sgd_step (dsn_sgd_chunk() elements per block).  coef (DEVICE memory) = {(float)d,
+ * (float)(1-d)} with d = decay*(1-exp(-updates/2000)) computed by the caller in double (torch_utils.py:323).  The three fp32
+ * operations are rounded separately, as the reference's `v *= d; v += (1. - d) * m`: results are bit-identical. */
+typedef struct {
+    void*       ema;
+    const void* model;
+    int64_t     numel;
+    int32_t     first_chunk, _pad;
+} dsn_ema_desc;
+int dsn_ema_step(const dsn_ema_desc* descs_dev, int32_t n_tensors, int32_t n_chunks, const float* coef_dev, void* stream);
+
 /* dw (packed [Co][KH][KW][Ci_pad] fp32) -> OIHW fp32 gradient, grad (+)= dw */
 int dsn_unpack_wgrad(const float* dw_packed, float* grad_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
                      int32_t ci_pad, int32_t accumulate, void* stream);
@@ -168,6 +180,10 @@ int64_t dsn_bn_workspace_bytes(int32_t c);
 int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                  float* rstd, void* workspace, int64_t workspace_bytes, void* stream);
+/* out[c] (+)= sum over n,h,w of t: bias gradient of a biased convolution (ATen convolution_backward's bias term for
+ * yolo.py:118 Detect.m and the seg classifier yolo.py:186).  workspace: as dsn_bn_stats. */
+int dsn_channel_sum(const dsn_tensor* t, float* out, int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                    void* stream);
 int dsn_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                     float* mean, float* rstd, void* stream);
@@ -197,6 +213,10 @@ int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const ds
  */
 int dsn_focus_s2d(const float* x_nchw, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
                   void* stream);
+/* the same from the data loader's uint8 NCHW batch with `imgs.float() / 255.0` (scripts/train.py:329, val.py:213,
+ * detect.py:129) folded in: y = Focus-slice((float)x / 255.0f), correctly rounded division (bit-exact vs ATen). */
+int dsn_focus_s2d_u8(const uint8_t* x_nchw, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
+                     void* stream);
 int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream);
 /* the same pool at n_out <= 3 window sizes ks[i] of ONE input (SPP: 5, 9, 13) in one launch; ys: contiguous descriptors,
  * idxs (array of int32 pointers, or NULL / NULL entries in eval) */

@@ -490,8 +490,44 @@ def gen_metrics():
     print("metrics:", len(s), "arrays")
 
 
+def gen_trainutils():
+    """Reference training-step helpers: torch_utils.ModelEMA over a tiny module whose weights move by
+    seeded deltas (three updates, starting near the top of the decay ramp and at its bottom), general.one_cycle samples."""
+    from core.utils.general import one_cycle
+    from core.utils.torch_utils import ModelEMA
+    import torch.nn as nn
+    s = {}
+    lf = one_cycle(1, 0.2, 300)
+    xs = np.array([0, 1, 3, 17, 150, 299, 300], dtype=np.float64)
+    s["one_cycle/x"], s["one_cycle/y"] = xs, np.array([lf(float(x)) for x in xs], dtype=np.float64)
+    for tag, updates0 in (("cold", 0), ("warm", 5000)):
+        torch.manual_seed(21)
+        net = nn.Sequential(nn.Conv2d(3, 5, 3), nn.BatchNorm2d(5), nn.Conv2d(5, 7, 1, bias=True))
+        with torch.no_grad():
+            net[1].running_mean.normal_()
+            net[1].running_var.uniform_(0.5, 1.5)
+        ema = ModelEMA(net, updates=updates0)
+        for k, v in net.state_dict().items():
+            s[f"ema_{tag}/init/{k}"] = v.detach().clone().numpy()
+        g = torch.Generator().manual_seed(22)
+        for step in range(3):
+            with torch.no_grad():
+                for k, v in net.state_dict().items():
+                    if v.dtype.is_floating_point:
+                        v.add_(torch.randn(v.shape, generator=g) * 0.05)
+                    else:
+                        v.add_(1)
+            for k, v in net.state_dict().items():
+                s[f"ema_{tag}/model{step}/{k}"] = v.detach().clone().numpy()
+            ema.update(net)
+        for k, v in ema.ema.state_dict().items():
+            s[f"ema_{tag}/final/{k}"] = v.detach().clone().numpy()
+        s[f"ema_{tag}/updates"] = np.int64(ema.updates)
+    np.savez_compressed(os.path.join(OUT, "trainutils.npz"), **s)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["calib", "modules", "net", "train", "nms", "metrics"]
+    which = sys.argv[1:] or ["calib", "modules", "net", "train", "nms", "metrics", "trainutils"]
     if "calib" in which:
         gen_calibration()
     if "modules" in which:
@@ -505,3 +541,5 @@ if __name__ == "__main__":
         gen_nms()
     if "metrics" in which:
         gen_metrics()
+    if "trainutils" in which:
+        gen_trainutils()

@@ -23,3 +23,8 @@ for r in step:
 print(f"step wall {(t1 - t0) / 1e6:.3f} ms, {len(step)} kernels, sum of kernel durations {busy / 1e6:.3f} ms")
 for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print(f"{d / 1e6:7.3f} ms {n:4d}x avg {d / n / 1e3:7.1f} us  {k}")
+if len(sys.argv) > 3:                      # ordered dump of the step: index, start offset, duration, grid/block, name
+    with open(sys.argv[3], "w") as f:
+        for i, r in enumerate(step):
+            s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            f.write(f"{i:4d} +{(s - t0) / 1e3:8.1f} us {(e - s) / 1e3:7.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>8} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')):>4} lds {r.get('LDS_Block_Size', '?'):>6} vgpr {r.get('VGPR_Count', '?'):>4}  {short(r['Kernel_Name'])}\n")
