@@ -63,6 +63,8 @@ PROTOTYPES = {
     "dsn_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_box_iou": (i32, [vp, i32, vp, i32, vp, vp]),
     "dsn_seg_eval_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "dsn_resize_bilinear_nchw": (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "dsn_seg_argmax_nearest": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_sgd_chunk": (i32, []),
     "dsn_sgd_step": (i32, [vp, i32, i32, vp, vp]),
     "dsn_ema_step": (i32, [vp, i32, i32, vp, vp]),

@@ -329,7 +329,87 @@ __global__ __launch_bounds__(256) void seg_eval_counts_kernel(const float* __res
         if (h[i]) atomicAdd(&out[i], (unsigned long long)h[i]);
 }
 
+// ---- evaluation resampling of the NCHW fp32 seg logits ---------------------------------------------------------------------
+// F.interpolate(pred, size, mode='bilinear', align_corners=False) (val.py:47), ATen's arithmetic: scale = in / out (fp32),
+// src = max(scale * (dst + 0.5) - 0.5, 0), i0 = min(floor(src), in - 1), i1 = i0 + (i0 < in - 1), l = src - i0, and
+// out = (1 - ly) * ((1 - lx) * v00 + lx * v01) + ly * ((1 - lx) * v10 + lx * v11).  align_corners != 0: src = dst * (in-1)/(out-1).
+__global__ __launch_bounds__(256) void resize_bilinear_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   int64_t planes, int hi, int wi, int ho, int wo, float ry,
+                                                                   float rx, int ac) {
+    const int64_t total = planes * ho * wo;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % wo);
+        const int64_t t = i / wo;
+        const int oy = (int)(t % ho);
+        const int64_t pl = t / ho;
+        float sy = ac ? ry * oy : ry * (oy + 0.5f) - 0.5f;
+        float sx = ac ? rx * ox : rx * (ox + 0.5f) - 0.5f;
+        if (!ac) { sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx; }
+        int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+        y0 = y0 < hi - 1 ? y0 : hi - 1;
+        x0 = x0 < wi - 1 ? x0 : wi - 1;
+        const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+        float ly = sy - y0, lx = sx - x0;
+        ly = ly < 0.f ? 0.f : (ly > 1.f ? 1.f : ly);
+        lx = lx < 0.f ? 0.f : (lx > 1.f ? 1.f : lx);
+        const float* p = x + pl * hi * wi;
+        const float top = (1.f - lx) * p[(int64_t)y0 * wi + x0] + lx * p[(int64_t)y0 * wi + x1];
+        const float bot = (1.f - lx) * p[(int64_t)y1 * wi + x0] + lx * p[(int64_t)y1 * wi + x1];
+        y[i] = (1.f - ly) * top + ly * bot;
+    }
+}
+
+// segoutput_to_target (plots.py:222-229): out[n][oy][ox] = (float) first arg-max over classes of logits[n][:][sy][sx] with
+// ATen's legacy 'nearest' source index: dst if out == in, dst >> 1 if out == 2*in, else min(floor(dst * (float)in / out), in-1).
+__device__ __forceinline__ int nearest_src(int dst, int in, int out, float scale) {
+    if (out == in) return dst;
+    if (out == 2 * in) return dst >> 1;
+    const int s = (int)floorf(dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+__global__ __launch_bounds__(256) void seg_argmax_nearest_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                                 int N, int C, int H, int W, int ho, int wo, float sy,
+                                                                 float sx) {
+    const int64_t total = (int64_t)N * ho * wo, HW = (int64_t)H * W;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % wo);
+        const int64_t t = i / wo;
+        const int oy = (int)(t % ho);
+        const int64_t n = t / ho;
+        const float* l = logits + n * C * HW + (int64_t)nearest_src(oy, H, ho, sy) * W + nearest_src(ox, W, wo, sx);
+        float best = l[0];
+        int pred = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = l[c * HW];
+            if (v > best) { best = v; pred = c; }
+        }
+        out[i] = (float)pred;
+    }
+}
+
 }  // namespace
+
+extern "C" int dsn_resize_bilinear_nchw(const float* x, float* y, int64_t planes, int32_t hi, int32_t wi, int32_t ho,
+                                        int32_t wo, int32_t align_corners, void* stream) {
+    DSN_CHECK_ARG(x && y && planes > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, "resize_bilinear_nchw: bad args");
+    const float ry = align_corners ? (ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.f) : (float)hi / (float)ho;
+    const float rx = align_corners ? (wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.f) : (float)wi / (float)wo;
+    const int64_t total = planes * ho * wo;
+    hipLaunchKernelGGL(resize_bilinear_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, planes, hi,
+                       wi, ho, wo, ry, rx, align_corners);
+    DSN_LAUNCH_CHECK("resize_bilinear_nchw");
+    return DSN_OK;
+}
+
+extern "C" int dsn_seg_argmax_nearest(const float* logits, float* out, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho,
+                                      int32_t wo, void* stream) {
+    DSN_CHECK_ARG(logits && out && n > 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "seg_argmax_nearest: bad args");
+    const int64_t total = (int64_t)n * ho * wo;
+    hipLaunchKernelGGL(seg_argmax_nearest_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, logits, out, n, c, h,
+                       w, ho, wo, (float)h / (float)ho, (float)w / (float)wo);
+    DSN_LAUNCH_CHECK("seg_argmax_nearest");
+    return DSN_OK;
+}
 
 extern "C" int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, int64_t pred_rows, int64_t row_off,
                                  int32_t na, int32_t no, float stride, const float* anchors_px, void* stream) {

@@ -754,3 +754,27 @@ def seg_eval_counts(logits: torch.Tensor, target: torch.Tensor, nclass: int):
                                               stream_ptr()), "seg_eval_counts")
     v = out.cpu().numpy()
     return int(v[0]), int(v[1]), v[2:2 + nb].copy(), v[2 + nb:2 + 2 * nb].copy(), v[2 + 2 * nb:2 + 3 * nb].copy()
+
+
+def resize_bilinear_nchw(x: torch.Tensor, size, align_corners: bool = False) -> torch.Tensor:
+    """F.interpolate(x, size, mode='bilinear', align_corners=...) for contiguous NCHW fp32 (evaluation resize of the seg logits)."""
+    _require_gpu(x)
+    xx = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+    n, c, h, w = xx.shape
+    ho, wo = int(size[0]), int(size[1])
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().dsn_resize_bilinear_nchw(xx.data_ptr(), y.data_ptr(), n * c, h, w, ho, wo, int(align_corners),
+                                                   stream_ptr()), "resize_bilinear_nchw")
+    return y
+
+
+def seg_argmax_nearest(logits: torch.Tensor, size=None) -> torch.Tensor:
+    """argmax over classes (first maximum) as float, nearest-resized to `size`: [N, size[0], size[1]] fp32."""
+    _require_gpu(logits)
+    lg = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
+    n, c, h, w = lg.shape
+    ho, wo = (h, w) if size is None else (int(size[0]), int(size[1]))
+    out = torch.empty((n, ho, wo), dtype=torch.float32, device=lg.device)
+    _lib.check(_lib.lib().dsn_seg_argmax_nearest(lg.data_ptr(), out.data_ptr(), n, c, h, w, ho, wo, stream_ptr()),
+               "seg_argmax_nearest")
+    return out

@@ -299,6 +299,14 @@ int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n, int32_t c,
 int dsn_box_iou(const float* boxes1, int32_t n, const float* boxes2, int32_t m, float* out, void* stream);
 int dsn_seg_eval_counts(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
                         int32_t nclass, int64_t* out, void* stream);
+/* dsn_resize_bilinear_nchw: F.interpolate(pred, size, mode='bilinear', align_corners=...) on contiguous NCHW fp32 planes
+ *   (seg_validation's resize of the logits to the label size, scripts/val.py:47: align_corners=False), ATen's arithmetic.
+ * dsn_seg_argmax_nearest: segoutput_to_target (core/utils/plots.py:222-229): first arg-max over classes as float, resized
+ *   with ATen's legacy 'nearest' index rule; out [n][ho][wo] fp32. */
+int dsn_resize_bilinear_nchw(const float* x, float* y, int64_t planes, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                             int32_t align_corners, void* stream);
+int dsn_seg_argmax_nearest(const float* logits, float* out, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho,
+                           int32_t wo, void* stream);
 
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 /* dst[i] = (dtype) src[i]  (flat fp32 master -> bf16 copy) */

@@ -98,3 +98,63 @@ def test_seg_counters_gpu_kernel():
     i1, u1 = batch_intersection_union(logits.cuda(), target.cuda(), 2)
     assert np.array_equal(i0, i1) and np.array_equal(u0, u1)
     assert batch_pix_accuracy(logits.cuda(), target.cuda()) == (c0, l0)
+
+
+@pytest.mark.gpu
+def test_det_evaluator_reproduces_the_val_loop():
+    """val.run's per-image statistics + final reduction (val.py:231-262, 279-289) on two synthetic NMS-output batches."""
+    from desenet_amd.core.utils.metrics import DetEvaluator
+    g = golden("metrics")
+    shapes = [((480, 640), ((1.0, 1.0), (0.0, 80.0))), ((720, 1280), ((0.5, 0.5), (0.0, 140.0))), ((640, 640), None)]
+    ev = DetEvaluator(nc=6)
+    for b in range(2):
+        out = [torch.from_numpy(g[f"de{b}/out{si}"]).cuda() for si in range(3)]
+        ev.update(out, torch.from_numpy(g[f"de{b}/targets"]).cuda(), (640, 640), shapes)
+    mp, mr, map50, map_, nt, ap_class, *_ = ev.result()
+    assert ev.seen == int(g["de/seen"])
+    assert np.allclose([mp, mr, map50, map_], g["de/summary"], rtol=0, atol=1e-12)
+    assert np.array_equal(nt, g["de/nt"]) and np.array_equal(ap_class, g["de/ap_class"])
+    empty = DetEvaluator(nc=6)
+    assert empty.result()[:4] == (0.0, 0.0, 0.0, 0.0)
+
+
+@pytest.mark.gpu
+def test_segoutput_to_target_and_eval_resize():
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.core.utils.metrics import segoutput_to_target
+    g = golden("metrics")
+    lg = torch.from_numpy(g["s2t/logits"]).cuda()
+    for j, size in enumerate([None, (40, 56), (33, 17), (10, 14)]):
+        assert np.array_equal(segoutput_to_target(lg, size).cpu().numpy(), g[f"s2t/out{j}"]), size     # index work: bit-exact
+    for j, size in enumerate([(40, 56), (33, 17), (10, 14), (20, 28)]):
+        got = ops.resize_bilinear_nchw(lg, size, align_corners=False).cpu().numpy()
+        assert np.allclose(got, g[f"s2t/bil{j}"], rtol=1e-5, atol=1e-5), (size, np.abs(got - g[f"s2t/bil{j}"]).max())   # fp32 bilinear
+    ac = ops.resize_bilinear_nchw(lg, (40, 56), align_corners=True).cpu()
+    want = torch.nn.functional.interpolate(lg.cpu(), (40, 56), mode="bilinear", align_corners=True)
+    assert torch.allclose(ac, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_seg_validation_loop_over_a_loader():
+    """seg_validation (val.py:40-76) with a two-batch in-memory loader: uint8 images in, labels at another resolution."""
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.core.models.yolo import Model
+    from desenet_amd.core.utils.metrics import SegEvaluator, seg_validation
+    from tests.util import load_cfg
+    desenet_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(1)
+    m = Model(load_cfg(), ch=3, nc=6).cuda()
+    gen = torch.Generator().manual_seed(2)
+    loader = [(torch.randint(0, 256, (2, 3, 64, 96), generator=gen, dtype=torch.uint8), None,
+               torch.randint(0, 2, (2, 48, 80), generator=gen), None, None) for _ in range(2)]
+    miou = seg_validation(m, 2, loader, half_precision=False)
+    assert desenet_amd.compute_dtype() == torch.float32 and not m.training
+    ev = SegEvaluator(2)
+    with torch.no_grad():
+        for img, _, tgt, _, _ in loader:
+            pred = m(img.cuda())[1]
+            ev.update(ops.resize_bilinear_nchw(pred, tgt.shape[1:], align_corners=False), tgt.cuda())
+    assert miou == ev.result()[1] and 0.0 <= miou <= 1.0
+    assert isinstance(seg_validation(m, 2, loader, half_precision=True), float)        # bf16 path runs, dtype restored
+    assert desenet_amd.compute_dtype() == torch.float32

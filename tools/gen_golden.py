@@ -486,6 +486,63 @@ def gen_metrics():
         s[f"seg{j}/logits"], s[f"seg{j}/target"], s[f"seg{j}/ncls"] = npy(logits), npy(target), np.array(ncls)
         s[f"seg{j}/correct"], s[f"seg{j}/labeled"] = np.array(correct), np.array(labeled)
         s[f"seg{j}/inter"], s[f"seg{j}/union"] = np.asarray(inter), np.asarray(union)
+    # the per-image statistics loop of val.run (val.py:231-262, 279-289) over two synthetic "batches" of NMS outputs, composed
+    # from the reference's own process_batch / scale_coords / xywh2xyxy / ap_per_class; batch 1 has an image without
+    # predictions and one without labels, native shapes differ from the 640x640 network input (letterbox ratio + pad)
+    from core.utils.general import scale_coords, xywh2xyxy
+    from core.utils.plots import segoutput_to_target
+    stats, seen = [], 0
+    for b in range(2):
+        shapes = [((480, 640), ((1.0, 1.0), (0.0, 80.0))), ((720, 1280), ((0.5, 0.5), (0.0, 140.0))), ((640, 640), None)]
+        outs, tgts = [], []
+        for si in range(3):
+            nd, nl = [(30, 8), (0, 5), (12, 0)][si] if b == 1 else [(25, 6), (40, 10), (9, 3)][si]
+            det, lab = det_case(nd, nl, 8.0) if nd else (np.zeros((0, 6), np.float32), det_case(1, nl, 1.0)[1])
+            if nl:
+                xyxy = lab[:, 1:]
+                xywh = np.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2, xyxy[:, 2] - xyxy[:, 0],
+                                 xyxy[:, 3] - xyxy[:, 1]], 1)
+                tgts.append(np.concatenate([np.full((nl, 1), si, np.float32), lab[:, 0:1], xywh], 1).astype(np.float32))
+            outs.append(det.astype(np.float32))
+        targets = torch.from_numpy(np.concatenate(tgts, 0))
+        for si, pred in enumerate(outs):
+            s[f"de{b}/out{si}"] = pred
+        s[f"de{b}/targets"] = npy(targets)
+        for si, pred in enumerate(torch.from_numpy(o) for o in outs):
+            labels = targets[targets[:, 0] == si, 1:]
+            nl = len(labels)
+            tcls = labels[:, 0].tolist() if nl else []
+            shape = shapes[si][0]
+            seen += 1
+            if len(pred) == 0:
+                if nl:
+                    stats.append((torch.zeros(0, 10, dtype=torch.bool), torch.Tensor(), torch.Tensor(), tcls))
+                continue
+            predn = pred.clone()
+            scale_coords((640, 640), predn[:, :4], shape, shapes[si][1])
+            if nl:
+                tbox = xywh2xyxy(labels[:, 1:5])
+                scale_coords((640, 640), tbox, shape, shapes[si][1])
+                labelsn = torch.cat((labels[:, 0:1], tbox), 1)
+                correct = V.process_batch(predn, labelsn, iouv)
+            else:
+                correct = torch.zeros(pred.shape[0], 10, dtype=torch.bool)
+            stats.append((correct.cpu(), pred[:, 4].cpu(), pred[:, 5].cpu(), tcls))
+    st = [np.concatenate(x, 0) for x in zip(*stats)]
+    p, r, ap, f1, ap_class = M.ap_per_class(*st, plot=False, names={i: str(i) for i in range(6)})
+    ap50, apm = ap[:, 0], ap.mean(1)
+    s["de/summary"] = np.array([p.mean(), r.mean(), ap50.mean(), apm.mean()])
+    s["de/nt"] = np.bincount(st[3].astype(np.int64), minlength=6)
+    s["de/ap_class"], s["de/seen"] = ap_class, np.array(seen)
+    # segoutput_to_target (plots.py:222-229) and the align_corners=False resize of seg_validation (val.py:47)
+    import torch.nn.functional as F
+    lg = torch.from_numpy(rng.normal(0, 1, (2, 3, 20, 28)).astype(np.float32))
+    lg[:, 2, :4] = lg[:, 1, :4]
+    s["s2t/logits"] = npy(lg)
+    for j, size in enumerate([None, (40, 56), (33, 17), (10, 14)]):
+        s[f"s2t/out{j}"] = npy(segoutput_to_target(lg, size))
+    for j, size in enumerate([(40, 56), (33, 17), (10, 14), (20, 28)]):
+        s[f"s2t/bil{j}"] = npy(F.interpolate(lg, size, mode="bilinear", align_corners=False))
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **s)
     print("metrics:", len(s), "arrays")
 
