@@ -39,7 +39,7 @@ class dsn_pack_desc(C.Structure):
 
 TP = C.POINTER(dsn_tensor)
 CP = C.POINTER(dsn_conv_params)
-vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+vp, i32, i64, f32, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_double
 
 # name -> (restype, argtypes); every symbol declared in include/desenet_hip.h
 PROTOTYPES = {
@@ -55,7 +55,7 @@ PROTOTYPES = {
     "dsn_conv2d_wgrad_plan_finish": (i32, [vp, i32, vp]),
     "dsn_conv2d_wgrad_run": (i32, [vp, i32, vp, vp]),
     "dsn_conv2d_fwd_bnacc": (i32, [TP, vp, TP, CP, vp, i64, vp]),
-    "dsn_bn_act_fwd_acc": (i32, [TP, vp, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, TP, TP, vp]),
+    "dsn_bn_act_fwd_acc": (i32, [TP, vp, i64, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, TP, TP, vp]),
     "dsn_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
     "dsn_conv2d_wgrad_workspace_bytes": (i64, [TP, TP, CP, i32]),
     "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
@@ -76,6 +76,8 @@ PROTOTYPES = {
     "dsn_channel_sum": (i32, [TP, vp, i32, vp, i64, vp]),
     "dsn_bn_act_fwd": (i32, [TP, vp, vp, i32, TP, TP, vp]),
     "dsn_bn_act_bwd": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, vp]),
+    "dsn_bn_act_bwd_reduce": (i32, [TP, TP, vp, vp, vp, vp, i32, vp, i64, vp]),
+    "dsn_bn_act_bwd_apply": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, f64, f32, vp]),
     "dsn_act_bwd": (i32, [TP, TP, i32, TP, vp]),
     "dsn_focus_s2d": (i32, [vp, i32, i32, i32, i32, TP, vp]),
     "dsn_focus_s2d_u8": (i32, [vp, i32, i32, i32, i32, TP, vp]),

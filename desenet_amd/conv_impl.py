@@ -91,6 +91,20 @@ def out_shape(conv: nn.Conv2d, x):
     return x.shape[0], conv.out_channels, ho, wo
 
 
+def _bn_sync(bn):
+    """(process group, world size) when this BatchNorm was converted by parallel.convert_sync_batchnorm and more than one rank
+    is running, else None."""
+    tag = bn.__dict__.get("_dsn_sync")
+    if tag is None:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = None if tag is True else tag
+    world = dist.get_world_size(group)
+    return (group, world) if world > 1 else None
+
+
 def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, training: bool, tape=None, out=None,
                    residual=None, q1: bool = False, ci_pad: Optional[int] = None):
     """x: NHWC-backed activation (channels may be zero-padded up to ci_pad).  Returns z (written into `out` if given)."""
@@ -111,13 +125,16 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     plain = skip_bn and act == ACT_NONE and residual is None
     y = out if plain else ops.new_act(n, co, ho, wo, dtype, x.device)
     stats = None
+    sync = _bn_sync(bn) if train_bn else None
     if train_bn and bias is None and co <= 1024:
         # BatchNorm statistics come out of the conv epilogue (fp32 accumulators) and are folded in the prologue of the
         # BN + act kernel: conv -> BN -> act is two launches, y is read once
         stats = ops.conv2d_fwd_bnstats(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), bn.weight, bn.bias, bn.running_mean,
                                        bn.running_var, bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps,
-                                       act, residual, out)
+                                       act, residual, out, sync=sync)
     else:
+        if sync is not None:
+            raise NotImplementedError("SyncBatchNorm after a biased or > 1024-channel convolution (not in DeSeNet)")
         ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE))
     rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, y=y, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
     if plain:
@@ -133,7 +150,7 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
             ops.bn_act_fwd(y, scale, shift, act, residual, out)
         if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
             bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
-        rec.update(scale=scale, shift=shift, mean=mean, rstd=rstd, frozen=False)
+        rec.update(scale=scale, shift=shift, mean=mean, rstd=rstd, frozen=False, sync=sync)
     else:
         # eval-mode BN kept differentiable (running statistics are constants): z = act(y*scale + shift)
         g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_var)
@@ -187,7 +204,8 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
         direct = gw is not None and gb is not None
         dg = gw if direct else torch.empty_like(rec["scale"])
         db = gb if direct else torch.empty_like(rec["scale"])
-        ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, dg, db, accumulate=direct)
+        ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, dg, db, accumulate=direct,
+                       sync=rec.get("sync"))
         if not direct:
             tape.add_grad(bn.weight, dg)
             tape.add_grad(bn.bias, db)

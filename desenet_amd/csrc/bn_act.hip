@@ -183,6 +183,7 @@ struct EwPro {
     float *scale, *shift, *mean, *rstd;     // forward: written (saved for the backward pass); backward: read
     float *dgamma, *dbeta;                  // backward: parameter gradients
     int32_t accumulate;
+    float pgrad_scale;                      // backward: factor on the dgamma / dbeta contribution (SyncBN: 1 / world size)
 };
 __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
     const int C = q.a.C;
@@ -215,8 +216,9 @@ __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
             lds[3 * C + c] = -sc * q.rstd[c] * m2;
             lds[4 * C + c] = -sc * m1;
             if (writer) {
-                if (q.dbeta) q.dbeta[c] = q.accumulate ? q.dbeta[c] + (float)s : (float)s;
-                if (q.dgamma) q.dgamma[c] = q.accumulate ? q.dgamma[c] + (float)ss : (float)ss;
+                const float gs = (float)s * q.pgrad_scale, gss = (float)ss * q.pgrad_scale;
+                if (q.dbeta) q.dbeta[c] = q.accumulate ? q.dbeta[c] + gs : gs;
+                if (q.dgamma) q.dgamma[c] = q.accumulate ? q.dgamma[c] + gss : gss;
             }
         }
     }
@@ -505,7 +507,7 @@ extern "C" int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const flo
 // Training-mode BatchNorm + activation (+ shortcut) straight from the accumulators dsn_conv2d_fwd_bnacc filled: the kernel's
 // prologue turns the sums into scale/shift; block 0 also writes scale/shift/mean/rstd (saved for dsn_bn_act_bwd) and
 // updates the running statistics.
-extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, const float* gamma,
+extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, double count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                   float* scale, float* shift, float* mean, float* rstd, int32_t act,
                                   const dsn_tensor* residual, const dsn_tensor* z, void* stream) {
@@ -521,7 +523,7 @@ extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t 
     ProfScope prof(KID_BN_ACT_FWD, 0.0, (double)P * y->c * (y->dtype == DSN_F32 ? 4.0 : 2.0) * (residual ? 3 : 2), st);
     BnParams bp{scale, shift, nullptr, nullptr, nullptr, act, y->c};
     EwPro pro{};
-    pro.a = BnAcc{(double*)acc, y->c, (double)P};
+    pro.a = BnAcc{(double*)acc, y->c, count > 0.0 ? count : (double)P};      // count: SyncBN passes the global pixel count
     pro.mode = 0;
     pro.gamma = gamma; pro.beta = beta; pro.running_mean = running_mean; pro.running_var = running_var;
     pro.momentum = momentum; pro.eps = eps;
@@ -536,37 +538,63 @@ extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t 
     return DSN_OK;
 }
 
-extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
-                              const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
-                              float* dbeta, int32_t accumulate, void* workspace, int64_t workspace_bytes,
-                              void* stream) {
-    DSN_CHECK_ARG(tensor_ok(dz) && tensor_ok(y) && tensor_ok(dy) && same_shape(dz, y) && same_shape(dy, y),
-                  "bn_act_bwd: invalid tensors");
-    DSN_CHECK_ARG(scale && shift && mean && rstd && workspace, "bn_act_bwd: null argument");
-    if (workspace_bytes < dsn_bn_workspace_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "bn_act_bwd: workspace too small");
+// Backward of BN + act in its two halves (dsn_bn_act_bwd = both).  SyncBatchNorm all-reduces `workspace` between them and
+// passes the global pixel count and 1 / world_size for the parameter-gradient contribution (dgamma / dbeta stay per-rank sums
+// after the gradient all-reduce, as torch.nn.SyncBatchNorm + DDP produce).
+extern "C" int dsn_bn_act_bwd_reduce(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                                     const float* mean, const float* rstd, int32_t act, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dz) && tensor_ok(y) && same_shape(dz, y), "bn_act_bwd_reduce: invalid tensors");
+    DSN_CHECK_ARG(scale && shift && mean && rstd && workspace, "bn_act_bwd_reduce: null argument");
+    if (workspace_bytes < dsn_bn_workspace_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "bn_act_bwd_reduce: workspace too small");
+    DSN_CHECK_ARG(y->c <= PRO_MAXC, "bn_act_bwd_reduce: at most %d channels", PRO_MAXC);
     const int64_t P = npix(y);
-    DSN_CHECK_ARG(y->c <= PRO_MAXC, "bn_act_bwd: at most %d channels", PRO_MAXC);
+    hipStream_t st = (hipStream_t)stream;
+    const bool v = vec_ok(y) && vec_ok(dz);
+    const double esz = y->dtype == DSN_F32 ? 4.0 : 2.0;
+    BnParams bp{scale, shift, mean, rstd, nullptr, act, y->c};
+    BnAcc f{(double*)workspace, y->c, (double)P};
+    ProfScope prof(KID_BN_BWD_REDUCE, 0.0, 2.0 * P * y->c * esz, st);
+    DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, true, BwdRedF>(v, y, dz, f, st, bp)));
+    DSN_LAUNCH_CHECK("bn_act_bwd reduce");
+    return DSN_OK;
+}
+
+extern "C" int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                                    const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
+                                    float* dbeta, int32_t accumulate, const void* workspace, int64_t workspace_bytes,
+                                    double count, float pgrad_scale, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dz) && tensor_ok(y) && tensor_ok(dy) && same_shape(dz, y) && same_shape(dy, y),
+                  "bn_act_bwd_apply: invalid tensors");
+    DSN_CHECK_ARG(scale && shift && mean && rstd && workspace, "bn_act_bwd_apply: null argument");
+    if (workspace_bytes < dsn_bn_workspace_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "bn_act_bwd_apply: workspace too small");
+    DSN_CHECK_ARG(y->c <= PRO_MAXC, "bn_act_bwd_apply: at most %d channels", PRO_MAXC);
+    const int64_t P = npix(y);
     hipStream_t st = (hipStream_t)stream;
     const bool v = vec_ok(y) && vec_ok(dz) && vec_ok(dy);
     const double esz = y->dtype == DSN_F32 ? 4.0 : 2.0;
     BnParams bp{scale, shift, mean, rstd, nullptr, act, y->c};
-    BnAcc f{(double*)workspace, y->c, (double)P};
-    {
-        ProfScope prof(KID_BN_BWD_REDUCE, 0.0, 2.0 * P * y->c * esz, st);
-        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, true, BwdRedF>(v, y, dz, f, st, bp)));
-    }
-    DSN_LAUNCH_CHECK("bn_act_bwd reduce");
     EwPro pro{};
-    pro.a = f;
+    pro.a = BnAcc{(double*)workspace, y->c, count > 0.0 ? count : (double)P};
     pro.mode = 1;
     pro.scale = (float*)scale; pro.shift = (float*)shift; pro.mean = (float*)mean; pro.rstd = (float*)rstd;   // read only
     pro.dgamma = dgamma; pro.dbeta = dbeta; pro.accumulate = accumulate;
-    {
-        ProfScope prof(KID_BN_BWD_APPLY, 0.0, 3.0 * P * y->c * esz, st);
-        DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, &pro, st, bp)));
-    }
+    pro.pgrad_scale = pgrad_scale;
+    ProfScope prof(KID_BN_BWD_APPLY, 0.0, 3.0 * P * y->c * esz, st);
+    DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, &pro, st, bp)));
     DSN_LAUNCH_CHECK("bn_act_bwd apply");
     return DSN_OK;
+}
+
+extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
+                              float* dbeta, int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dy), "bn_act_bwd: invalid tensors");
+    int rc = dsn_bn_act_bwd_reduce(dz, y, scale, shift, mean, rstd, act, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return dsn_bn_act_bwd_apply(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate, workspace,
+                                workspace_bytes, 0.0, 1.f, stream);
 }
 
 extern "C" int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const dsn_tensor* dy, void* stream) {

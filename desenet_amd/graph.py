@@ -23,6 +23,8 @@ class GraphedTrainStep:
         """loss_and_grads(det_out, seg_out) -> (loss tensor, d_det, d_seg): HIP kernels only (capturable).
         ema: optional desenet_amd ModelEMA, updated right after the optimizer step (scripts/train.py:374-375) inside the graph."""
         self.model, self.loss_and_grads, self.flat, self.opt, self.ema = model, loss_and_grads, flat, optimizer, ema
+        if any(m.__dict__.get("_dsn_sync") is not None for m in model.modules()):
+            raise NotImplementedError("GraphedTrainStep with SyncBatchNorm: the per-layer collectives run eagerly; use eager steps")
         self.x = example_input.clone()
         dev = self.x.device
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

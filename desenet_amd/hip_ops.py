@@ -117,8 +117,14 @@ def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params):
     return y
 
 
+def _sync_sum(acc_bytes_tensor, nbytes, group):
+    """SyncBatchNorm's exchange: SUM the fp64 accumulators over the ranks of `group` (in place, on the current stream)."""
+    import torch.distributed as dist
+    dist.all_reduce(acc_bytes_tensor[:nbytes].view(torch.float64), op=dist.ReduceOp.SUM, group=group)
+
+
 def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_mean, running_var, momentum, eps, act,
-                       residual, z):
+                       residual, z, sync=None):
     """Training forward of conv -> BatchNorm -> act (+ shortcut) in TWO launches: the conv epilogue adds the per-channel
     sums into fp64 accumulators, the elementwise kernel folds them in its prologue (no statistics pass, no finalize
     launch).  Writes z; returns (scale, shift, mean, rstd) fp32 [C] for the backward pass."""
@@ -129,8 +135,12 @@ def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_
     acc, nbytes = bn_acc(c, y.device)
     _lib.check(L.dsn_conv2d_fwd_bnacc(C.byref(dx), w_packed.data_ptr(), C.byref(dy), C.byref(p), acc.data_ptr(), nbytes,
                                       stream_ptr()), "conv2d_fwd_bnacc")
+    count = 0.0
+    if sync is not None:                # (group, world size): statistics over the global batch (equal per-rank batches)
+        _sync_sum(acc, nbytes, sync[0])
+        count = float(y.shape[0] * y.shape[2] * y.shape[3]) * sync[1]
     out = torch.empty((4, c), dtype=torch.float32, device=y.device)
-    _lib.check(L.dsn_bn_act_fwd_acc(C.byref(dy), acc.data_ptr(), nbytes, _p(gamma), _p(beta), _p(running_mean),
+    _lib.check(L.dsn_bn_act_fwd_acc(C.byref(dy), acc.data_ptr(), nbytes, count, _p(gamma), _p(beta), _p(running_mean),
                                     _p(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
                                     out[2].data_ptr(), out[3].data_ptr(), act, _ref(dr), C.byref(dz), stream_ptr()),
                "bn_act_fwd_acc")
@@ -457,9 +467,19 @@ def bn_act_fwd(y, scale, shift, act, residual, z):
     return z
 
 
-def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False):
+def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False, sync=None):
     a, b, c = desc(dz), desc(y), desc(dy)
     ws, nbytes = bn_acc(y.shape[1], y.device)
+    if sync is not None:                # SyncBatchNorm: global sums for dy, per-rank share of dgamma / dbeta
+        L = _lib.lib()
+        _lib.check(L.dsn_bn_act_bwd_reduce(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), act, ws.data_ptr(), nbytes, stream_ptr()), "bn_act_bwd_reduce")
+        _sync_sum(ws, nbytes, sync[0])
+        count = float(y.shape[0] * y.shape[2] * y.shape[3]) * sync[1]
+        _lib.check(L.dsn_bn_act_bwd_apply(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),
+                                          ws.data_ptr(), nbytes, count, 1.0 / sync[1], stream_ptr()), "bn_act_bwd_apply")
+        return dy
     _lib.check(_lib.lib().dsn_bn_act_bwd(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),
                                          ws.data_ptr(), nbytes, stream_ptr()), "bn_act_bwd")

@@ -69,3 +69,16 @@ def sgd_param_groups(model: torch.nn.Module, weight_decay: float = 5e-4):
             g_w.append(m.weight)
     return [dict(params=g_bn, weight_decay=0.0), dict(params=g_w, weight_decay=weight_decay),
             dict(params=g_b, weight_decay=0.0)]
+
+
+def convert_sync_batchnorm(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """`torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` for the mirrored model (scripts/train.py:218-220): every
+    BatchNorm2d computes its training statistics over the GLOBAL batch.  The modules keep their type and `state_dict` (same
+    keys as SyncBatchNorm); the exchange is one all-reduce (SUM) of the layer's fp64 sum / sum-of-squares accumulators in the
+    forward pass and one of its two backward sums -- the same two collectives per layer as torch's implementation, on raw sums
+    instead of (mean, invstd, count) triples.  Per-rank batches must be equal (they are under the reference's DDP split,
+    train.py:223).  Returns `module`.  A graph-captured step does not support it (collectives per layer): use eager steps."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.__dict__["_dsn_sync"] = process_group if process_group is not None else True
+    return module

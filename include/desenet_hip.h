@@ -175,6 +175,12 @@ int dsn_unpack_wgrad(const float* dw_packed, float* grad_oihw, int32_t co, int32
  * dsn_bn_act_fwd:  z = act(y*scale + shift) + residual      (also the eval path of un-fused BN: RFB2 quirk Q3)
  * dsn_bn_act_bwd:  given dz, y: dy = BN/act backward, dgamma/dbeta (+)=.  workspace: dsn_bn_workspace_bytes(c) bytes,
  *   ZERO ON ENTRY, left dirty (callers hand out slices of an arena cleared once per step).
+ * SyncBatchNorm (scripts/train.py:218-220, torch.nn.SyncBatchNorm semantics): the fp64 accumulators are plain sums, so the
+ *   caller all-reduces (SUM) the accumulator buffer between producer and consumer -- between dsn_conv2d_fwd_bnacc and
+ *   dsn_bn_act_fwd_acc in the forward pass, between dsn_bn_act_bwd_reduce and dsn_bn_act_bwd_apply in the backward pass --
+ *   and passes `count` = the GLOBAL number of pixels (<= 0: this tensor's own) and, for the backward pass,
+ *   `pgrad_scale` = 1 / world_size on the dgamma / dbeta contribution (they are summed over ranks by the gradient
+ *   all-reduce afterwards).  dsn_bn_act_bwd = reduce + apply with local count and scale 1.
  */
 int64_t dsn_bn_workspace_bytes(int32_t c);
 int dsn_bn_stats(const dsn_tensor* y, const float* gamma, const float* beta, float* running_mean,
@@ -189,14 +195,21 @@ int dsn_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count
                     float* mean, float* rstd, void* stream);
 int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const float* shift, int32_t act,
                    const dsn_tensor* residual, const dsn_tensor* z, void* stream);
-int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, double count, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                        float* mean, float* rstd, int32_t act, const dsn_tensor* residual, const dsn_tensor* z,
                        void* stream);
 int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                    const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                    float* dbeta, int32_t accumulate_param_grads, void* workspace, int64_t workspace_bytes,
                    void* stream);
+int dsn_bn_act_bwd_reduce(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                          const float* mean, const float* rstd, int32_t act, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
+                         float* dbeta, int32_t accumulate_param_grads, const void* workspace, int64_t workspace_bytes,
+                         double count, float pgrad_scale, void* stream);
 /* act backward without BN (conv -> act, quirk Q1 path and FFM attention): dy = dz * act'(y) */
 int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const dsn_tensor* dy, void* stream);
 
