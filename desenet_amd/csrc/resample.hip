@@ -829,6 +829,61 @@ inline bool vec16(const dsn_tensor* t) {
 }  // namespace
 
 namespace {
+// ---- letterbox (mixed_datasets.py:722-752) + `img.transpose(2, 0, 1)[::-1]` (:576) in ONE launch ---------------------------
+// src: uint8 HWC (BGR as cv2 loads it), h0 x w0.  dst: uint8 H x W, either HWC in the source's channel order (what
+// letterbox() returns) or CHW with the channel order reversed (what the loader hands to the network).  Inside the window
+// [top, top + nh) x [left, left + nw) the pixel is the INTER_LINEAR resize of src to nh x nw, outside it the border colour.
+// The resize restates OpenCV's 8-bit INTER_LINEAR (cv2.resize is a third-party dependency that is not in the image): source
+// coordinate f = (d + 0.5) * (in / out) - 0.5, taps (floor f, +1) clamped to the image, 11-bit fixed-point weights
+// cvRound(w * 2048) (round half to even), horizontal pass exact in int32, vertical pass
+// (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+__device__ __forceinline__ void lb_tap(int d, int in, double scale, int& i0, int& i1, int& a0, int& a1) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= in - 1) { s = in - 1; f = 0.f; }
+    i0 = s;
+    i1 = s + 1 < in ? s + 1 : in - 1;
+    a0 = (int)rintf((1.f - f) * 2048.f);
+    a1 = (int)rintf(f * 2048.f);
+}
+__global__ __launch_bounds__(256) void letterbox_u8_kernel(const uint8_t* __restrict__ src, int h0, int w0,
+                                                           uint8_t* __restrict__ dst, int H, int W, int nh, int nw, int top,
+                                                           int left, int pad0, int pad1, int pad2, int chw_reversed,
+                                                           double sy, double sx) {
+    const int64_t total = (int64_t)H * W;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)(i / W);
+        int v[3] = {pad0, pad1, pad2};
+        const int ry = y - top, rx = x - left;
+        if (ry >= 0 && ry < nh && rx >= 0 && rx < nw) {
+            if (nh == h0 && nw == w0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = src[((int64_t)ry * w0 + rx) * 3 + c];
+            } else {
+                int y0, y1, b0, b1, x0, x1, a0, a1;
+                lb_tap(ry, h0, sy, y0, y1, b0, b1);
+                lb_tap(rx, w0, sx, x0, x1, a0, a1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int r0 = src[((int64_t)y0 * w0 + x0) * 3 + c] * a0 + src[((int64_t)y0 * w0 + x1) * 3 + c] * a1;
+                    const int r1 = src[((int64_t)y1 * w0 + x0) * 3 + c] * a0 + src[((int64_t)y1 * w0 + x1) * 3 + c] * a1;
+                    const int o = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                    v[c] = o < 0 ? 0 : (o > 255 ? 255 : o);
+                }
+            }
+        }
+        if (chw_reversed) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[(int64_t)(2 - c) * total + i] = (uint8_t)v[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[i * 3 + c] = (uint8_t)v[c];
+        }
+    }
+}
+
 template <typename IN>
 int focus_impl(const IN* x, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y, void* stream) {
     DSN_CHECK_ARG(x && tensor_ok(y) && n > 0 && c > 0, "focus_s2d: invalid arguments");
@@ -857,6 +912,17 @@ int focus_impl(const IN* x, int32_t n, int32_t c, int32_t h, int32_t w, const ds
 extern "C" int dsn_focus_s2d(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
                              void* stream) {
     return focus_impl<float>(x, n, c, h, w, y, stream);
+}
+
+extern "C" int dsn_letterbox_u8(const uint8_t* src_hwc, int32_t h0, int32_t w0, uint8_t* dst, int32_t h, int32_t w,
+                                int32_t new_h, int32_t new_w, int32_t top, int32_t left, int32_t pad0, int32_t pad1,
+                                int32_t pad2, int32_t chw_reversed, void* stream) {
+    DSN_CHECK_ARG(src_hwc && dst && h0 > 0 && w0 > 0 && h > 0 && w > 0 && new_h > 0 && new_w > 0, "letterbox_u8: bad sizes");
+    DSN_CHECK_ARG(top >= 0 && left >= 0 && top + new_h <= h && left + new_w <= w, "letterbox_u8: window outside the output");
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3(ew_grid((int64_t)h * w)), dim3(256), 0, (hipStream_t)stream, src_hwc, h0, w0,
+                       dst, h, w, new_h, new_w, top, left, pad0, pad1, pad2, chw_reversed, (double)h0 / new_h, (double)w0 / new_w);
+    DSN_LAUNCH_CHECK("letterbox_u8");
+    return DSN_OK;
 }
 
 // the same from the loader's uint8 NCHW batch, with its `.float() / 255.0` folded in (4x fewer input bytes)

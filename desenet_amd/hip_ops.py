@@ -798,3 +798,18 @@ def seg_argmax_nearest(logits: torch.Tensor, size=None) -> torch.Tensor:
     _lib.check(_lib.lib().dsn_seg_argmax_nearest(lg.data_ptr(), out.data_ptr(), n, c, h, w, ho, wo, stream_ptr()),
                "seg_argmax_nearest")
     return out
+
+
+def letterbox_u8(src_hwc: torch.Tensor, out_hw, new_hw, top: int, left: int, color=(114, 114, 114), chw_reversed=False):
+    """Resize a uint8 HWC image to new_hw, place it at (top, left) of an out_hw canvas filled with `color`; optionally emit CHW
+    with reversed channel order (BGR -> RGB).  One launch."""
+    _require_gpu(src_hwc)
+    if src_hwc.dtype != torch.uint8 or src_hwc.dim() != 3 or src_hwc.shape[2] != 3:
+        raise TypeError("letterbox_u8: expects a uint8 [H, W, 3] image")
+    src = src_hwc if src_hwc.is_contiguous() else src_hwc.contiguous()
+    h, w = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((3, h, w) if chw_reversed else (h, w, 3), dtype=torch.uint8, device=src.device)
+    _lib.check(_lib.lib().dsn_letterbox_u8(src.data_ptr(), src.shape[0], src.shape[1], out.data_ptr(), h, w, int(new_hw[0]),
+                                           int(new_hw[1]), int(top), int(left), int(color[0]), int(color[1]), int(color[2]),
+                                           int(chw_reversed), stream_ptr()), "letterbox_u8")
+    return out

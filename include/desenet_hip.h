@@ -230,6 +230,16 @@ int dsn_focus_s2d(const float* x_nchw, int32_t n, int32_t c, int32_t h, int32_t 
  * detect.py:129) folded in: y = Focus-slice((float)x / 255.0f), correctly rounded division (bit-exact vs ATen). */
 int dsn_focus_s2d_u8(const uint8_t* x_nchw, int32_t n, int32_t c, int32_t h, int32_t w, const dsn_tensor* y,
                      void* stream);
+/* letterbox (core/utils/mixed_datasets.py:722-752) with the loader's `transpose(2,0,1)[::-1]` (:576) optionally folded in:
+ * src uint8 HWC h0 x w0 (3 channels) -> dst uint8 h x w; the window [top, top+new_h) x [left, left+new_w) holds the
+ * INTER_LINEAR resize of src to new_h x new_w (a plain copy when the sizes are equal), the rest the border colour
+ * (pad0..2 in source channel order).  chw_reversed = 0: HWC, source channel order (letterbox()'s return value);
+ * 1: CHW with reversed channels (BGR -> RGB), the network's input layout.  The host computes the geometry (ratio, new_unpad,
+ * dw, dh: desenet_amd.core.utils.augmentations.letterbox).  The resize restates OpenCV's 8-bit fixed-point INTER_LINEAR;
+ * cv2 is a third-party dependency absent from the reference tree and this image: that part is "parity unpinned". */
+int dsn_letterbox_u8(const uint8_t* src_hwc, int32_t h0, int32_t w0, uint8_t* dst, int32_t h, int32_t w, int32_t new_h,
+                     int32_t new_w, int32_t top, int32_t left, int32_t pad0, int32_t pad1, int32_t pad2,
+                     int32_t chw_reversed, void* stream);
 int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream);
 /* the same pool at n_out <= 3 window sizes ks[i] of ONE input (SPP: 5, 9, 13) in one launch; ys: contiguous descriptors,
  * idxs (array of int32 pointers, or NULL / NULL entries in eval) */
