@@ -26,6 +26,11 @@ class dsn_sgd_desc(C.Structure):
                 ("group", C.c_int32), ("first_chunk", C.c_int32)]
 
 
+class dsn_bn_split(C.Structure):
+    _fields_ = [("split_c", C.c_int32), ("_pad", C.c_int32), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
 class dsn_ema_desc(C.Structure):
     _fields_ = [("ema", C.c_void_p), ("model", C.c_void_p), ("numel", C.c_int64), ("first_chunk", C.c_int32),
                 ("_pad", C.c_int32)]
@@ -55,7 +60,7 @@ PROTOTYPES = {
     "dsn_conv2d_wgrad_plan_finish": (i32, [vp, i32, vp]),
     "dsn_conv2d_wgrad_run": (i32, [vp, i32, vp, vp]),
     "dsn_conv2d_fwd_bnacc": (i32, [TP, vp, TP, CP, vp, i64, vp]),
-    "dsn_bn_act_fwd_acc": (i32, [TP, vp, i64, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, TP, TP, vp]),
+    "dsn_bn_act_fwd_acc": (i32, [TP, vp, i64, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, TP, TP, vp, vp]),
     "dsn_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
     "dsn_conv2d_wgrad_workspace_bytes": (i64, [TP, TP, CP, i32]),
     "dsn_conv2d_wgrad": (i32, [TP, TP, vp, i32, i32, CP, vp, i64, vp]),
@@ -77,7 +82,7 @@ PROTOTYPES = {
     "dsn_bn_act_fwd": (i32, [TP, vp, vp, i32, TP, TP, vp]),
     "dsn_bn_act_bwd": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, vp]),
     "dsn_bn_act_bwd_reduce": (i32, [TP, TP, vp, vp, vp, vp, i32, vp, i64, vp]),
-    "dsn_bn_act_bwd_apply": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, f64, f32, vp]),
+    "dsn_bn_act_bwd_apply": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, f64, f32, vp, vp]),
     "dsn_act_bwd": (i32, [TP, TP, i32, TP, vp]),
     "dsn_focus_s2d": (i32, [vp, i32, i32, i32, i32, TP, vp]),
     "dsn_letterbox_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -164,6 +164,75 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     return out
 
 
+def pair_ready(blk_a, blk_b, x, tape, dtype):
+    """Can blk_a | blk_b (Conv modules: 1x1 conv + BN + act on the SAME input) run as one merged convolution right now?
+    Needs the model's WeightBank to have packed them back to back for the current weights, training-mode BatchNorm on a map
+    larger than 1x1, gradient slots to accumulate into, and identical BN hyper-parameters / sync state."""
+    if tape is None or not (blk_a.training and blk_b.training) or blk_a.fused or blk_b.fused:
+        return None
+    ca, cb, ba, bb = blk_a.conv, blk_b.conv, blk_a.bn, blk_b.bn
+    hit = _cache(ca).get(("pair", dtype))
+    if hit is None or hit[1] is not cb or hit[0] != _ver(ca.weight, cb.weight) or x.shape[2] * x.shape[3] == 1:
+        return None
+    if ba.eps != bb.eps or ba.momentum != bb.momentum or type(blk_a.act) is not type(blk_b.act) or _bn_sync(ba) != _bn_sync(bb):
+        return None
+    if (ba.running_mean is None) != (bb.running_mean is None) or ca.out_channels + cb.out_channels > 1024:
+        return None
+    for p_ in (ca.weight, cb.weight, ba.weight, ba.bias, bb.weight, bb.bias):
+        if _grad_slot(p_) is None:
+            return None
+    return hit
+
+
+def pair_block_fwd(x, blk_a, blk_b, hit, tape, out):
+    """z[:, :coA] = blk_a(x), z[:, coA:] = blk_b(x) as ONE convolution + ONE BatchNorm/act launch (`out`: coA+coB channels)."""
+    ca, cb, ba, bb = blk_a.conv, blk_b.conv, blk_a.bn, blk_b.bn
+    _, _, wf, _ = hit
+    n, _, h, w = x.shape
+    co = ca.out_channels + cb.out_channels
+    act = act_code(blk_a.act)
+    y = ops.new_act(n, co, h, w, x.dtype, x.device)
+    sync = _bn_sync(ba)
+    mom = ba.momentum if ba.momentum is not None else BN_MOMENTUM
+    scale, shift, mean, rstd = ops.conv2d_fwd_bnstats(
+        x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), ba.weight, ba.bias, ba.running_mean, ba.running_var, mom, ba.eps, act,
+        None, out, sync=sync, second=(ca.out_channels, bb.weight, bb.bias, bb.running_mean, bb.running_var, None, None))
+    for bn in (ba, bb):
+        if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
+            bn.num_batches_tracked.add_(1)
+    tape.push(dict(pair=(blk_a, blk_b), x=x, y=y, act=act, scale=scale, shift=shift, mean=mean, rstd=rstd, sync=sync))
+    return out
+
+
+def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
+    """Backward of pair_block_fwd: one BN/act backward over the merged tensor, two queued weight-gradient jobs, one dgrad."""
+    rec = tape.pop()
+    blk_a, blk_b = rec["pair"]
+    ca, cb, ba, bb = blk_a.conv, blk_b.conv, blk_a.bn, blk_b.bn
+    x, y, act = rec["x"], rec["y"], rec["act"]
+    dtype = x.dtype
+    hit = _cache(ca).get(("pair", dtype))
+    if hit is None or hit[0] != _ver(ca.weight, cb.weight):
+        raise RuntimeError("merged C3 pair: the packed weights changed between forward and backward")
+    coa = ca.out_channels
+    dy = ops.new_act(*y.shape, dtype, y.device)
+    ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, _grad_slot(ba.weight),
+                   _grad_slot(ba.bias), accumulate=True, sync=rec["sync"],
+                   second=(coa, None, None, None, None, _grad_slot(bb.weight), _grad_slot(bb.bias)))
+    q = tape.wgrad_queue(x.device)
+    for conv, sl in ((ca, dy[:, :coa]), (cb, dy[:, coa:])):
+        if conv.weight.requires_grad:
+            ops.conv2d_wgrad(x, sl, _grad_slot(conv.weight), conv.in_channels, ops.conv_params(1, 1, 0, 1, accumulate=True),
+                             oihw=True, queue=q)
+    if not need_dx:
+        return None
+    if dx is None:
+        dx = ops.new_act(*x.shape, dtype, x.device)
+        acc = False
+    ops.conv2d_dgrad(dy, hit[3], dx, ops.conv_params(1, 1, 0, 1, accumulate=acc))
+    return dx
+
+
 class _NullCtx:
     def __enter__(self):
         return None

@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from ... import hip_ops as ops
-from ...conv_impl import act_code, conv_block_bwd, conv_block_fwd, out_shape
+from ...conv_impl import (act_code, conv_block_bwd, conv_block_fwd, out_shape, pair_block_bwd, pair_block_fwd,
+                          pair_ready)
 from ...hip_ops import ACT_NONE, ACT_SIGMOID, ACT_SILU
 from ...runtime import compute_dtype, run_module
 
@@ -120,16 +121,43 @@ class C3(HipModule):
         x = _as_input(x)
         c_ = self.cv1.conv.out_channels
         n, _, h, w = x.shape
-        cat = ops.new_act(n, 2 * c_, h, w, x.dtype, x.device)
         blocks = list(self.m)
+        hit = pair_ready(self.cv2, self.cv1, x, tape, x.dtype) if blocks else None
+        if hit is not None:
+            # training: cv2 | cv1 as ONE 2c_-wide convolution + ONE BatchNorm launch.  Buffer [m(..) | cv2(x) | cv1(x)]: the
+            # merged block writes the last two thirds, the bottleneck chain reads the last third and its final block writes
+            # the first, cv3 reads the first two thirds -- every operand is a channel slice, nothing is copied.
+            cat3 = ops.new_act(n, 3 * c_, h, w, x.dtype, x.device)
+            pair_block_fwd(x, self.cv2, self.cv1, hit, tape, cat3[:, c_:])
+            a = cat3[:, 2 * c_:]
+            for i, b in enumerate(blocks):
+                a = b.fwd(a, tape, cat3[:, :c_] if i == len(blocks) - 1 else None)
+            z = self.cv3.fwd(cat3[:, :2 * c_], tape, out)
+            tape.push("c3-merged")
+            return z
+        cat = ops.new_act(n, 2 * c_, h, w, x.dtype, x.device)
         a = self.cv1.fwd(x, tape, cat[:, :c_] if not blocks else None)
         for i, b in enumerate(blocks):
             a = b.fwd(a, tape, cat[:, :c_] if i == len(blocks) - 1 else None)
         self.cv2.fwd(x, tape, cat[:, c_:])
-        return self.cv3.fwd(cat, tape, out)
+        z = self.cv3.fwd(cat, tape, out)
+        if tape is not None:
+            tape.push("c3-plain")
+        return z
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         c_ = self.cv1.conv.out_channels
+        if tape.pop() == "c3-merged":
+            # gradient buffer [d m(..) | d cv2 | d cv1]: cv3's dgrad fills the first two thirds, the chain's first block the
+            # last one; the merged block reads the last two thirds
+            n, _, h, w = dy.shape
+            d3 = ops.new_act(n, 3 * c_, h, w, dy.dtype, dy.device)
+            self.cv3.bwd(tape, dy, d3[:, :2 * c_], False)
+            da = d3[:, :c_]
+            blocks = list(self.m)
+            for i, b in enumerate(reversed(blocks)):
+                da = b.bwd(tape, da, d3[:, 2 * c_:], False) if i == len(blocks) - 1 else b.bwd(tape, da)
+            return pair_block_bwd(tape, d3[:, c_:], dx, acc, need_dx)
         dcat = self.cv3.bwd(tape, dy)
         dx = self.cv2.bwd(tape, dcat[:, c_:], dx, acc, need_dx)
         da = dcat[:, :c_]

@@ -324,9 +324,12 @@ class Model(HipModule):
             pads = [((c.in_channels + vec - 1) // vec * vec) if c in focus_convs else c.in_channels for c in convs]
             det_convs = {c for m in self.modules() if isinstance(m, Detect) for c in m.m}
             co_pads = [((c.out_channels + vec - 1) // vec * vec) if c in det_convs else c.out_channels for c in convs]
-            bank = self.__dict__["_dsn_bank"] = ops.WeightBank(convs, pads, dtype, device, co_pads=co_pads)
-            self.__dict__["_dsn_bank_pads"] = pads
+            # C3's cv2 and cv1 read the same input: packed back to back they also run as ONE convolution (conv_impl.pair_block_*)
+            pairs = [(m.cv2.conv, m.cv1.conv) for m in self.modules() if isinstance(m, C3) and not m.cv1.fused]
+            bank = self.__dict__["_dsn_bank"] = ops.WeightBank(convs, pads, dtype, device, co_pads=co_pads, pairs=pairs)
+            self.__dict__["_dsn_bank_pads"] = bank.ci_pads
             self.__dict__["_dsn_bank_version"] = None
+        convs = bank.convs                    # the bank's own order (pairs adjacent)
         version = tuple(c.weight._version for c in convs)
         # (while a graph is being captured the re-pack is ALWAYS recorded: every replay follows an optimizer step)
         if version != self.__dict__.get("_dsn_bank_version") or torch.cuda.is_current_stream_capturing():
@@ -340,8 +343,11 @@ class Model(HipModule):
                     cache[("fwd", dtype, None, False)] = cache[("fwd", dtype, cp, False)]
                 if s2 is not None:
                     cache[("dgrad_s2", dtype)] = (_ver(c.weight), s2)
-                cop = d.shape[-1]          # > out_channels for the row-padded Detect heads
-                cache[("dgrad", dtype) if cop == c.out_channels else ("dgrad", dtype, cop)] = (_ver(c.weight), d)
+                if d is not None:          # (None: second half of a pair, its columns live in the pair's merged matrix)
+                    cop = d.shape[-1]      # > out_channels for the row-padded Detect heads and the merged pairs
+                    cache[("dgrad", dtype) if cop == c.out_channels else ("dgrad", dtype, cop)] = (_ver(c.weight), d)
+            for a, (b, wf) in bank.pair_fwd.items():
+                _cache(a)[("pair", dtype)] = (_ver(a.weight, b.weight), b, wf, bank.pair_dgrad[a])
         # BatchNorm `num_batches_tracked`: every counter is a view of one int64 vector -> a single add per step
         bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None
                and not getattr(m, "_dsn_never_runs", False)]

@@ -184,6 +184,11 @@ struct EwPro {
     float *dgamma, *dbeta;                  // backward: parameter gradients
     int32_t accumulate;
     float pgrad_scale;                      // backward: factor on the dgamma / dbeta contribution (SyncBN: 1 / world size)
+    // two BatchNorm modules over one merged tensor (C3's cv2 | cv1 as ONE convolution): channels >= split belong to the second
+    // module, whose parameter vectors are indexed from 0.  split == 0: one module.
+    int32_t split;
+    const float *gamma2, *beta2;
+    float *running_mean2, *running_var2, *dgamma2, *dbeta2;
 };
 __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
     const int C = q.a.C;
@@ -191,21 +196,27 @@ __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
     for (int c = threadIdx.x; c < C; c += THREADS) {
         double s, ss;
         bn_acc_fold(q.a, c, s, ss);
+        const bool second = q.split > 0 && c >= q.split;
+        const int pc = second ? c - q.split : c;                       // index into the owning module's parameter vectors
         if (q.mode == 0) {
             const double mean = s / q.a.count;
             double var = ss / q.a.count - mean * mean;
             if (var < 0.0) var = 0.0;
             const float rstd = (float)(1.0 / sqrt(var + (double)q.eps));
-            const float g = q.gamma ? q.gamma[c] : 1.f, b = q.beta ? q.beta[c] : 0.f;
+            const float* gam = second ? q.gamma2 : q.gamma;
+            const float* bet = second ? q.beta2 : q.beta;
+            const float g = gam ? gam[pc] : 1.f, b = bet ? bet[pc] : 0.f;
             const float sc = g * rstd, sh = b - (float)mean * sc;
             lds[c] = sc;
             lds[C + c] = sh;
             if (writer) {
                 q.scale[c] = sc; q.shift[c] = sh; q.mean[c] = (float)mean; q.rstd[c] = rstd;
-                if (q.running_mean) {
+                float* rm = second ? q.running_mean2 : q.running_mean;
+                float* rv = second ? q.running_var2 : q.running_var;
+                if (rm) {
                     const double unbiased = q.a.count > 1.0 ? var * q.a.count / (q.a.count - 1.0) : var;
-                    q.running_mean[c] = (1.f - q.momentum) * q.running_mean[c] + q.momentum * (float)mean;
-                    q.running_var[c] = (1.f - q.momentum) * q.running_var[c] + q.momentum * (float)unbiased;
+                    rm[pc] = (1.f - q.momentum) * rm[pc] + q.momentum * (float)mean;
+                    rv[pc] = (1.f - q.momentum) * rv[pc] + q.momentum * (float)unbiased;
                 }
             }
         } else {
@@ -217,8 +228,10 @@ __device__ __forceinline__ void ew_prologue(const EwPro& q, float* lds) {
             lds[4 * C + c] = -sc * m1;
             if (writer) {
                 const float gs = (float)s * q.pgrad_scale, gss = (float)ss * q.pgrad_scale;
-                if (q.dbeta) q.dbeta[c] = q.accumulate ? q.dbeta[c] + gs : gs;
-                if (q.dgamma) q.dgamma[c] = q.accumulate ? q.dgamma[c] + gss : gss;
+                float* db = second ? q.dbeta2 : q.dbeta;
+                float* dg = second ? q.dgamma2 : q.dgamma;
+                if (db) db[pc] = q.accumulate ? db[pc] + gs : gs;
+                if (dg) dg[pc] = q.accumulate ? dg[pc] + gss : gss;
             }
         }
     }
@@ -510,7 +523,8 @@ extern "C" int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const flo
 extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, double count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                   float* scale, float* shift, float* mean, float* rstd, int32_t act,
-                                  const dsn_tensor* residual, const dsn_tensor* z, void* stream) {
+                                  const dsn_tensor* residual, const dsn_tensor* z, const dsn_bn_split* second,
+                                  void* stream) {
     DSN_CHECK_ARG(tensor_ok(y) && tensor_ok(z) && same_shape(y, z), "bn_act_fwd_acc: invalid tensors");
     DSN_CHECK_ARG(acc && scale && shift && mean && rstd, "bn_act_fwd_acc: null argument");
     DSN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_act_fwd_acc: running stats must come in pairs");
@@ -528,6 +542,13 @@ extern "C" int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t 
     pro.gamma = gamma; pro.beta = beta; pro.running_mean = running_mean; pro.running_var = running_var;
     pro.momentum = momentum; pro.eps = eps;
     pro.scale = scale; pro.shift = shift; pro.mean = mean; pro.rstd = rstd;
+    if (second && second->split_c > 0) {
+        DSN_CHECK_ARG(second->split_c < y->c && (second->running_mean == nullptr) == (running_mean == nullptr),
+                      "bn_act_fwd_acc: bad split");
+        pro.split = second->split_c;
+        pro.gamma2 = second->gamma; pro.beta2 = second->beta;
+        pro.running_mean2 = second->running_mean; pro.running_var2 = second->running_var;
+    }
     DSN_DISPATCH_DTYPE(y->dtype, T, {
         if (residual)
             launch_ew<T, true, FwdF>(v, y, residual, z, &pro, st, bp, true);
@@ -563,7 +584,7 @@ extern "C" int dsn_bn_act_bwd_reduce(const dsn_tensor* dz, const dsn_tensor* y, 
 extern "C" int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                                     const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                                     float* dbeta, int32_t accumulate, const void* workspace, int64_t workspace_bytes,
-                                    double count, float pgrad_scale, void* stream) {
+                                    double count, float pgrad_scale, const dsn_bn_split* second, void* stream) {
     DSN_CHECK_ARG(tensor_ok(dz) && tensor_ok(y) && tensor_ok(dy) && same_shape(dz, y) && same_shape(dy, y),
                   "bn_act_bwd_apply: invalid tensors");
     DSN_CHECK_ARG(scale && shift && mean && rstd && workspace, "bn_act_bwd_apply: null argument");
@@ -580,6 +601,11 @@ extern "C" int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, c
     pro.scale = (float*)scale; pro.shift = (float*)shift; pro.mean = (float*)mean; pro.rstd = (float*)rstd;   // read only
     pro.dgamma = dgamma; pro.dbeta = dbeta; pro.accumulate = accumulate;
     pro.pgrad_scale = pgrad_scale;
+    if (second && second->split_c > 0) {
+        DSN_CHECK_ARG(second->split_c < y->c, "bn_act_bwd_apply: bad split");
+        pro.split = second->split_c;
+        pro.dgamma2 = second->dgamma; pro.dbeta2 = second->dbeta;
+    }
     ProfScope prof(KID_BN_BWD_APPLY, 0.0, 3.0 * P * y->c * esz, st);
     DSN_DISPATCH_DTYPE(y->dtype, T, (launch_ew<T, true, BwdApplyF>(v, y, dz, dy, &pro, st, bp)));
     DSN_LAUNCH_CHECK("bn_act_bwd apply");
@@ -594,7 +620,7 @@ extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const f
     int rc = dsn_bn_act_bwd_reduce(dz, y, scale, shift, mean, rstd, act, workspace, workspace_bytes, stream);
     if (rc) return rc;
     return dsn_bn_act_bwd_apply(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate, workspace,
-                                workspace_bytes, 0.0, 1.f, stream);
+                                workspace_bytes, 0.0, 1.f, nullptr, stream);
 }
 
 extern "C" int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const dsn_tensor* dy, void* stream) {

@@ -123,8 +123,17 @@ def _sync_sum(acc_bytes_tensor, nbytes, group):
     dist.all_reduce(acc_bytes_tensor[:nbytes].view(torch.float64), op=dist.ReduceOp.SUM, group=group)
 
 
+def _bn_split(second):
+    """dsn_bn_split from (split_c, gamma2, beta2, running_mean2, running_var2, dgamma2, dbeta2) (None entries allowed)."""
+    if second is None:
+        return None, None
+    sc, g2, b2, rm2, rv2, dg2, db2 = second
+    st = _lib.dsn_bn_split(int(sc), 0, _p(g2), _p(b2), _p(rm2), _p(rv2), _p(dg2), _p(db2))
+    return st, C.byref(st)
+
+
 def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_mean, running_var, momentum, eps, act,
-                       residual, z, sync=None):
+                       residual, z, sync=None, second=None):
     """Training forward of conv -> BatchNorm -> act (+ shortcut) in TWO launches: the conv epilogue adds the per-channel
     sums into fp64 accumulators, the elementwise kernel folds them in its prologue (no statistics pass, no finalize
     launch).  Writes z; returns (scale, shift, mean, rstd) fp32 [C] for the backward pass."""
@@ -142,7 +151,8 @@ def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_
     out = torch.empty((4, c), dtype=torch.float32, device=y.device)
     _lib.check(L.dsn_bn_act_fwd_acc(C.byref(dy), acc.data_ptr(), nbytes, count, _p(gamma), _p(beta), _p(running_mean),
                                     _p(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
-                                    out[2].data_ptr(), out[3].data_ptr(), act, _ref(dr), C.byref(dz), stream_ptr()),
+                                    out[2].data_ptr(), out[3].data_ptr(), act, _ref(dr), C.byref(dz),
+                                    _bn_split(second)[1], stream_ptr()),
                "bn_act_fwd_acc")
     return out[0], out[1], out[2], out[3]
 
@@ -291,14 +301,37 @@ class WgradQueue:
 class WeightBank:
     """All conv weights of a model packed by ONE kernel launch per optimizer step (forward + dgrad layouts)."""
 
-    def __init__(self, convs, ci_pads, dtype, device, need_dgrad=True, co_pads=None):
+    def __init__(self, convs, ci_pads, dtype, device, need_dgrad=True, co_pads=None, pairs=()):
+        """pairs: (convA, convB) 1x1 convolutions of the SAME input that also run as one merged convolution with output
+        channels [A | B] (C3's cv2 | cv1): their forward layouts are placed back to back (`pair_fwd[A]` = the merged
+        [coA+coB][1][1][ci] matrix) and their dgrad layouts interleave into one [ci][1][1][coA+coB] matrix (`pair_dgrad[A]`)."""
         L = _lib.lib()
         es = 2 if dtype == torch.bfloat16 else 4
+        convs, ci_pads = list(convs), list(ci_pads)
+        co_pads = list(co_pads) if co_pads is not None else [c.out_channels for c in convs]
+        pairs = [(a, b) for a, b in pairs
+                 if a.kernel_size == (1, 1) and b.kernel_size == (1, 1) and a.in_channels == b.in_channels
+                 and a.bias is None and b.bias is None and a.stride == (1, 1) and b.stride == (1, 1)
+                 and ci_pads[convs.index(a)] == a.in_channels and ci_pads[convs.index(b)] == b.in_channels
+                 and (a.in_channels * a.out_channels) % 64 == 0]
+        second = {id(b) for _, b in pairs}
+        follow = {id(a): b for a, b in pairs}
+        order = []
+        for c in convs:                               # A immediately followed by B, everything else in module order
+            if id(c) in second:
+                continue
+            order.append(c)
+            if id(c) in follow:
+                order.append(follow[id(c)])
+        perm = [convs.index(c) for c in order]
+        convs, ci_pads, co_pads = order, [ci_pads[i] for i in perm], [co_pads[i] for i in perm]
+        for a, b in pairs:
+            co_pads[convs.index(a)] = co_pads[convs.index(b)] = a.out_channels + b.out_channels
+        self.ci_pads = ci_pads
         self.dtype, self.convs = dtype, list(convs)
         sizes_f = [c.out_channels * c.kernel_size[0] * c.kernel_size[1] * cp for c, cp in zip(self.convs, ci_pads)]
-        co_pads = list(co_pads) if co_pads is not None else [c.out_channels for c in self.convs]
         self.co_pads = co_pads
-        sizes_d = [c.weight.numel() // c.out_channels * cop for c, cop in zip(self.convs, co_pads)]
+        sizes_d = [0 if id(c) in second else c.weight.numel() // c.out_channels * cop for c, cop in zip(self.convs, co_pads)]
         al = lambda n: (n + 63) // 64 * 64
         self.fwd_buf = torch.zeros(sum(al(n) for n in sizes_f), dtype=dtype, device=device)    # ci_pad lanes stay zero
         self.dg_buf = torch.zeros(sum(al(n) for n in sizes_d), dtype=dtype, device=device) if need_dgrad else None    # co_pad lanes stay zero
@@ -313,14 +346,20 @@ class WeightBank:
         for i, (c, cp) in enumerate(zip(self.convs, ci_pads)):
             co, ci, kh, kw = c.weight.shape
             fv = self.fwd_buf[of:of + sizes_f[i]].view(co, kh, kw, cp)
-            dv = self.dg_buf[od:od + sizes_d[i]].view(ci, kh, kw, co_pads[i]) if need_dgrad else None
+            if id(c) in second:       # B of a pair: its dgrad columns live inside A's merged matrix, after A's coA columns
+                prev = self.convs[i - 1]
+                dv = None
+                dptr = self.dgrad[i - 1].data_ptr() + prev.out_channels * es if need_dgrad else None
+            else:
+                dv = self.dg_buf[od:od + sizes_d[i]].view(ci, kh, kw, co_pads[i]) if need_dgrad else None
+                dptr = dv.data_ptr() if need_dgrad else None
             sv = self.s2_buf[o2:o2 + sizes_2[i]].view(4 * ci, 2, 2, co) if is_s2[i] else None
             self.fwd.append(fv)
             self.dgrad.append(dv)
             self.dgrad_s2.append(sv)
             w = c.weight
             assert w.dtype == torch.float32 and w.is_contiguous()
-            descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dv.data_ptr() if need_dgrad else None,
+            descs[i] = _lib.dsn_pack_desc(w.data_ptr(), fv.data_ptr(), dptr,
                                           sv.data_ptr() if sv is not None else None, co, ci, kh, kw, cp, co_pads[i])
             work += [(i, t) for t in range(L.dsn_pack_tiles(co, ci, kh, kw))]
             of += al(sizes_f[i])
@@ -331,6 +370,15 @@ class WeightBank:
         self.work_dev = torch.tensor(work, dtype=torch.int32).to(device)
         self.n_work = len(work)
         self.ptrs = tuple(c.weight.data_ptr() for c in self.convs)
+        self.pair_fwd, self.pair_dgrad = {}, {}
+        for a, b in pairs:
+            i = self.convs.index(a)
+            fa, fb = self.fwd[i], self.fwd[i + 1]
+            assert fb.data_ptr() == fa.data_ptr() + fa.numel() * es, "pair forward layouts must be back to back"
+            n = fa.numel() + fb.numel()
+            start = (fa.data_ptr() - self.fwd_buf.data_ptr()) // es
+            self.pair_fwd[a] = (b, self.fwd_buf[start:start + n].view(a.out_channels + b.out_channels, 1, 1, a.in_channels))
+            self.pair_dgrad[a] = self.dgrad[i] if need_dgrad else None
 
     def valid_for(self, dtype):
         return dtype == self.dtype and self.ptrs == tuple(c.weight.data_ptr() for c in self.convs)
@@ -467,18 +515,21 @@ def bn_act_fwd(y, scale, shift, act, residual, z):
     return z
 
 
-def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False, sync=None):
+def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False, sync=None, second=None):
     a, b, c = desc(dz), desc(y), desc(dy)
     ws, nbytes = bn_acc(y.shape[1], y.device)
-    if sync is not None:                # SyncBatchNorm: global sums for dy, per-rank share of dgamma / dbeta
+    if sync is not None or second is not None:   # SyncBatchNorm: global sums for dy, per-rank share of dgamma / dbeta
         L = _lib.lib()
         _lib.check(L.dsn_bn_act_bwd_reduce(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                            rstd.data_ptr(), act, ws.data_ptr(), nbytes, stream_ptr()), "bn_act_bwd_reduce")
-        _sync_sum(ws, nbytes, sync[0])
-        count = float(y.shape[0] * y.shape[2] * y.shape[3]) * sync[1]
+        count, share = 0.0, 1.0
+        if sync is not None:
+            _sync_sum(ws, nbytes, sync[0])
+            count, share = float(y.shape[0] * y.shape[2] * y.shape[3]) * sync[1], 1.0 / sync[1]
         _lib.check(L.dsn_bn_act_bwd_apply(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),
-                                          ws.data_ptr(), nbytes, count, 1.0 / sync[1], stream_ptr()), "bn_act_bwd_apply")
+                                          ws.data_ptr(), nbytes, count, share, _bn_split(second)[1], stream_ptr()),
+                   "bn_act_bwd_apply")
         return dy
     _lib.check(_lib.lib().dsn_bn_act_bwd(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),

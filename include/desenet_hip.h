@@ -195,10 +195,22 @@ int dsn_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count
                     float* mean, float* rstd, void* stream);
 int dsn_bn_act_fwd(const dsn_tensor* y, const float* scale, const float* shift, int32_t act,
                    const dsn_tensor* residual, const dsn_tensor* z, void* stream);
+/* Two BatchNorm modules over ONE merged tensor (C3's cv2 and cv1 -- same input, common.py:143-145 -- run as a single
+ * convolution with 2c_ output channels): channels [split_c, C) belong to the second module, whose vectors below are indexed
+ * from 0.  NULL / split_c == 0: a single module. */
+typedef struct {
+    int32_t      split_c, _pad;
+    const float* gamma;
+    const float* beta;
+    float*       running_mean;
+    float*       running_var;
+    float*       dgamma;
+    float*       dbeta;
+} dsn_bn_split;
 int dsn_bn_act_fwd_acc(const dsn_tensor* y, const void* acc, int64_t acc_bytes, double count, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                        float* mean, float* rstd, int32_t act, const dsn_tensor* residual, const dsn_tensor* z,
-                       void* stream);
+                       const dsn_bn_split* second, void* stream);
 int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                    const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                    float* dbeta, int32_t accumulate_param_grads, void* workspace, int64_t workspace_bytes,
@@ -209,7 +221,7 @@ int dsn_bn_act_bwd_reduce(const dsn_tensor* dz, const dsn_tensor* y, const float
 int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                          const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                          float* dbeta, int32_t accumulate_param_grads, const void* workspace, int64_t workspace_bytes,
-                         double count, float pgrad_scale, void* stream);
+                         double count, float pgrad_scale, const dsn_bn_split* second, void* stream);
 /* act backward without BN (conv -> act, quirk Q1 path and FFM attention): dy = dz * act'(y) */
 int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const dsn_tensor* dy, void* stream);
 

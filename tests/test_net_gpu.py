@@ -169,6 +169,48 @@ def test_train_step_gradients(net, tag, bs, size, seed, dtype, ltol, gtol):
             assert_close(params[name].grad.float().cpu(), g[k], gtol, name)
 
 
+def test_train_step_with_merged_c3_pairs_vs_reference(net, monkeypatch):
+    """With gradient slots attached (FlatGradients) every C3 runs cv2 | cv1 as ONE convolution + ONE BatchNorm launch
+    (conv_impl.pair_block_*): the same reference goldens (G3: losses, outputs, gradient norm, full gradients), fp32."""
+    import copy
+    from desenet_amd import conv_impl
+    from desenet_amd.core.models import common
+    from desenet_amd.core.utils.hyp import scale_hyp
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from desenet_amd.parallel import FlatGradients
+    dsn, m = net
+    g, tag = golden("train"), "n2_128"
+    calls = []
+    real = conv_impl.pair_block_fwd
+    monkeypatch.setattr(common, "pair_block_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    mt = copy.deepcopy(m).train()
+    mt.hyp = dict(scale_hyp(6, 128), label_smoothing=0.0)
+    flat = FlatGradients(mt.parameters())
+    flat.zero()
+    x = synth_images(2, 128, 21).cuda()
+    det_t, seg_t = synth_targets(2, 128, 21)
+    det_pred, seg_pred = mt(x)
+    det_loss, items = ComputeLoss(mt)(det_pred, det_t.cuda())
+    seg_loss = SegmentationLosses()(seg_pred, seg_t.cuda())
+    (det_loss * 0.14 + seg_loss * 1.0).backward()
+    assert len(calls) == sum(isinstance(mod, common.C3) for mod in mt.modules()) == 8
+    assert_close(det_loss.cpu(), g[f"{tag}/det_loss"], 1e-3, "det_loss")
+    assert_close(seg_loss.cpu(), g[f"{tag}/seg_loss"], 1e-3, "seg_loss")
+    for j in range(3):
+        assert_close(det_pred[j].float().cpu(), g[f"{tag}/raw{j}"], 1e-3, f"raw{j}")
+    assert_close(seg_pred.float().cpu(), g[f"{tag}/seg"], 1e-3, "seg")
+    params = dict(mt.named_parameters())
+    names = [str(k) for k in g[f"{tag}/grad_names"]]
+    sq = np.array([(params[k].grad.double() ** 2).sum().item() for k in names])
+    np.testing.assert_allclose(np.sqrt(sq.sum()), g[f"{tag}/grad_l2"], rtol=2e-2)
+    # per-parameter gradient energy: covers cv1 / cv2 weights and BatchNorm parameters of every merged pair
+    np.testing.assert_allclose(np.sqrt(sq), np.sqrt(g[f"{tag}/grad_sq"]), rtol=8e-2, atol=2e-2 * float(g[f"{tag}/grad_l2"]) * 1e-2)
+    for k in g.files:
+        if k.startswith(f"{tag}/grad/"):
+            name = k.split("/grad/")[1]
+            assert_close(params[name].grad.float().cpu(), g[k], 2e-2, name)
+
+
 def test_two_backward_calls_like_the_reference(net):
     """scripts/train.py:366-367 calls backward twice on one forward (retain_graph=True): det first, seg second; the
     accumulated gradients must equal one combined backward.  Fixed upstream gradients are used instead of the losses:
@@ -199,7 +241,9 @@ def test_two_backward_calls_like_the_reference(net):
 
 def test_direct_accumulation_into_flat_gradients(net):
     """With FlatGradients every .grad is a view of one buffer and the kernels accumulate into it directly (no autograd
-    temporaries): same numbers as the plain autograd path, and a second step after zero() is identical (deterministic)."""
+    temporaries): same numbers as the plain autograd path, and a second step after zero() is identical (deterministic).
+    With gradient slots present C3 runs cv2 | cv1 as one merged convolution (one K = 2c_ dgrad instead of two accumulated
+    ones: another fp32 summation order, amplified by ~70 batch-statistics layers to 5e-5 at layer 0) -- tolerance 2e-4."""
     import copy
     from desenet_amd.parallel import FlatGradients
     _, m = net
@@ -225,7 +269,7 @@ def test_direct_accumulation_into_flat_gradients(net):
         for k, p in direct.named_parameters():
             assert p.grad.untyped_storage().data_ptr() == flat.flat.untyped_storage().data_ptr()
             if k in ref:
-                assert rel_err(p.grad.cpu(), ref[k].cpu()) < 1e-5, (rep, k)
+                assert rel_err(p.grad.cpu(), ref[k].cpu()) < 2e-4, (rep, k)
             else:
                 assert float(p.grad.abs().max()) == 0.0, k
     assert int(direct.state_dict()["model.0.conv.bn.num_batches_tracked"]) == 1
@@ -280,7 +324,7 @@ def test_graph_replay_equals_eager_training(net, fused):
             assert torch.equal(sd_g[k].cpu(), sd_e[k].cpu()), k
     # every replay must re-pack the weights the previous replay's optimizer step produced (a stale bank would train on old
     # bf16/fp32 copies forever): the bank after replay n+1 is exactly pack(master weights after replay n)
-    convs = [c for c in mg.modules() if isinstance(c, torch.nn.Conv2d)]
+    convs = list(mg.__dict__["_dsn_bank"].convs)          # the bank's own order (C3's cv2 | cv1 pairs are adjacent)
     snap = [c.weight.detach().clone() for c in convs]
     step()
     bank = mg.__dict__["_dsn_bank"]
