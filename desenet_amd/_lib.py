@@ -52,6 +52,7 @@ PROTOTYPES = {
     "dsn_last_error": (C.c_char_p, []),
     "dsn_conv2d_fwd": (i32, [TP, vp, vp, TP, TP, CP, vp]),
     "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
+    "dsn_conv2d_dgrad_res": (i32, [TP, vp, TP, CP, TP, vp]),
     "dsn_conv2d_dgrad_s2": (i32, [TP, vp, TP, CP, vp]),
     "dsn_conv2d_stats_rows": (i32, [i64]),
     "dsn_conv2d_fwd_stats": (i32, [TP, vp, TP, CP, vp, vp, vp]),

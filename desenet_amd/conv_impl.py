@@ -251,8 +251,9 @@ def _grad_slot(p):
     return g
 
 
-def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
+def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, residual=None):
     """Backward of conv_block_fwd.  dz: gradient of the block output (the caller routes dz to a shortcut itself).
+    residual: a tensor of dx's shape added to the input gradient in the dgrad epilogue (a shortcut's gradient).
     A dz whose rows are padded with ZEROS up to a multiple of the vector width (ops.new_act(ldc_align=...), padding cleared by
     its producer -- Detect.bwd does this for its 33-channel heads) takes the 16-byte paths: the weight gradient ignores the
     padding lanes, the input gradient runs over the padded K axis with zero-padded weights."""
@@ -314,5 +315,8 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
             # stride-2 3x3: one 2x2 stride-1 conv over dy + depth-to-space store (weights packed by the model's WeightBank)
             ops.conv2d_dgrad_s2(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc))
         else:
-            ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc))
+            ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc), residual=residual)
+            residual = None
+    if residual is not None:                       # (paths without a fused epilogue add: not taken by Bottleneck's 1x1)
+        ops.copy(residual, dx, accumulate=True)
     return dx

@@ -74,8 +74,8 @@ class Conv(HipModule):
         return conv_block_fwd(x, self.conv, bn, act_code(self.act), self.training, tape, out, residual,
                               q1=not self.fused, ci_pad=ci_pad)
 
-    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
-        return conv_block_bwd(tape, dy, dx, acc, need_dx)
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, residual=None):
+        return conv_block_bwd(tape, dy, dx, acc, need_dx, residual)
 
     def forward_fuse(self, x):   # reference API (common.py:55-56); the fused state is detected from the missing `bn`
         return self.forward(x)
@@ -96,14 +96,8 @@ class Bottleneck(HipModule):
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         dt = self.cv2.bwd(tape, dy)
-        if self.add and need_dx:
-            if dx is None:
-                dx = ops.new_act(*dy.shape, dy.dtype, dy.device)
-                ops.copy(dy, dx)
-            else:
-                ops.copy(dy, dx, accumulate=acc)
-            acc = True
-        return self.cv1.bwd(tape, dt, dx, acc, need_dx)
+        # shortcut: d x = dy + d cv1 -- dy rides in the epilogue of cv1's input gradient (no copy / add pass)
+        return self.cv1.bwd(tape, dt, dx, acc, need_dx, residual=dy if (self.add and need_dx) else None)
 
 
 class C3(HipModule):

@@ -682,21 +682,39 @@ extern "C" int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const
     return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
 }
 
-extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
-                                void* stream) {
+namespace {
+int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
+                    const dsn_tensor* residual, void* stream) {
     int rc = check_common(dy, w, dx, p);
     if (rc) return rc;
     const int ho = (dx->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int wo = (dx->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     DSN_CHECK_ARG(ho == dy->h && wo == dy->w, "conv dgrad: dy is %dx%d, expected %dx%d", dy->h, dy->w, ho, wo);
+    if (residual)
+        DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == dx->dtype && residual->n == dx->n && residual->h == dx->h &&
+                          residual->w == dx->w && residual->c == dx->c && p->stride == 1,
+                      "conv dgrad: residual must have dx's shape (stride-1 convolutions only)");
     Geom g{};
     g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;
     g.Hs = dy->h; g.Ws = dy->w; g.Cs = dy->c; g.Cd = dx->c;
     g.KH = p->kh; g.KW = p->kw; g.Ktot = p->kh * p->kw * dy->c;
     g.a = 1; g.b = p->pad; g.d = -p->dil; g.q = p->stride;
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
-    g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
+    g.sld = dy->ldc; g.dld = dx->ldc; g.rld = residual ? residual->ldc : 0;
     if (dy->dtype == DSN_F32)
-        return launch<float>(dy, w, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
-    return launch<bf16_t>(dy, w, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+        return launch<float>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+    return launch<bf16_t>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+}
+}  // namespace
+
+extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
+                                void* stream) {
+    return conv_dgrad_impl(dy, w, dx, p, nullptr, stream);
+}
+
+// dx (+)= conv_transpose(dy, w) + residual: the Bottleneck shortcut's gradient (common.py:111, `x + cv2(cv1(x))`) rides in the
+// epilogue of cv1's input gradient instead of a separate copy / add pass.
+extern "C" int dsn_conv2d_dgrad_res(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
+                                    const dsn_tensor* residual, void* stream) {
+    return conv_dgrad_impl(dy, w, dx, p, residual, stream);
 }

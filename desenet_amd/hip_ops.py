@@ -165,9 +165,15 @@ def conv2d_dgrad_s2(dy, w_s2, dx, p: dsn_conv_params):
     return dx
 
 
-def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params):
+def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params, residual=None):
+    """dx (+)= conv_transpose(dy, w) (+ residual: a shortcut's gradient, added in the epilogue)."""
     L = _lib.lib()
     a, b = desc(dy), desc(dx)
+    if residual is not None:
+        r = desc(residual)
+        _lib.check(L.dsn_conv2d_dgrad_res(C.byref(a), w_packed_dgrad.data_ptr(), C.byref(b), C.byref(p), C.byref(r),
+                                          stream_ptr()), "conv2d_dgrad_res")
+        return dx
     _lib.check(L.dsn_conv2d_dgrad(C.byref(a), w_packed_dgrad.data_ptr(), C.byref(b), C.byref(p), stream_ptr()),
                "conv2d_dgrad")
     return dx

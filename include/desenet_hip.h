@@ -72,6 +72,10 @@ int dsn_conv2d_fwd(const dsn_tensor* x, const void* w_packed, const float* bias,
                    const dsn_tensor* y, const dsn_conv_params* p, void* stream);
 int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w_packed, const dsn_tensor* dx, const dsn_conv_params* p,
                      void* stream);
+/* dx (+)= conv_transpose(dy, w) + residual (residual: dx's shape, stride-1 convs): the gradient of the Bottleneck shortcut
+ * `x + cv2(cv1(x))` (common.py:111) added in the epilogue of cv1's input gradient. */
+int dsn_conv2d_dgrad_res(const dsn_tensor* dy, const void* w_packed, const dsn_tensor* dx, const dsn_conv_params* p,
+                         const dsn_tensor* residual, void* stream);
 /* Input gradient of a 3x3 / stride 2 / pad 1 conv as one 2x2 stride-1 conv over dy + depth-to-space store (weights in the
  * dsn_pack_desc.out_dgrad_s2 layout).  Same result as dsn_conv2d_dgrad; needs 16-byte-aligned channel counts. */
 int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
