@@ -86,7 +86,11 @@ class SegMaskPSP(HipModule):
         dev = dy.device
         c = self.m8[0].conv.out_channels
         g = dy if (dy.dtype == torch.float32 and dy.is_contiguous()) else dy.float().contiguous()
-        dlog = ops.bilinear_ac_bwd(g, ops.new_act(*sl, dt, dev), dy_nchw=True)
+        # rows padded with zeros to the 16-byte vector (2 -> 4 / 8 classes): the classifier's weight and input gradients take the
+        # vector paths (and the weight gradient joins the grouped launch) instead of the scalar-load ones
+        vec = 4 if dt == torch.float32 else 8
+        dlog = ops.bilinear_ac_bwd(g, ops.new_act(*sl, dt, dev, zero=True, ldc_align=vec), dy_nchw=True)
+        dlog._dsn_zero_padded = True
         d_y = conv_block_bwd(tape, dlog)
         dpp = self.out[2].bwd(tape, d_y)
         drfb = self.out[1].bwd(tape, dpp)
@@ -323,6 +327,7 @@ class Model(HipModule):
             focus_convs = {m.conv.conv for m in self.modules() if isinstance(m, Focus)}
             pads = [((c.in_channels + vec - 1) // vec * vec) if c in focus_convs else c.in_channels for c in convs]
             det_convs = {c for m in self.modules() if isinstance(m, Detect) for c in m.m}
+            det_convs |= {m.out[3] for m in self.modules() if isinstance(m, SegMaskPSP)}    # seg classifier: same row padding
             co_pads = [((c.out_channels + vec - 1) // vec * vec) if c in det_convs else c.out_channels for c in convs]
             # C3's cv2 and cv1 read the same input: packed back to back they also run as ONE convolution (conv_impl.pair_block_*)
             pairs = [(m.cv2.conv, m.cv1.conv) for m in self.modules() if isinstance(m, C3) and not m.cv1.fused]
