@@ -144,16 +144,21 @@ def roofline_from_profile(prof, steps, dtype):
     name = max(prof, key=lambda k: prof[k]["ms"])
     r = prof[name]
     avg_ms = r["ms"] / r["launches"]
-    if r["flops"] > 0:
-        peak = PEAK["mfma_bf16_TFs"] if "bf16" in name else PEAK["mfma_f32_TFs"]
+    peak_tf = PEAK["mfma_bf16_TFs"] if "bf16" in name else PEAK["mfma_f32_TFs"]
+    ridge = peak_tf * 1e12 / (PEAK["hbm_GBs"] * 1e9)          # FLOP per byte where the two roofs meet (312 bf16 / 20 fp32)
+    intensity = r["flops"] / r["bytes"] if r["bytes"] else 0.0
+    # a kernel whose algorithmic intensity is below the ridge is priced against HBM, above it against MFMA
+    if r["flops"] > 0 and intensity >= ridge:
         ach = r["flops"] / r["launches"] / (avg_ms * 1e-3) / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
     else:
         ach = r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9
         roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK["hbm_GBs"], "unit": "GB/s",
                 "frac": ach / PEAK["hbm_GBs"]}
     roof.update({"avg_launch_us": avg_ms * 1e3, "launches_per_step": r["launches"] / steps,
-                 "algorithmic_GBs": r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9, "traffic": None})
+                 "algorithmic_GBs": r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9,
+                 "algorithmic_TFLOPs": (r["flops"] / r["launches"] / (avg_ms * 1e-3) / 1e12) if r["flops"] else None,
+                 "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "traffic": None})
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
