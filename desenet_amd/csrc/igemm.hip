@@ -41,6 +41,7 @@ struct Geom {
     // depth-to-space store (stride-2 dgrad as a 2x2 stride-1 conv over dy): GEMM column (cls, ci), cls = py*2 + px, of GEMM
     // row (n, y, x) lands at destination pixel (n, 2y + py, 2x + px), channel ci.  d2s_c = channels per sub-pixel (0 = off).
     int32_t d2s_c, Hout, Wout;
+    int32_t longk;        // K chunks from which the branch-free main loop is used (tuning knob DSN_IGEMM_LONGK)
     uint32_t src_bytes, w_bytes;   // buffer-descriptor ranges: out-of-range lanes of a buffer_load return 0 (free zero padding)
     // stride-2 dgrad by destination-pixel parity class (py, px): only the taps that can reach a class are visited
     // (1 + 2 + 2 + 4 of the 9 taps of a 3x3 instead of 9 masked ones for every pixel).  Class c = py*2 + px.
@@ -355,20 +356,44 @@ __global__ __launch_bounds__(256, (MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : MI * NI <
     // ---- main loop: NST register stages feeding 2 LDS buffers, one barrier per chunk ------------------------------------
     // step i: loads of chunk i+NST go into the stage that held chunk i (already in LDS), chunk i runs on the matrix cores,
     // chunk i+1 moves from its stage into the other LDS buffer.
+    // Two forms.  Long K (>= g.longk chunks, the 3x3 layers): BRANCH-FREE body -- loads past the last chunk are issued anyway
+    // (offsets out of range: zeros, no traffic) and the only control flow is the uniform loop exit, so the compiler's
+    // s_waitcnt bookkeeping keeps two chunks in flight (vmcnt(8..11) in the ISA).  With the guards of the short form it joins
+    // the paths pessimistically and waits for the loads of the SAME iteration (vmcnt(0..3)): harmless when operands sit in
+    // L2, a full HBM round trip per chunk when they are cold, as weights are right after the per-step re-pack.  Short K keeps
+    // the guarded form: no wasted out-of-range loads / LDS stores when a block's life is two or three chunks.
+    if (nchunks >= g.longk) {
 #pragma unroll
-    for (int s = 0; s < NST; ++s)
-        if (nchunks > s) load_chunk(s, rga[s], rgb[s]);
-    if (nchunks > 0) store_chunk(0, rga[0], rgb[0]);
-    __syncthreads();
-    for (int it = 0; it < nchunks; it += NST) {
+        for (int s = 0; s < NST; ++s) load_chunk(s, rga[s], rgb[s]);
+        store_chunk(0, rga[0], rgb[0]);
+        __syncthreads();
+        for (int it = 0; it < nchunks; it += NST) {
 #pragma unroll
-        for (int s = 0; s < NST; ++s) {
-            const int i = it + s;
-            if (i < nchunks) {
-                if (i + NST < nchunks) load_chunk(i + NST, rga[s], rgb[s]);
+            for (int s = 0; s < NST; ++s) {
+                const int i = it + s;
+                if (s > 0 && i >= nchunks) break;
+                load_chunk(i + NST, rga[s], rgb[s]);
                 compute(i & 1);
-                if (i + 1 < nchunks) store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST]);
+                store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST]);
                 __syncthreads();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+            if (nchunks > s) load_chunk(s, rga[s], rgb[s]);
+        if (nchunks > 0) store_chunk(0, rga[0], rgb[0]);
+        __syncthreads();
+        for (int it = 0; it < nchunks; it += NST) {
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                const int i = it + s;
+                if (i < nchunks) {
+                    if (i + NST < nchunks) load_chunk(i + NST, rga[s], rgb[s]);
+                    compute(i & 1);
+                    if (i + 1 < nchunks) store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST]);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -535,6 +560,8 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
                    elems * sizeof(T), st);
     static const bool no_uni = getenv("DSN_IGEMM_NOUNI") != nullptr;                                          // tuning knob
+    static const int longk = [] { const char* e = getenv("DSN_IGEMM_LONGK"); return e ? atoi(e) : 9; }();
+    g.longk = longk;
     const bool uni = vec && !par && g.q == 1 && g.Cs % (ROWB / (int)sizeof(T)) == 0 && g.KH * g.KW <= 32 && !no_uni;
     if (par)
         hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g);
@@ -582,7 +609,7 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     }
     if (tiles64 >= 1536 && g.Ktot >= 1024 && g.Cd >= 128)
         return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 128x128
-    if (tiles64 < 256)
+    if (tiles64 < 256 || (tiles64 <= 400 && g.Ktot <= 512))      // (short-K layers on 40x40 / 20x20 maps: measured 5.0 vs 5.6 us)
         return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);      // 32x64
     return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out);          // 64x64
 }
