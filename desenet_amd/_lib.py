@@ -86,6 +86,9 @@ PROTOTYPES = {
     "dsn_bn_act_bwd_apply": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, f64, f32, vp, vp]),
     "dsn_act_bwd": (i32, [TP, TP, i32, TP, vp]),
     "dsn_focus_s2d": (i32, [vp, i32, i32, i32, i32, TP, vp]),
+    "dsn_adaptive_avgpool_multi": (i32, [TP, vp, i32, vp, i64, vp]),
+    "dsn_bilinear_ac_multi": (i32, [vp, vp, i32, vp]),
+    "dsn_bilinear_ac_bwd_multi": (i32, [vp, vp, i32, i32, vp, i64, vp]),
     "dsn_letterbox_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dsn_focus_s2d_u8": (i32, [vp, i32, i32, i32, i32, TP, vp]),
     "dsn_maxpool_s1": (i32, [TP, TP, vp, i32, vp]),

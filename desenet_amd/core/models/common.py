@@ -375,11 +375,11 @@ class PyramidPooling(HipModule):
             out = ops.new_act(n, base + 4 * oc, h, w, x.dtype, x.device)
         if self.short_cut and out[:, :c].data_ptr() != x.data_ptr():
             ops.copy(x, out[:, :c])
-        for j, (pool, conv) in enumerate(self._branches()):
-            ksz = pool.output_size if isinstance(pool.output_size, int) else pool.output_size[0]
-            pooled = ops.adaptive_avgpool(x, ops.new_act(n, c, ksz, ksz, x.dtype, x.device))
-            f = conv.fwd(pooled, tape)
-            ops.bilinear_ac(f, out[:, base + j * oc: base + (j + 1) * oc])
+        # each stage of the four branches is ONE launch: pools (x read once), then the tiny convs, then the upsampling
+        ks = [p.output_size if isinstance(p.output_size, int) else p.output_size[0] for p, _ in self._branches()]
+        pooled = ops.adaptive_avgpool_multi(x, [ops.new_act(n, c, k, k, x.dtype, x.device) for k in ks])
+        fs = [conv.fwd(pooled[j], tape) for j, (_, conv) in enumerate(self._branches())]
+        ops.bilinear_ac_multi(fs, [out[:, base + j * oc: base + (j + 1) * oc] for j in range(len(fs))])
         if tape is not None:
             tape.push((n, c, h, w))
         return out
@@ -396,13 +396,14 @@ class PyramidPooling(HipModule):
         elif self.short_cut:
             ops.copy(dy[:, :c], dx, accumulate=acc)
             acc = True
-        dpools = []
-        for j, (pool, conv) in reversed(list(enumerate(self._branches()))):
-            ksz = pool.output_size if isinstance(pool.output_size, int) else pool.output_size[0]
-            df = ops.bilinear_ac_bwd(dy[:, base + j * oc: base + (j + 1) * oc],
-                                     ops.new_act(n, oc, ksz, ksz, dy.dtype, dy.device))
-            dpools.append(conv.bwd(tape, df))
-        ops.adaptive_avgpool_bwd_multi(dpools, dx, accumulate=acc)      # the four grids in one pass over dx
+        br = list(enumerate(self._branches()))
+        ks = [p.output_size if isinstance(p.output_size, int) else p.output_size[0] for _, (p, _) in br]
+        dfs = ops.bilinear_ac_bwd_multi([dy[:, base + j * oc: base + (j + 1) * oc] for j, _ in br],
+                                        [ops.new_act(n, oc, k, k, dy.dtype, dy.device) for k in ks])    # one launch pair
+        dpools = [None] * len(br)
+        for j, (_, conv) in reversed(br):             # tape order: the branches' convs were recorded 0..3
+            dpools[j] = conv.bwd(tape, dfs[j])
+        ops.adaptive_avgpool_bwd_multi(dpools[::-1], dx, accumulate=acc)      # the four grids in one pass over dx
         return dx
 
 

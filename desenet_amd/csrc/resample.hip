@@ -414,6 +414,46 @@ __global__ void bilinear_vec_kernel(const T* __restrict__ x, int64_t xld, T* __r
     }
 }
 
+// up to four (source, destination) pairs in ONE launch: job j owns blocks [blk0[j], blk0[j+1]) (PyramidPooling's branches)
+struct BilinearMulti {
+    const void* x[4];
+    void* y[4];
+    int64_t xld[4], yld[4];
+    int32_t hi[4], wi[4], c[4];
+    float sh[4], sw[4];
+    int32_t blk0[5];
+    int32_t n, N, Ho, Wo;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bilinear_vec_multi_kernel(const BilinearMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.blk0[j + 1]) ++j;
+    const T* __restrict__ x = (const T*)m.x[j];
+    T* __restrict__ y = (T*)m.y[j];
+    const int Hi = m.hi[j], Wi = m.wi[j], ncv = m.c[j] / V;
+    const int64_t xld = m.xld[j], yld = m.yld[j];
+    const float sh = m.sh[j], sw = m.sw[j];
+    const int64_t total = (int64_t)m.N * m.Ho * m.Wo * ncv;
+    const int nblk = m.blk0[j + 1] - m.blk0[j];
+    for (int64_t i = ((int64_t)blockIdx.x - m.blk0[j]) * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+        const int cv = (int)(i % ncv);
+        int64_t t = i / ncv;
+        const int w = (int)(t % m.Wo); t /= m.Wo;
+        const int h = (int)(t % m.Ho);
+        const int n = (int)(t / m.Ho);
+        const Lerp a = lerp_coord(h, sh, Hi), b = lerp_coord(w, sw, Wi);
+        const T* base = x + (int64_t)n * Hi * Wi * xld + cv * V;
+        float v00[V], v01[V], v10[V], v11[V], o[V];
+        VecIO<T, V>::load(base + ((int64_t)a.i0 * Wi + b.i0) * xld, v00);
+        VecIO<T, V>::load(base + ((int64_t)a.i0 * Wi + b.i1) * xld, v01);
+        VecIO<T, V>::load(base + ((int64_t)a.i1 * Wi + b.i0) * xld, v10);
+        VecIO<T, V>::load(base + ((int64_t)a.i1 * Wi + b.i1) * xld, v11);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = a.l0 * (b.l0 * v00[k] + b.l1 * v01[k]) + a.l1 * (b.l0 * v10[k] + b.l1 * v11[k]);
+        VecIO<T, V>::store(y + (((int64_t)n * m.Ho + h) * m.Wo + w) * yld + cv * V, o);
+    }
+}
+
 // gather form with 16-byte channel vectors (NHWC dy)
 template <typename T, int V>
 __global__ void bilinear_bwd_vec_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld, int N, int Hi,
@@ -704,11 +744,10 @@ struct WRGeom {
 };
 
 template <typename T, int MODE, int V>
-__global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
-                                                            float* __restrict__ partial, const WRGeom g) {
-    __shared__ float red[256 * V];
-    const int s = blockIdx.x % g.S;
-    const int seg = blockIdx.x / g.S;
+__device__ __forceinline__ void window_reduce_body(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ partial,
+                                                   const WRGeom& g, const int bid, float* red) {
+    const int s = bid % g.S;
+    const int seg = bid / g.S;
     const int kw = seg % g.KW, kh = (seg / g.KW) % g.KH, n = seg / (g.KW * g.KH);
     int h0 = 0, h1 = g.H, w0 = 0, w1 = g.W;
     float inv = 1.f;
@@ -730,7 +769,7 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict_
     const int ncv = g.C / V;                      // V channels per thread (16-byte loads when V > 1)
     const int TX = ncv < 256 ? ncv : 256, TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    float* out = partial + (int64_t)blockIdx.x * g.C;
+    float* out = partial + (int64_t)bid * g.C;
     for (int cv0 = 0; cv0 < ncv; cv0 += TX) {
         const int cv = cv0 + tx;
         float acc[V];
@@ -780,16 +819,44 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict_
     }
 }
 
+template <typename T, int MODE, int V>
+__global__ __launch_bounds__(256) void window_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                            float* __restrict__ partial, const WRGeom g) {
+    __shared__ float red[256 * V];
+    window_reduce_body<T, MODE, V>(x, y, partial, g, (int)blockIdx.x, red);
+}
+
+// Up to four window reductions in ONE launch (PyramidPooling: the four adaptive pools of one map, and the four small-source
+// bilinear backward passes of its branches): job j owns blocks [blk0[j], blk0[j+1]).
+constexpr int WR_MAXJOBS = 4;
+struct WRMulti {
+    WRGeom g[WR_MAXJOBS];
+    const void* x[WR_MAXJOBS];
+    float* partial[WR_MAXJOBS];
+    void* out[WR_MAXJOBS];
+    int64_t old_[WR_MAXJOBS];
+    int32_t blk0[WR_MAXJOBS + 1];      // reduce kernel
+    int32_t fin0[WR_MAXJOBS + 1];      // finalize kernel
+    int32_t nseg[WR_MAXJOBS];
+    int32_t n, accumulate;
+};
+template <typename T, int MODE, int V>
+__global__ __launch_bounds__(256) void window_reduce_multi_kernel(const WRMulti m) {
+    __shared__ float red[256 * V];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.blk0[j + 1]) ++j;
+    window_reduce_body<T, MODE, V>((const T*)m.x[j], (const T*)nullptr, m.partial[j], m.g[j], (int)blockIdx.x - m.blk0[j], red);
+}
+
 // out[seg][c] (+)= sum_k partial[seg*S + k][c].  A block owns one segment and 32 channels; its 8 thread groups each add
 // every 8th partial row (independent loads in flight), LDS folds the 8 sums in a fixed order.  (One thread per output
 // walking all S rows serially took 13 us for a few KB.)
 template <typename T>
-__global__ __launch_bounds__(256) void window_finalize_kernel(const float* __restrict__ partial, int S, int64_t nseg, int C,
-                                                              T* __restrict__ out, int64_t old_, int accumulate) {
-    __shared__ float red[8][33];
+__device__ __forceinline__ void window_finalize_body(const float* __restrict__ partial, int S, int C, T* __restrict__ out,
+                                                     int64_t old_, int accumulate, const int bid, float (*red)[33]) {
     const int cgroups = (C + 31) / 32;
-    const int64_t seg = blockIdx.x / cgroups;
-    const int c = (blockIdx.x % cgroups) * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+    const int64_t seg = bid / cgroups;
+    const int c = (bid % cgroups) * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
     float v0 = 0.f, v1 = 0.f;
     if (c < C) {
         const float* src = partial + seg * S * C + c;
@@ -807,6 +874,22 @@ __global__ __launch_bounds__(256) void window_finalize_kernel(const float* __res
         if (accumulate) v += to_f32<T>(*o);
         *o = from_f32<T>(v);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_finalize_kernel(const float* __restrict__ partial, int S, int64_t nseg, int C,
+                                                              T* __restrict__ out, int64_t old_, int accumulate) {
+    __shared__ float red[8][33];
+    window_finalize_body<T>(partial, S, C, out, old_, accumulate, (int)blockIdx.x, red);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_finalize_multi_kernel(const WRMulti m) {
+    __shared__ float red[8][33];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.fin0[j + 1]) ++j;
+    window_finalize_body<T>(m.partial[j], m.g[j].S, m.g[j].C, (T*)m.out[j], m.old_[j], m.accumulate, (int)blockIdx.x - m.fin0[j],
+                            red);
 }
 
 inline int wr_splits(int64_t nseg, int rows) {
@@ -1157,6 +1240,112 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
                                accumulate);
     });
     DSN_LAUNCH_CHECK("bilinear_ac_bwd");
+    return DSN_OK;
+}
+
+// ---- PyramidPooling's four branches in one launch per stage (common.py:597-615) ------------------------------------------
+namespace {
+template <int MODE>
+int window_multi(const dsn_tensor* const* big, const dsn_tensor* const* small_, int n, int accumulate, void* workspace,
+                 int64_t workspace_bytes, hipStream_t st, const char* what) {
+    WRMulti m{};
+    m.n = n;
+    m.accumulate = accumulate;
+    int64_t off = 0;
+    int blk = 0, fin = 0;
+    for (int j = 0; j < n; ++j) {
+        const dsn_tensor* B = big[j];
+        const dsn_tensor* S = small_[j];
+        const int64_t nseg = (int64_t)S->n * S->h * S->w;
+        const int splits = wr_splits(nseg, B->h);
+        float sh = 0.f, sw = 0.f;
+        if (MODE == WR_BILINEAR_BWD) { sh = ac_scale(S->h, B->h); sw = ac_scale(S->w, B->w); }
+        m.g[j] = WRGeom{B->n, B->h, B->w, B->c, S->h, S->w, splits, sh, sw, B->ldc, 0};
+        m.x[j] = B->ptr;
+        m.partial[j] = (float*)((char*)workspace + off);
+        m.out[j] = S->ptr;
+        m.old_[j] = S->ldc;
+        m.nseg[j] = (int32_t)nseg;
+        m.blk0[j] = blk;
+        m.fin0[j] = fin;
+        blk += (int)(nseg * splits);
+        fin += (int)(nseg * ((S->c + 31) / 32));
+        off += nseg * splits * B->c * (int64_t)sizeof(float);
+    }
+    m.blk0[n] = blk;
+    m.fin0[n] = fin;
+    if (!workspace || workspace_bytes < off) DSN_FAIL(DSN_EWORKSPACE, "%s: workspace too small", what);
+    DSN_DISPATCH_DTYPE(big[0]->dtype, T, {
+        hipLaunchKernelGGL((window_reduce_multi_kernel<T, MODE, VW<T>::N>), dim3((unsigned)blk), dim3(256), 0, st, m);
+        hipLaunchKernelGGL(window_finalize_multi_kernel<T>, dim3((unsigned)fin), dim3(256), 0, st, m);
+    });
+    return DSN_OK;
+}
+}  // namespace
+
+// ys[j] = AdaptiveAvgPool2d(ys[j].h)(x) for up to four output sizes: x is read by ONE reduction launch, one finalize launch
+extern "C" int dsn_adaptive_avgpool_multi(const dsn_tensor* x, const dsn_tensor* ys, int32_t n_out, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && ys && n_out >= 1 && n_out <= WR_MAXJOBS && vec16(x), "adaptive_avgpool_multi: invalid arguments");
+    const dsn_tensor* big[WR_MAXJOBS];
+    const dsn_tensor* sm[WR_MAXJOBS];
+    for (int j = 0; j < n_out; ++j) {
+        DSN_CHECK_ARG(tensor_ok(&ys[j]) && ys[j].dtype == x->dtype && ys[j].n == x->n && ys[j].c == x->c,
+                      "adaptive_avgpool_multi: output %d does not match the input", j);
+        big[j] = x;
+        sm[j] = &ys[j];
+    }
+    int rc = window_multi<WR_AVGPOOL>(big, sm, n_out, 0, workspace, workspace_bytes, (hipStream_t)stream, "adaptive_avgpool_multi");
+    if (rc) return rc;
+    DSN_LAUNCH_CHECK("adaptive_avgpool_multi");
+    return DSN_OK;
+}
+
+// dxs[j] (+)= bilinear(align_corners=True) backward of dys[j], small sources (h*w <= 64 each): one reduction + one finalize launch
+extern "C" int dsn_bilinear_ac_bwd_multi(const dsn_tensor* dys, const dsn_tensor* dxs, int32_t n, int32_t accumulate,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(dys && dxs && n >= 1 && n <= WR_MAXJOBS, "bilinear_ac_bwd_multi: invalid arguments");
+    const dsn_tensor* big[WR_MAXJOBS];
+    const dsn_tensor* sm[WR_MAXJOBS];
+    for (int j = 0; j < n; ++j) {
+        DSN_CHECK_ARG(tensor_ok(&dys[j]) && tensor_ok(&dxs[j]) && dys[j].dtype == dxs[0].dtype && dxs[j].dtype == dxs[0].dtype &&
+                          dys[j].n == dxs[j].n && dys[j].c == dxs[j].c && vec16(&dys[j]) && dxs[j].h * dxs[j].w <= 64,
+                      "bilinear_ac_bwd_multi: job %d needs matching NHWC tensors, 16-byte channel vectors and a source of <= 64 pixels", j);
+        big[j] = &dys[j];
+        sm[j] = &dxs[j];
+    }
+    int rc = window_multi<WR_BILINEAR_BWD>(big, sm, n, accumulate, workspace, workspace_bytes, (hipStream_t)stream,
+                                           "bilinear_ac_bwd_multi");
+    if (rc) return rc;
+    DSN_LAUNCH_CHECK("bilinear_ac_bwd_multi");
+    return DSN_OK;
+}
+
+// ys[j] = bilinear(align_corners=True)(xs[j]) for up to four sources onto destinations of ONE common size (channel slices of a
+// concat buffer): one launch
+extern "C" int dsn_bilinear_ac_multi(const dsn_tensor* xs, const dsn_tensor* ys, int32_t n, void* stream) {
+    DSN_CHECK_ARG(xs && ys && n >= 1 && n <= 4, "bilinear_ac_multi: invalid arguments");
+    BilinearMulti m{};
+    m.n = n; m.N = ys[0].n; m.Ho = ys[0].h; m.Wo = ys[0].w;
+    int blk = 0;
+    for (int j = 0; j < n; ++j) {
+        DSN_CHECK_ARG(tensor_ok(&xs[j]) && tensor_ok(&ys[j]) && xs[j].dtype == ys[0].dtype && ys[j].dtype == ys[0].dtype &&
+                          xs[j].n == ys[j].n && xs[j].c == ys[j].c && ys[j].n == m.N && ys[j].h == m.Ho && ys[j].w == m.Wo &&
+                          vec16(&xs[j]) && vec16(&ys[j]),
+                      "bilinear_ac_multi: job %d needs matching NHWC tensors with 16-byte channel vectors and a common output size", j);
+        m.x[j] = xs[j].ptr; m.y[j] = ys[j].ptr; m.xld[j] = xs[j].ldc; m.yld[j] = ys[j].ldc;
+        m.hi[j] = xs[j].h; m.wi[j] = xs[j].w; m.c[j] = xs[j].c;
+        m.sh[j] = ac_scale(xs[j].h, m.Ho); m.sw[j] = ac_scale(xs[j].w, m.Wo);
+        m.blk0[j] = blk;
+        const int vw = ys[0].dtype == DSN_F32 ? 4 : 8;
+        blk += ew_grid((int64_t)m.N * m.Ho * m.Wo * (xs[j].c / vw));
+    }
+    m.blk0[n] = blk;
+    if (ys[0].dtype == DSN_F32)
+        hipLaunchKernelGGL((bilinear_vec_multi_kernel<float, 4>), dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, m);
+    else
+        hipLaunchKernelGGL((bilinear_vec_multi_kernel<bf16_t, 8>), dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, m);
+    DSN_LAUNCH_CHECK("bilinear_ac_multi");
     return DSN_OK;
 }
 

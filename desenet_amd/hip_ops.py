@@ -657,6 +657,63 @@ def adaptive_avgpool(x, y):
     return y
 
 
+def _wr_multi_ws(smalls, rows_list, cs, device):
+    L = _lib.lib()
+    nbytes = sum(int(L.dsn_window_reduce_workspace_bytes(t.shape[0] * t.shape[2] * t.shape[3], r, c))
+                 for t, r, c in zip(smalls, rows_list, cs))
+    return scratch(nbytes, device), nbytes
+
+
+def _vec16(t) -> bool:
+    """16-byte channel vectors possible: channel count and pixel stride multiples of the vector, base aligned."""
+    vw = 4 if t.dtype == torch.float32 else 8
+    ldc = _nhwc_ldc(t)
+    return ldc is not None and t.shape[1] % vw == 0 and ldc % vw == 0 and t.data_ptr() % 16 == 0
+
+
+def adaptive_avgpool_multi(x, ys):
+    """ys[j] = adaptive average pool of x to ys[j]'s size, all (<= 4) in one reduction + one finalize launch."""
+    n = len(ys)
+    if n > 4 or not _vec16(x):
+        for y in ys:
+            adaptive_avgpool(x, y)
+        return ys
+    arr = (dsn_tensor * n)(*[desc(t) for t in ys])
+    a = desc(x)
+    ws, nbytes = _wr_multi_ws(ys, [x.shape[2]] * n, [x.shape[1]] * n, x.device)
+    _lib.check(_lib.lib().dsn_adaptive_avgpool_multi(C.byref(a), arr, n, ws.data_ptr(), nbytes, stream_ptr()),
+               "adaptive_avgpool_multi")
+    return ys
+
+
+def bilinear_ac_multi(xs, ys):
+    """ys[j] = bilinear(align_corners=True) of xs[j]; all ys share one spatial size (slices of a concat buffer)."""
+    n = len(xs)
+    if n > 4 or not all(_vec16(t) for t in list(xs) + list(ys)):
+        for x, y in zip(xs, ys):
+            bilinear_ac(x, y)
+        return ys
+    ax = (dsn_tensor * n)(*[desc(t) for t in xs])
+    ay = (dsn_tensor * n)(*[desc(t) for t in ys])
+    _lib.check(_lib.lib().dsn_bilinear_ac_multi(ax, ay, n, stream_ptr()), "bilinear_ac_multi")
+    return ys
+
+
+def bilinear_ac_bwd_multi(dys, dxs, accumulate=False):
+    """dxs[j] (+)= backward of bilinear_ac for small sources (<= 64 pixels each), one reduction + one finalize launch."""
+    n = len(dys)
+    if n > 4 or not all(_vec16(t) for t in dys) or any(t.shape[2] * t.shape[3] > 64 for t in dxs):
+        for dy, dx in zip(dys, dxs):
+            bilinear_ac_bwd(dy, dx, accumulate=accumulate)
+        return dxs
+    ay = (dsn_tensor * n)(*[desc(t) for t in dys])
+    ax = (dsn_tensor * n)(*[desc(t) for t in dxs])
+    ws, nbytes = _wr_multi_ws(dxs, [t.shape[2] for t in dys], [t.shape[1] for t in dxs], dxs[0].device)
+    _lib.check(_lib.lib().dsn_bilinear_ac_bwd_multi(ay, ax, n, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
+               "bilinear_ac_bwd_multi")
+    return dxs
+
+
 def adaptive_avgpool_bwd(dy, dx, accumulate=False):
     a, b = desc(dy), desc(dx)
     _lib.check(_lib.lib().dsn_adaptive_avgpool_bwd(C.byref(a), C.byref(b), int(accumulate), stream_ptr()),

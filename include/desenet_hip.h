@@ -256,6 +256,18 @@ int dsn_focus_s2d_u8(const uint8_t* x_nchw, int32_t n, int32_t c, int32_t h, int
 int dsn_letterbox_u8(const uint8_t* src_hwc, int32_t h0, int32_t w0, uint8_t* dst, int32_t h, int32_t w, int32_t new_h,
                      int32_t new_w, int32_t top, int32_t left, int32_t pad0, int32_t pad1, int32_t pad2,
                      int32_t chw_reversed, void* stream);
+/* PyramidPooling (common.py:597-615) runs four branches over one map; these do each stage of all branches in one launch
+ * (+ one finalize launch for the two reductions).  ys / dys / dxs / xs: contiguous arrays of descriptors, at most 4.
+ * dsn_adaptive_avgpool_multi: ys[j] = AdaptiveAvgPool2d(ys[j].h)(x); workspace: sum over j of
+ *   dsn_window_reduce_workspace_bytes(n*h_j*w_j, x.h, x.c), jobs laid out back to back.
+ * dsn_bilinear_ac_multi: ys[j] = bilinear(align_corners=True)(xs[j]), all ys of one size (channel slices of one buffer).
+ * dsn_bilinear_ac_bwd_multi: dxs[j] (+)= its backward for sources of <= 64 pixels; workspace: sum over j of
+ *   dsn_window_reduce_workspace_bytes(n*h_j*w_j, dys[j].h, c_j). */
+int dsn_adaptive_avgpool_multi(const dsn_tensor* x, const dsn_tensor* ys, int32_t n_out, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+int dsn_bilinear_ac_multi(const dsn_tensor* xs, const dsn_tensor* ys, int32_t n, void* stream);
+int dsn_bilinear_ac_bwd_multi(const dsn_tensor* dys, const dsn_tensor* dxs, int32_t n, int32_t accumulate, void* workspace,
+                              int64_t workspace_bytes, void* stream);
 int dsn_maxpool_s1(const dsn_tensor* x, const dsn_tensor* y, int32_t* idx, int32_t k, void* stream);
 /* the same pool at n_out <= 3 window sizes ks[i] of ONE input (SPP: 5, 9, 13) in one launch; ys: contiguous descriptors,
  * idxs (array of int32 pointers, or NULL / NULL entries in eval) */

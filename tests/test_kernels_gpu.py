@@ -523,3 +523,37 @@ def test_errors_are_reported_not_fatal(ops):
         ops.conv2d_fwd(x, w, None, None, y, ops.conv_params(3))
     with pytest.raises(RuntimeError, match="CPU tensor"):
         ops.desc(torch.zeros(1, 8, 4, 4))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pyramid_multi_launches_equal_the_single_ones(ops, dtype):
+    """dsn_adaptive_avgpool_multi / dsn_bilinear_ac_multi / dsn_bilinear_ac_bwd_multi (PyramidPooling's four branches per
+    launch) against the one-branch entry points they batch.  The reductions are the same code (bit-identical); the bilinear
+    interpolation is the same expression compiled in another kernel (FMA contraction may differ: one ulp)."""
+    g = torch.Generator().manual_seed(12)
+    n, c, h, w, oc = 2, 32, 20, 24, 8
+    x = ops.new_act(n, c, h, w, dtype, "cuda")
+    x.copy_(torch.randn(n, c, h, w, generator=g))
+    ks = [1, 2, 3, 6]
+    single = [ops.adaptive_avgpool(x, ops.new_act(n, c, k, k, dtype, "cuda")) for k in ks]
+    multi = ops.adaptive_avgpool_multi(x, [ops.new_act(n, c, k, k, dtype, "cuda") for k in ks])
+    for a, b in zip(single, multi):
+        assert torch.equal(a, b)
+    fs = []
+    for k in ks:
+        f = ops.new_act(n, oc, k, k, dtype, "cuda")
+        f.copy_(torch.randn(n, oc, k, k, generator=g))
+        fs.append(f)
+    out_s, out_m = ops.new_act(n, 4 * oc, h, w, dtype, "cuda"), ops.new_act(n, 4 * oc, h, w, dtype, "cuda")
+    for j, f in enumerate(fs):
+        ops.bilinear_ac(f, out_s[:, j * oc:(j + 1) * oc])
+    ops.bilinear_ac_multi(fs, [out_m[:, j * oc:(j + 1) * oc] for j in range(4)])
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=8e-3, atol=1e-3)
+    assert torch.allclose(out_s.float(), out_m.float(), **tol)
+    dy = ops.new_act(n, 4 * oc, h, w, dtype, "cuda")
+    dy.copy_(torch.randn(n, 4 * oc, h, w, generator=g))
+    ds = [ops.bilinear_ac_bwd(dy[:, j * oc:(j + 1) * oc], ops.new_act(n, oc, k, k, dtype, "cuda")) for j, k in enumerate(ks)]
+    dm = ops.bilinear_ac_bwd_multi([dy[:, j * oc:(j + 1) * oc] for j in range(4)],
+                                   [ops.new_act(n, oc, k, k, dtype, "cuda") for k in ks])
+    for a, b in zip(ds, dm):
+        assert torch.equal(a, b)
