@@ -553,9 +553,11 @@ inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
 
 inline int choose_split(const WGeom& g, bool alltaps = false) {
     const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
-    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
+    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 320; }();
     static const int scap = [] { const char* e = getenv("DSN_WGRAD_SCAP"); return e ? atoi(e) : 256; }();
-    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 1024; }();
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 4096; }();
+    // (re-measured with the grouped launches, MI355X: blocks 288..352 x minpx 4096..5120 is a plateau -- 0.54 ms gather + 0.06 ms
+    //  slab reduce; 256 / 1024 was 0.56 + 0.14: four times the slab traffic for parallelism the shared grids no longer need)
     const int tgt = alltaps ? target / 2 : target, cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
     int64_t s = (tgt + base - 1) / base;
     const int64_t smax = (g.P + minpx - 1) / minpx;
