@@ -252,11 +252,25 @@ def main():
     else:
         from desenet_amd.core.utils.general import non_max_suppression
         model.eval().fuse()
-        x = synth_images(batch, a.img, 2 + rank).to(dev)
+        # the loader's product: uint8 NCHW on the device (detect.py:127-129 `img.float() / 255` is folded into Focus)
+        x = (synth_images(batch, a.img, 2 + rank) * 255.0).round().to(torch.uint8).to(dev)
+        fwd = lambda: model(x)
+        if not a.eager:
+            try:
+                from desenet_amd.graph import GraphedInference
+                ginf = GraphedInference(model, x)
+                fwd = lambda: ginf()
+            except Exception as e:
+                log(f"hipGraph capture of the forward pass failed ({type(e).__name__}: {e}); eager launches")
+
+        def eager_step():
+            with torch.no_grad():
+                (pred, _), seg = model(x)
+                return non_max_suppression(pred, 0.25, 0.45, max_det=1000), seg
 
         def step():
             with torch.no_grad():
-                (pred, _), seg = model(x)
+                (pred, _), seg = fwd()
                 return non_max_suppression(pred, 0.25, 0.45, max_det=1000), seg
 
     def sync():
@@ -272,7 +286,7 @@ def main():
             log("first step done")
     sync()
     log(f"timing {a.steps} steps")
-    graphed_run = train and not a.eager and step is not eager_step
+    graphed_run = not a.eager and step is not eager_step
     if not a.no_profile and not graphed_run:
         ops.profile_enable(True)
     t0 = time.perf_counter()
@@ -313,7 +327,8 @@ def main():
                         f"{mode_note}")
         else:
             metric = f"images/sec ({a.img}x{a.img}) inference fwd+NMS"
-            workload = f"config 2: DeSeNet-s fused inference (fwd + Detect decode + NMS), batch {batch}, {a.img}x{a.img}"
+            workload = (f"config 2: DeSeNet-s fused inference (uint8 input /255 + fwd + Detect decode + NMS), batch {batch}, "
+                        f"{a.img}x{a.img}, {'eager launches' if a.eager else 'forward pass replayed from a hipGraph, NMS eager'}")
         out = {
             "metric": metric, "value": world * batch * a.steps / elapsed, "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,

@@ -80,36 +80,53 @@ __device__ __forceinline__ uint64_t make_key(float conf, uint32_t idx) {
     return ((uint64_t)(~__float_as_uint(conf)) << 32) | idx;
 }
 
-__global__ void nms_candidates_kernel(const float* __restrict__ pred, int bs, int n, int nc, float conf_thres,
-                                      int multi_label, uint64_t classes_mask, uint64_t* __restrict__ keys,
-                                      int64_t cap, int32_t* __restrict__ counts) {
+// One returning atomic per WAVE, not per candidate: the lanes that keep a candidate are counted with a ballot, the first of them
+// reserves the slots, every lane takes base + (kept lanes below it).  (One atomicAdd per candidate on the image's counter
+// serialised at ~100 ns each: 2.6 ms for 16 x 25200 rows when every row survives the threshold.)  blockIdx.y = image.
+__device__ __forceinline__ int wave_slot(bool want, int32_t* counter) {
+    const uint64_t mask = __ballot(want);
+    if (mask == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    return want ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+}
+
+__global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int bs, int n, int nc,
+                                                             float conf_thres, int multi_label, uint64_t classes_mask,
+                                                             uint64_t* __restrict__ keys, int64_t cap,
+                                                             int32_t* __restrict__ counts) {
     const int no = 5 + nc;
-    const int64_t total = (int64_t)bs * n;
-    GRID_STRIDE(i, total) {
-        const int b = (int)(i / n), row = (int)(i - (int64_t)b * n);
-        const float* r = pred + i * no;
-        const float obj = r[4];
-        if (!(obj > conf_thres)) continue;
-        uint64_t* kb = keys + (int64_t)b * cap;
+    const int b = blockIdx.y;
+    uint64_t* kb = keys + (int64_t)b * cap;
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {       // uniform trip count: ballots see whole waves
+        const int row = base + (int)threadIdx.x;
+        const bool in = row < n;
+        const float* r = pred + ((int64_t)b * n + (in ? row : 0)) * no;
+        const float obj = in ? r[4] : 0.f;
+        const bool live = in && (obj > conf_thres);
         if (multi_label) {
             for (int j = 0; j < nc; ++j) {
-                const float conf = r[5 + j] * obj;
-                if (conf > conf_thres && (classes_mask == 0 || ((classes_mask >> j) & 1))) {
-                    const int slot = atomicAdd(&counts[b], 1);
-                    kb[slot] = make_key(conf, (uint32_t)(row * nc + j));
-                }
+                const float conf = live ? r[5 + j] * obj : 0.f;
+                const bool want = live && conf > conf_thres && (classes_mask == 0 || ((classes_mask >> j) & 1));
+                const int slot = wave_slot(want, &counts[b]);
+                if (want) kb[slot] = make_key(conf, (uint32_t)(row * nc + j));
             }
         } else {
-            float best = r[5] * obj;
+            float best = 0.f;
             int bj = 0;
-            for (int j = 1; j < nc; ++j) {
-                const float conf = r[5 + j] * obj;
-                if (conf > best) { best = conf; bj = j; }
+            if (live) {
+                best = r[5] * obj;
+                for (int j = 1; j < nc; ++j) {
+                    const float conf = r[5 + j] * obj;
+                    if (conf > best) { best = conf; bj = j; }
+                }
             }
-            if (best > conf_thres && (classes_mask == 0 || ((classes_mask >> bj) & 1))) {
-                const int slot = atomicAdd(&counts[b], 1);
-                kb[slot] = make_key(best, (uint32_t)(row * nc + bj));
-            }
+            const bool want = live && best > conf_thres && (classes_mask == 0 || ((classes_mask >> bj) & 1));
+            const int slot = wave_slot(want, &counts[b]);
+            if (want) kb[slot] = make_key(best, (uint32_t)(row * nc + bj));
         }
     }
 }
@@ -459,8 +476,9 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
     int32_t* counts = (int32_t*)workspace;
     uint64_t* keys = (uint64_t*)((char*)workspace + (int64_t)((bs * 4 + 255) / 256) * 256);
     dsn_fill_u32(counts, 0u, bs, st);
-    hipLaunchKernelGGL(nms_candidates_kernel, dim3(ew_grid((int64_t)bs * n)), dim3(256), 0, st, pred, bs, n, nc,
-                       conf_thres, multi_label, classes_mask, keys, cap, counts);
+    const int cb = (n + 255) / 256;
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3(cb < 128 ? cb : 128, bs), dim3(256), 0, st, pred, bs, n, nc, conf_thres,
+                       multi_label, classes_mask, keys, cap, counts);
     DSN_LAUNCH_CHECK("nms candidates");
     hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
     DSN_LAUNCH_CHECK("nms sort");

@@ -82,3 +82,33 @@ class GraphedTrainStep:
             self.flat.all_reduce()
             self.gb.replay()
         return self.loss
+
+
+class GraphedInference:
+    """hipGraph replay of the eval-mode forward pass for a fixed input shape (detect.py / val.py run batches of one shape):
+    the ~230 launches of a fused DeSeNet-s forward become one `hipGraphLaunch`.  Returns the model's usual eval output
+    `((pred, raws), seg)` -- views of buffers that the next call overwrites.  NMS stays outside (its output sizes are data)."""
+
+    def __init__(self, model, example_input: torch.Tensor, warmup: int = 2):
+        if model.training:
+            raise ValueError("GraphedInference captures the eval-mode forward: call model.eval() (and .fuse()) first")
+        self.model = model
+        self.x = example_input.clone()
+        dev = self.x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                  # packed-weight caches, workspaces
+                model(self.x)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.g, capture_error_mode="thread_local"):
+            self.out = model(self.x)
+        torch.cuda.synchronize(dev)
+
+    def __call__(self, x: torch.Tensor = None):
+        if x is not None and x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x)
+        self.g.replay()
+        return self.out

@@ -333,6 +333,25 @@ def test_graph_replay_equals_eager_training(net, fused):
         assert not torch.equal(c.weight.detach(), w0), "the optimizer step inside the graph did not update the weights"
 
 
+def test_graphed_inference_equals_eager(net):
+    """desenet_amd.graph.GraphedInference: the fused eval forward replayed from a hipGraph returns what eager launches
+    return -- for the capture input and for a new batch copied into the captured buffer (uint8 input path)."""
+    import copy
+    from desenet_amd.graph import GraphedInference
+    _, m = net
+    mf = copy.deepcopy(m).eval().fuse()
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randint(0, 256, (2, 3, 128, 128), generator=g, dtype=torch.uint8).cuda() for _ in range(2)]
+    gi = GraphedInference(mf, xs[0])
+    for x in xs:
+        with torch.no_grad():
+            (p0, r0), s0 = mf(x)
+        (p1, r1), s1 = gi(x)
+        assert torch.equal(p0, p1) and torch.equal(s0, s1) and all(torch.equal(a, b) for a, b in zip(r0, r1))
+    with pytest.raises(ValueError):
+        GraphedInference(copy.deepcopy(m).train(), xs[0])
+
+
 def test_config5_desenet_m_train_step_vs_oracle():
     """BASELINE.json config 5's graph (DeSeNet-m: the same yaml at width x1.0 / depth x1.0 -- channels up to 1024, K up to
     9216, 24 bottlenecks) through one fp32 training step against the CPU oracle on the same hash-filled weights: forward
