@@ -96,6 +96,15 @@ def main():
         res = {}
         if which in ("all", "fwd"):
             res["fwd"] = timeit(lambda: ops.conv2d_fwd(x, wf, None, None, y, p))
+        if which == "fwdbn":     # conv with the BatchNorm partial sums in its epilogue (fp64 atomics into 8 replicas) vs plain
+            import ctypes as C
+            from desenet_amd import _lib
+            L = _lib.lib()
+            acc, nbytes = ops.bn_acc(co, "cuda")
+            dxx, dyy = ops.desc(x), ops.desc(y)
+            res["fwd"] = timeit(lambda: ops.conv2d_fwd(x, wf, None, None, y, p))
+            res["fwd+bnacc"] = timeit(lambda: _lib.check(L.dsn_conv2d_fwd_bnacc(C.byref(dxx), wf.data_ptr(), C.byref(dyy), C.byref(p),
+                                                                              acc.data_ptr(), nbytes, ops.stream_ptr()), "x"))
         if which in ("all", "dgrad"):
             res["dgrad"] = timeit(lambda: ops.conv2d_dgrad(dy, wd, dx, p))
         if which in ("all", "wgrad"):
