@@ -79,6 +79,12 @@ __global__ void detect_raw_bwd_kernel(const float* __restrict__ draw, T* __restr
 __device__ __forceinline__ uint64_t make_key(float conf, uint32_t idx) {
     return ((uint64_t)(~__float_as_uint(conf)) << 32) | idx;
 }
+// flat layout of the large case (nms_sort.hip): image in bits 48.., the 30 significant bits of ~conf (0 < conf <= 1: sign and
+// top exponent bit are zero), 18 bits of candidate index
+constexpr int FLAT_IDX_BITS = 18;
+__device__ __forceinline__ uint64_t make_key_flat(int b, float conf, uint32_t idx) {
+    return ((uint64_t)b << 48) | ((uint64_t)(~__float_as_uint(conf) & 0x3FFFFFFFu) << FLAT_IDX_BITS) | idx;
+}
 
 // One returning atomic per WAVE, not per candidate: the lanes that keep a candidate are counted with a ballot, the first of them
 // reserves the slots, every lane takes base + (kept lanes below it).  (One atomicAdd per candidate on the image's counter
@@ -97,7 +103,7 @@ __device__ __forceinline__ int wave_slot(bool want, int32_t* counter) {
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int bs, int n, int nc,
                                                              float conf_thres, int multi_label, uint64_t classes_mask,
                                                              uint64_t* __restrict__ keys, int64_t cap,
-                                                             int32_t* __restrict__ counts) {
+                                                             int32_t* __restrict__ counts, int flat) {
     const int no = 5 + nc;
     const int b = blockIdx.y;
     uint64_t* kb = keys + (int64_t)b * cap;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
                 const float conf = live ? r[5 + j] * obj : 0.f;
                 const bool want = live && conf > conf_thres && (classes_mask == 0 || ((classes_mask >> j) & 1));
                 const int slot = wave_slot(want, &counts[b]);
-                if (want) kb[slot] = make_key(conf, (uint32_t)(row * nc + j));
+                if (want) kb[slot] = flat ? make_key_flat(b, conf, (uint32_t)(row * nc + j)) : make_key(conf, (uint32_t)(row * nc + j));
             }
         } else {
             float best = 0.f;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
             }
             const bool want = live && best > conf_thres && (classes_mask == 0 || ((classes_mask >> bj) & 1));
             const int slot = wave_slot(want, &counts[b]);
-            if (want) kb[slot] = make_key(best, (uint32_t)(row * nc + bj));
+            if (want) kb[slot] = flat ? make_key_flat(b, best, (uint32_t)(row * nc + bj)) : make_key(best, (uint32_t)(row * nc + bj));
         }
     }
 }
@@ -204,13 +210,14 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
                                                          const uint64_t* __restrict__ keys, int64_t cap,
                                                          const int32_t* __restrict__ counts, float iou_thres,
                                                          int agnostic, int max_det, float* __restrict__ out,
-                                                         int32_t* __restrict__ out_count) {
+                                                         int32_t* __restrict__ out_count, const int32_t* __restrict__ starts) {
     extern __shared__ float kept[];   // [max_det][5]
     __shared__ unsigned long long dead_s[4];
     __shared__ int nkept_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
     const int no = 5 + nc;
-    const uint64_t* k = keys + (int64_t)b * cap;
+    const uint64_t* k = starts ? keys + starts[b] : keys + (int64_t)b * cap;      // flat (one sort over all images) / per-image
+    const uint32_t idx_mask = starts ? ((1u << FLAT_IDX_BITS) - 1u) : 0xFFFFFFFFu;
     int cnt = counts[b];
     if (cnt > MAX_NMS) cnt = MAX_NMS;
     if (tid == 0) nkept_s = 0;
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
         Box me{0.f, 0.f, 0.f, 0.f, 0.f};
         float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu);
+            const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu) & idx_mask;
             const int row = idx / nc, cls = idx - row * nc;
             const float* r = pred + ((int64_t)b * n + row) * no;
             const float hw = r[2] / 2.0f, hh = r[3] / 2.0f;
@@ -454,9 +461,19 @@ extern "C" int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32
     return DSN_OK;
 }
 
+// large case (nms_sort.hip): device-wide segmented radix sort into a second key buffer
+int64_t dsn_nms_radix_temp_bytes(int32_t bs, int64_t cap);
+int dsn_nms_radix_sort(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* counts, int32_t bs, int64_t cap, void* temp,
+                       int64_t temp_bytes, const int32_t** starts_out, hipStream_t st);
+constexpr int64_t RADIX_FROM = 32768;      // keys per image above which the one-workgroup bitonic network loses (5.4 ms at 151200)
+
 extern "C" int64_t dsn_nms_workspace_bytes(int32_t bs, int32_t n, int32_t nc, int32_t multi_label) {
     if (bs <= 0 || n <= 0 || nc <= 0) return 0;
-    return (int64_t)bs * key_cap(n, nc, multi_label && nc > 1) * 8 + (int64_t)((bs * 4 + 255) / 256) * 256;
+    const int64_t cap = key_cap(n, nc, multi_label && nc > 1);
+    int64_t bytes = (int64_t)bs * cap * 8 + (int64_t)((bs * 4 + 255) / 256) * 256;
+    if (cap > RADIX_FROM && cap <= (1ll << FLAT_IDX_BITS) && bs <= 256 && (int64_t)bs * cap < (1ll << 31))
+        bytes += (int64_t)bs * cap * 8 + 256 + dsn_nms_radix_temp_bytes(bs, cap);     // second key buffer + sort temp
+    return bytes;
 }
 
 extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, float conf_thres, float iou_thres,
@@ -476,14 +493,27 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
     int32_t* counts = (int32_t*)workspace;
     uint64_t* keys = (uint64_t*)((char*)workspace + (int64_t)((bs * 4 + 255) / 256) * 256);
     dsn_fill_u32(counts, 0u, bs, st);
+    const bool flat = cap > RADIX_FROM && cap <= (1ll << FLAT_IDX_BITS) && bs <= 256 && (int64_t)bs * cap < (1ll << 31);
+    if (flat) dsn_fill_u32(keys, 0xFFFFFFFFu, bs * cap * 2, st);        // unused slots sort behind every image
     const int cb = (n + 255) / 256;
     hipLaunchKernelGGL(nms_candidates_kernel, dim3(cb < 128 ? cb : 128, bs), dim3(256), 0, st, pred, bs, n, nc, conf_thres,
-                       multi_label, classes_mask, keys, cap, counts);
+                       multi_label, classes_mask, keys, cap, counts, flat ? 1 : 0);
     DSN_LAUNCH_CHECK("nms candidates");
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
+    const uint64_t* sorted = keys;
+    const int32_t* starts = nullptr;
+    if (flat) {
+        uint64_t* keys2 = (uint64_t*)(((uintptr_t)(keys + (int64_t)bs * cap) + 255) / 256 * 256);
+        void* temp = keys2 + (int64_t)bs * cap;
+        const int64_t temp_bytes = workspace_bytes - (int64_t)((char*)temp - (char*)workspace);
+        const int rc = dsn_nms_radix_sort(keys, keys2, counts, bs, cap, temp, temp_bytes, &starts, st);
+        if (rc) DSN_FAIL(rc, "nms: radix sort failed");
+        sorted = keys2;
+    } else {
+        hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
+    }
     DSN_LAUNCH_CHECK("nms sort");
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(256), (size_t)max_det * 5 * sizeof(float), st, pred, n, nc,
-                       keys, cap, counts, iou_thres, agnostic, max_det, out, out_count);
+                       sorted, cap, counts, iou_thres, agnostic, max_det, out, out_count, starts);
     DSN_LAUNCH_CHECK("nms greedy");
     return DSN_OK;
 }

@@ -20,3 +20,5 @@ print("NMS only       %.2f ms" % t(lambda: non_max_suppression(pred, 0.25, 0.45,
 print("both           %.2f ms" % t(lambda: non_max_suppression(g()[0][0], 0.25, 0.45, max_det=1000)))
 out = non_max_suppression(pred, 0.25, 0.45, max_det=1000)
 print("detections per image:", [o.shape[0] for o in out])
+print("NMS val settings (conf .001, IoU .6, multi_label, max_det 300)  %.2f ms" %
+      t(lambda: non_max_suppression(pred, 0.001, 0.6, multi_label=True, max_det=300), n=5))
