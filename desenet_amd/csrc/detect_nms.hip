@@ -465,7 +465,7 @@ extern "C" int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32
 int64_t dsn_nms_radix_temp_bytes(int32_t bs, int64_t cap);
 int dsn_nms_radix_sort(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* counts, int32_t bs, int64_t cap, void* temp,
                        int64_t temp_bytes, const int32_t** starts_out, hipStream_t st);
-constexpr int64_t RADIX_FROM = 32768;      // keys per image above which the one-workgroup bitonic network loses (5.4 ms at 151200)
+constexpr int64_t RADIX_FROM = 8192;       // slots per image above which the one-workgroup bitonic network loses (it sorts <= 8192 keys in LDS)
 
 extern "C" int64_t dsn_nms_workspace_bytes(int32_t bs, int32_t n, int32_t nc, int32_t multi_label) {
     if (bs <= 0 || n <= 0 || nc <= 0) return 0;
