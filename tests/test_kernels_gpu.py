@@ -55,6 +55,8 @@ CONV_CASES = [
     (1, 64, 80, 80, 64, 3, 1, 1, 1),
     (4, 128, 1, 1, 128, 1, 1, 0, 1),     # FFM attention / 1x1 maps
     (1, 6, 7, 5, 10, 3, 1, 1, 1),        # scalar-load path (Ci % 4 != 0)
+    (2, 192, 12, 12, 64, 3, 1, 1, 1),    # long K, few tiles: in-block split-K with an ODD chunk count (27 bf16 chunks)
+    (1, 128, 16, 16, 64, 3, 1, 2, 2),    # the same path, dilated taps
 ]
 
 
