@@ -108,6 +108,8 @@ PROTOTYPES = {
     "dsn_ffm_scale_bwd": (i32, [TP, TP, TP, TP, TP, i32, vp, i64, vp]),
     "dsn_detect_decode": (i32, [TP, vp, vp, i64, i64, i32, i32, f32, vp, vp]),
     "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, i32, vp]),
+    "dsn_detect_decode_multi": (i32, [vp, vp, i32, vp, i64, vp, i32, i32, vp, vp, vp]),
+    "dsn_detect_raw_bwd_multi": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp]),
     "dsn_nms_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "dsn_nms": (i32, [vp, i32, i32, i32, f32, f32, i32, i32, u64, i32, vp, vp, vp, i64, vp]),
     "dsn_det_loss_workspace_bytes": (i64, [i32, i32, i32, i32, i64]),

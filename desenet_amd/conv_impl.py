@@ -290,7 +290,7 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
                              queue=tape.wgrad_queue(x.device) if (side is None and conv.weight not in tape.grads) else None)
             if slot is None:
                 tape.add_grad(conv.weight, g)
-        if conv.bias is not None and conv.bias.requires_grad:
+        if conv.bias is not None and conv.bias.requires_grad and not getattr(dz, "_dsn_bias_done", False):
             slot = _grad_slot(conv.bias)
             if slot is not None:
                 ops.channel_sum(dy, out=slot, accumulate=True)

@@ -122,6 +122,15 @@ class Detect(HipModule):
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
         self.inplace = inplace
 
+    def _strides_host(self):
+        """Detect.stride as host floats, cached (a .tolist() per forward would be a device sync when it lives on the GPU)."""
+        key = (self.stride.data_ptr(), self.stride._version) if torch.is_tensor(self.stride) else None
+        hit = self.__dict__.get("_dsn_strides")
+        if hit is None or hit[0] != key:
+            vals = [float(v) for v in (self.stride.tolist() if torch.is_tensor(self.stride) else self.stride)]
+            hit = self.__dict__["_dsn_strides"] = (key, vals)
+        return hit[1]
+
     def fwd(self, xs, tape=None, out=None):
         xs = [_as_input(t) for t in xs]
         n = xs[0].shape[0]
@@ -130,13 +139,15 @@ class Detect(HipModule):
         pred = None if self.training else torch.empty((n, total, self.no), dtype=torch.float32, device=dev)
         raws, row = [], 0
         anchors_px = self.anchor_grid.view(self.nl, self.na, 2).float().contiguous()
-        for i, x in enumerate(xs):
+        ts, rows = [], []
+        for i, x in enumerate(xs):               # the three head convs, then ONE decode launch for all levels
             t = conv_block_fwd(x, self.m[i], None, ACT_NONE, self.training, tape)
             _, _, ny, nx = t.shape
-            raw = torch.empty((n, self.na, ny, nx, self.no), dtype=torch.float32, device=dev)
-            ops.detect_decode(t, raw, pred, row, self.na, self.no, float(self.stride[i]), anchors_px[i])
-            raws.append(raw)
+            ts.append(t)
+            raws.append(torch.empty((n, self.na, ny, nx, self.no), dtype=torch.float32, device=dev))
+            rows.append(row)
             row += self.na * ny * nx
+        ops.detect_decode_multi(ts, raws, pred, rows, self.na, self.no, [float(v) for v in self._strides_host()], anchors_px)
         if tape is not None:
             tape.push([(tuple(x.shape), x.dtype) for x in xs])
         return raws if self.training else (pred, raws)
@@ -146,15 +157,22 @@ class Detect(HipModule):
         draws = dy if self.training else dy[1]
         dxs = list(dx) if dx is not None else [None] * self.nl
         accs = list(acc) if isinstance(acc, (list, tuple)) else [acc] * self.nl
-        for i in reversed(range(self.nl)):
+        # rows padded to a multiple of the 16-byte vector (33 -> 40 channels), padding written as zeros: the heads' weight and
+        # input gradients then take the vector paths instead of the scalar-load ones.  ONE launch un-permutes every level and
+        # sums the bias gradients (when the biases have gradient slots to add into), one more finalizes them.
+        dtls = []
+        for i in range(self.nl):
             (n, _, ny, nx), dt = metas[i]
-            # rows padded to a multiple of the 16-byte vector (33 -> 40 channels), padding written as zeros: the head's weight
-            # and input gradients then take the vector paths instead of the scalar-load ones
             vec = 4 if dt == torch.float32 else 8
-            dtl = ops.detect_raw_bwd(draws[i], ops.new_act(n, self.na * self.no, ny, nx, dt, draws[i].device, ldc_align=vec),
-                                     self.na, self.no, zero_padding=True)
-            dtl._dsn_zero_padded = True
-            dxs[i] = conv_block_bwd(tape, dtl, dxs[i], accs[i], need_dx)
+            dtls.append(ops.new_act(n, self.na * self.no, ny, nx, dt, draws[i].device, ldc_align=vec))
+        slots = [m.bias.grad if (m.bias is not None and m.bias.requires_grad and m.bias.grad is not None
+                                 and m.bias.grad.dtype == torch.float32 and m.bias.grad.is_contiguous()) else None for m in self.m]
+        fused_bias = all(s is not None for s in slots)
+        ops.detect_raw_bwd_multi(list(draws), dtls, self.na, self.no, slots if fused_bias else None)
+        for i in reversed(range(self.nl)):
+            dtls[i]._dsn_zero_padded = True
+            dtls[i]._dsn_bias_done = fused_bias
+            dxs[i] = conv_block_bwd(tape, dtls[i], dxs[i], accs[i], need_dx)
         return dxs
 
 

@@ -75,6 +75,100 @@ __global__ void detect_raw_bwd_kernel(const float* __restrict__ draw, T* __restr
     }
 }
 
+// ---- all Detect levels per launch (yolo.py:258-276 runs the three heads one after the other) ---------------------------------
+constexpr int DET_MAXL = 4;
+struct DetectLevels {
+    const void* t[DET_MAXL];       // head conv outputs (NHWC, na*no channels)
+    int64_t tld[DET_MAXL];
+    float* raw[DET_MAXL];          // [N][na][ny][nx][no] fp32 (forward: written; backward: the incoming gradient)
+    int32_t ny[DET_MAXL], nx[DET_MAXL];
+    int64_t row_off[DET_MAXL];     // first row of the level in pred
+    float stride[DET_MAXL];
+    int32_t cw[DET_MAXL];          // backward: channels written per pixel (>= na*no: zero-filled row padding)
+    float* part[DET_MAXL];         // backward: per-block per-channel partial sums [gridDim.x][cw] (bias gradient) or NULL
+    float* bias_grad[DET_MAXL];
+    int32_t nl, N, na, no;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void detect_decode_multi_kernel(const DetectLevels L, float* __restrict__ pred, int64_t pred_rows,
+                                                                  const float* __restrict__ anchors) {
+    const int l = blockIdx.y;
+    const int ny = L.ny[l], nx = L.nx[l], na = L.na, no = L.no, C = na * no;
+    const T* __restrict__ t = (const T*)L.t[l];
+    float* __restrict__ raw = L.raw[l];
+    const int64_t tld = L.tld[l], total = (int64_t)L.N * ny * nx * C;
+    const float stride = L.stride[l];
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % C);
+        int64_t p = i / C;
+        const int x = (int)(p % nx);
+        int64_t q = p / nx;
+        const int y = (int)(q % ny);
+        const int n = (int)(q / ny);
+        const int a = ch / no, o = ch - a * no;
+        const float v = to_f32<T>(t[p * tld + ch]);
+        const int64_t cell = ((int64_t)a * ny + y) * nx + x;
+        raw[(((int64_t)n * na * ny * nx) + cell) * no + o] = v;
+        if (pred) {
+            const float s = 1.0f / (1.0f + expf(-v));
+            float r;
+            if (o == 0) r = (s * 2.0f - 0.5f + (float)x) * stride;
+            else if (o == 1) r = (s * 2.0f - 0.5f + (float)y) * stride;
+            else if (o == 2) { const float u = s * 2.0f; r = u * u * anchors[(l * na + a) * 2]; }
+            else if (o == 3) { const float u = s * 2.0f; r = u * u * anchors[(l * na + a) * 2 + 1]; }
+            else r = s;
+            pred[((int64_t)n * pred_rows + L.row_off[l] + cell) * no + o] = r;
+        }
+    }
+}
+
+// backward of the permute for every level + the heads' bias gradients: a thread keeps ONE channel (the grid stride is a
+// multiple of the row width); the block folds its threads' sums in LDS and writes ONE partial row, a finalize kernel adds the
+// rows in order (an atomic per thread on the channel's accumulator serialised 6400 deep: 0.25 ms)
+template <typename T>
+__global__ __launch_bounds__(256) void detect_raw_bwd_multi_kernel(const DetectLevels L) {
+    const int l = blockIdx.y;
+    const int ny = L.ny[l], nx = L.nx[l], na = L.na, no = L.no, C = na * no, Cw = L.cw[l];
+    const float* __restrict__ draw = L.raw[l];
+    T* __restrict__ dt = (T*)L.t[l];
+    const int64_t tld = L.tld[l], total = (int64_t)L.N * ny * nx * Cw;
+    __shared__ float sh[64];
+    if (threadIdx.x < 64) sh[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int64_t i0 = blockIdx.x * 256ll + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * 256 / Cw * Cw;          // whole pixels per sweep: the channel of a thread is fixed
+    const int ch = (int)(i0 % Cw);
+    const int a = ch / no, o = ch - a * no;
+    float s = 0.f;
+    for (int64_t i = i0; i < total && i0 < step; i += step) {
+        const int64_t p = i / Cw;
+        const int x = (int)(p % nx);
+        const int64_t q = p / nx;
+        const int y = (int)(q % ny);
+        const int n = (int)(q / ny);
+        const float v = ch < C ? draw[((((int64_t)n * na + a) * ny + y) * nx + x) * no + o] : 0.f;
+        dt[p * tld + ch] = from_f32<T>(v);
+        s += v;
+    }
+    if (L.part[l]) {
+        if (ch < C && i0 < step) atomicAdd(&sh[ch], s);
+        __syncthreads();
+        if ((int)threadIdx.x < C) L.part[l][(int64_t)blockIdx.x * C + threadIdx.x] = sh[threadIdx.x];
+    }
+}
+
+// bias_grad[l][c] += sum over blocks of part[l][block][c] (fixed order; one wave per channel)
+__global__ __launch_bounds__(64) void detect_bias_finalize_kernel(const DetectLevels L, int nblocks) {
+    const int l = blockIdx.y, c = blockIdx.x, C = L.na * L.no;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)L.part[l][(int64_t)b * C + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (threadIdx.x == 0) L.bias_grad[l][c] += (float)s;
+}
+
 // ---- NMS stage 1: candidates ----------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t make_key(float conf, uint32_t idx) {
     return ((uint64_t)(~__float_as_uint(conf)) << 32) | idx;
@@ -458,6 +552,69 @@ extern "C" int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32
                        hipLaunchKernelGGL(detect_raw_bwd_kernel<T>, dim3(ew_grid(npix(dt) * cw)), dim3(256), 0,
                                           (hipStream_t)stream, draw, (T*)dt->ptr, dt->ldc, dt->n, dt->h, dt->w, na, no, cw));
     DSN_LAUNCH_CHECK("detect_raw_bwd");
+    return DSN_OK;
+}
+
+// forward of all levels: ts[l] head outputs, raws[l] fp32 [N][na][ny][nx][no]; pred (may be NULL) [N][pred_rows][no] with level
+// l starting at row_offs[l]; anchors_px: device [nl][na][2]
+extern "C" int dsn_detect_decode_multi(const dsn_tensor* ts, float* const* raws, int32_t nl, float* pred, int64_t pred_rows,
+                                       const int64_t* row_offs, int32_t na, int32_t no, const float* strides,
+                                       const float* anchors_px, void* stream) {
+    DSN_CHECK_ARG(ts && raws && nl >= 1 && nl <= DET_MAXL && na > 0 && no > 5 && strides && row_offs, "detect_decode_multi: invalid arguments");
+    DSN_CHECK_ARG(!pred || anchors_px, "detect_decode_multi: pred needs anchors");
+    DetectLevels L{};
+    L.nl = nl; L.N = ts[0].n; L.na = na; L.no = no;
+    int64_t most = 0;
+    for (int l = 0; l < nl; ++l) {
+        DSN_CHECK_ARG(tensor_ok(&ts[l]) && raws[l] && ts[l].c == na * no && ts[l].n == L.N && ts[l].dtype == ts[0].dtype,
+                      "detect_decode_multi: level %d is malformed", l);
+        DSN_CHECK_ARG(!pred || (row_offs[l] >= 0 && row_offs[l] + (int64_t)na * ts[l].h * ts[l].w <= pred_rows),
+                      "detect_decode_multi: pred slice of level %d out of range", l);
+        L.t[l] = ts[l].ptr; L.tld[l] = ts[l].ldc; L.raw[l] = raws[l]; L.ny[l] = ts[l].h; L.nx[l] = ts[l].w;
+        L.row_off[l] = row_offs[l]; L.stride[l] = strides[l];
+        const int64_t tot = npix(&ts[l]) * ts[l].c;
+        most = tot > most ? tot : most;
+    }
+    DSN_DISPATCH_DTYPE(ts[0].dtype, T,
+                       hipLaunchKernelGGL(detect_decode_multi_kernel<T>, dim3(ew_grid(most), nl), dim3(256), 0, (hipStream_t)stream, L,
+                                          pred, pred_rows, anchors_px));
+    DSN_LAUNCH_CHECK("detect_decode_multi");
+    return DSN_OK;
+}
+
+// backward of all levels: dts[l] (+ zero-filled row padding up to zero_pad_to[l]) from draws[l]; bias_grads[l] (may be NULL as
+// a whole) += per-channel sums.  workspace: nl * 512 * na*no floats (per-block partial rows; no initialisation needed).
+extern "C" int dsn_detect_raw_bwd_multi(const float* const* draws, const dsn_tensor* dts, int32_t nl, int32_t na, int32_t no,
+                                        const int32_t* zero_pad_to, float* const* bias_grads, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(draws && dts && nl >= 1 && nl <= DET_MAXL && na > 0 && no > 0, "detect_raw_bwd_multi: invalid arguments");
+    const int C = na * no;
+    DSN_CHECK_ARG(C <= 64, "detect_raw_bwd_multi: at most 64 head channels");
+    constexpr int MAXB = 512;
+    if (bias_grads && (!workspace || workspace_bytes < (int64_t)nl * MAXB * C * 4)) DSN_FAIL(DSN_EWORKSPACE, "detect_raw_bwd_multi: workspace too small");
+    DetectLevels L{};
+    L.nl = nl; L.N = dts[0].n; L.na = na; L.no = no;
+    int64_t most = 0;
+    for (int l = 0; l < nl; ++l) {
+        DSN_CHECK_ARG(tensor_ok(&dts[l]) && draws[l] && dts[l].c == C && dts[l].n == L.N && dts[l].dtype == dts[0].dtype,
+                      "detect_raw_bwd_multi: level %d is malformed", l);
+        const int zp = zero_pad_to ? zero_pad_to[l] : 0;
+        DSN_CHECK_ARG(zp == 0 || (zp >= C && zp <= dts[l].ldc), "detect_raw_bwd_multi: bad zero_pad_to for level %d", l);
+        L.t[l] = dts[l].ptr; L.tld[l] = dts[l].ldc; L.raw[l] = (float*)draws[l]; L.ny[l] = dts[l].h; L.nx[l] = dts[l].w;
+        L.cw[l] = zp > C ? zp : C;
+        L.part[l] = bias_grads ? (float*)workspace + (int64_t)l * MAXB * C : nullptr;
+        L.bias_grad[l] = bias_grads ? bias_grads[l] : nullptr;
+        if (bias_grads) DSN_CHECK_ARG(bias_grads[l], "detect_raw_bwd_multi: null bias gradient for level %d", l);
+        const int64_t tot = npix(&dts[l]) * L.cw[l];
+        most = tot > most ? tot : most;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = (most + 256 * 8 - 1) / (256 * 8);           // ~8 elements per thread
+    blocks = blocks < 1 ? 1 : (blocks > MAXB ? MAXB : blocks);
+    DSN_DISPATCH_DTYPE(dts[0].dtype, T,
+                       hipLaunchKernelGGL(detect_raw_bwd_multi_kernel<T>, dim3((unsigned)blocks, nl), dim3(256), 0, st, L));
+    if (bias_grads) hipLaunchKernelGGL(detect_bias_finalize_kernel, dim3(C, nl), dim3(64), 0, st, L, (int)blocks);
+    DSN_LAUNCH_CHECK("detect_raw_bwd_multi");
     return DSN_OK;
 }
 

@@ -759,6 +759,42 @@ def detect_decode(t, raw, pred, row_offset, na, no, stride, anchors_px):
                                             float(stride), _p(anchors_px), stream_ptr()), "detect_decode")
 
 
+def detect_decode_multi(ts, raws, pred, row_offsets, na, no, strides, anchors_px):
+    """All Detect levels in one launch: ts[l] head outputs -> raws[l] (+ the decoded rows of pred when given)."""
+    nl = len(ts)
+    arr = (dsn_tensor * nl)(*[desc(t) for t in ts])
+    rp = (C.c_void_p * nl)(*[r.data_ptr() for r in raws])
+    ro = (C.c_int64 * nl)(*[int(v) for v in row_offsets])
+    st = (C.c_float * nl)(*[float(v) for v in strides])
+    total = 0 if pred is None else pred.shape[1]
+    _lib.check(_lib.lib().dsn_detect_decode_multi(arr, rp, nl, _p(pred), total, ro, na, no, st, _p(anchors_px), stream_ptr()),
+               "detect_decode_multi")
+
+
+_det_ws = {}
+
+
+def detect_raw_bwd_multi(draws, dts, na, no, bias_grads=None):
+    """dts[l] (row padding zero-filled) from the raw-output gradients of every level in one launch; bias_grads[l] += the heads'
+    bias gradients (one more tiny launch for all levels)."""
+    nl = len(dts)
+    gs = [d if (d.is_contiguous() and d.dtype == torch.float32) else d.float().contiguous() for d in draws]
+    arr = (dsn_tensor * nl)(*[desc(t) for t in dts])
+    dp = (C.c_void_p * nl)(*[g.data_ptr() for g in gs])
+    zp = (C.c_int32 * nl)(*[int(a.ldc) for a in arr])
+    bp, ws, nbytes = None, None, 0
+    if bias_grads is not None:
+        bp = (C.c_void_p * nl)(*[b.data_ptr() for b in bias_grads])
+        nbytes = nl * 512 * na * no * 4
+        key = (dts[0].device, nbytes)
+        ws = _det_ws.get(key)
+        if ws is None:
+            ws = _det_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dts[0].device)
+    _lib.check(_lib.lib().dsn_detect_raw_bwd_multi(dp, arr, nl, na, no, zp, bp, _p(ws), nbytes, stream_ptr()),
+               "detect_raw_bwd_multi")
+    return dts
+
+
 def detect_raw_bwd(draw, dt, na, no, zero_padding=False):
     """zero_padding: dt is a row-padded activation (new_act ldc_align) whose padding lanes must read as zeros."""
     d = desc(dt)

@@ -313,6 +313,17 @@ int dsn_detect_decode(const dsn_tensor* t, float* raw, float* pred, int64_t pred
 /* zero_pad_to (0 or in [c, ldc]): channels c .. zero_pad_to-1 of every pixel row are written as zeros (row padding that
  * lets the consumers read 16-byte vectors; never set it on a channel SLICE of a wider tensor). */
 int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int32_t no, int32_t zero_pad_to, void* stream);
+/* All Detect levels in one launch each way (the reference loops over its three heads, yolo.py:258-276): ts / dts are
+ * contiguous descriptor arrays (nl <= 4), raws / draws arrays of fp32 [N][na][ny][nx][no] buffers, row_offs[l] the first row
+ * of level l in pred (NULL in training), strides[l] host floats, anchors_px DEVICE [nl][na][2].  The backward also adds the
+ * heads' bias gradients (per-channel sums of draws[l]) into bias_grads[l] (NULL: skip); workspace: nl * 512 * na*no floats
+ * of per-block partial rows (no initialisation needed), folded in a fixed order. */
+int dsn_detect_decode_multi(const dsn_tensor* ts, float* const* raws, int32_t nl, float* pred, int64_t pred_rows,
+                            const int64_t* row_offs, int32_t na, int32_t no, const float* strides, const float* anchors_px,
+                            void* stream);
+int dsn_detect_raw_bwd_multi(const float* const* draws, const dsn_tensor* dts, int32_t nl, int32_t na, int32_t no,
+                             const int32_t* zero_pad_to, float* const* bias_grads, void* workspace, int64_t workspace_bytes,
+                             void* stream);
 
 /* ---- NMS (general.py:659-750 + torchvision.ops.nms) ------------------------------------------------------------
  * pred: fp32 [bs, n, 5+nc].  For every image: candidate filter (obj > conf), conf = obj*cls, best-class or
