@@ -333,19 +333,39 @@ class RFB2(HipModule):
         x = _as_input(x)
         i = self.branch1[0].in_channels
         n, _, h, w = x.shape
-        cat = ops.new_act(n, 4 * i, h, w, x.dtype, x.device)     # [x0 | x1 | x2 | x3]
-        self.branch3[0].fwd(x, tape, cat[:, 3 * i:])
-        t = self.branch0[0].fwd(x, tape)
+        hit = pair_ready(self.branch3[0], self.branch0[0], x, tape, x.dtype)
+        if hit is not None:
+            # training: branch3's and branch0's first 1x1 read the same x -> ONE convolution + ONE BatchNorm launch writing
+            # [x3 | t] into the tail of a 5i-wide buffer [x0 | x1 | x2 | x3 | t]; ConvLinear reads the first four fifths
+            cat = ops.new_act(n, 5 * i, h, w, x.dtype, x.device)
+            pair_block_fwd(x, self.branch3[0], self.branch0[0], hit, tape, cat[:, 3 * i:])
+            t = cat[:, 4 * i:]
+        else:
+            cat = ops.new_act(n, 4 * i, h, w, x.dtype, x.device)     # [x0 | x1 | x2 | x3]
+            self.branch3[0].fwd(x, tape, cat[:, 3 * i:])
+            t = self.branch0[0].fwd(x, tape)
         x0 = self.branch0[1].fwd(t, tape, cat[:, :i])
         x1 = self.branch1.fwd(x0, tape, cat[:, i:2 * i])
         self.branch2.fwd(x1, tape, cat[:, 2 * i:3 * i])
-        return self.ConvLinear.fwd(cat, tape, out)
+        z = self.ConvLinear.fwd(cat[:, :4 * i], tape, out)
+        if tape is not None:
+            tape.push("rfb-merged" if hit is not None else "rfb-plain")
+        return z
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         i = self.branch1[0].in_channels
-        dcat = self.ConvLinear.bwd(tape, dy)
+        merged = tape.pop() == "rfb-merged"
+        if merged:
+            n, _, h, w = dy.shape
+            d5 = ops.new_act(n, 5 * i, h, w, dy.dtype, dy.device)     # [d x0 | d x1 | d x2 | d x3 | d t]
+            dcat = self.ConvLinear.bwd(tape, dy, d5[:, :4 * i], False)
+        else:
+            dcat = self.ConvLinear.bwd(tape, dy)
         d1 = self.branch2.bwd(tape, dcat[:, 2 * i:3 * i], dcat[:, i:2 * i], True)     # dx1 += ...
         d0 = self.branch1.bwd(tape, d1, dcat[:, :i], True)                            # dx0 += ...
+        if merged:
+            self.branch0[1].bwd(tape, d0, d5[:, 4 * i:], False)
+            return pair_block_bwd(tape, d5[:, 3 * i:], dx, acc, need_dx)
         dt = self.branch0[1].bwd(tape, d0)
         dx = self.branch0[0].bwd(tape, dt, dx, acc, need_dx)
         return self.branch3[0].bwd(tape, dcat[:, 3 * i:], dx, True, need_dx)

@@ -349,6 +349,8 @@ class Model(HipModule):
             co_pads = [((c.out_channels + vec - 1) // vec * vec) if c in det_convs else c.out_channels for c in convs]
             # C3's cv2 and cv1 read the same input: packed back to back they also run as ONE convolution (conv_impl.pair_block_*)
             pairs = [(m.cv2.conv, m.cv1.conv) for m in self.modules() if isinstance(m, C3) and not m.cv1.fused]
+            pairs += [(m.branch3[0].conv, m.branch0[0].conv) for m in self.modules()
+                      if isinstance(m, RFB2) and not m.branch3[0].fused]      # RFB2's two 1x1 convs of x (common.py:515-523)
             bank = self.__dict__["_dsn_bank"] = ops.WeightBank(convs, pads, dtype, device, co_pads=co_pads, pairs=pairs)
             self.__dict__["_dsn_bank_pads"] = bank.ci_pads
             self.__dict__["_dsn_bank_version"] = None

@@ -183,6 +183,8 @@ def test_train_step_with_merged_c3_pairs_vs_reference(net, monkeypatch):
     calls = []
     real = conv_impl.pair_block_fwd
     monkeypatch.setattr(common, "pair_block_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    # (RFB2's merged pair is additionally held to the reference's module golden in test_modules_gpu: its gradients are part
+    #  of the per-parameter energy comparison below)
     mt = copy.deepcopy(m).train()
     mt.hyp = dict(scale_hyp(6, 128), label_smoothing=0.0)
     flat = FlatGradients(mt.parameters())
@@ -193,7 +195,8 @@ def test_train_step_with_merged_c3_pairs_vs_reference(net, monkeypatch):
     det_loss, items = ComputeLoss(mt)(det_pred, det_t.cuda())
     seg_loss = SegmentationLosses()(seg_pred, seg_t.cuda())
     (det_loss * 0.14 + seg_loss * 1.0).backward()
-    assert len(calls) == sum(isinstance(mod, common.C3) for mod in mt.modules()) == 8
+    # eight C3 pairs (cv2 | cv1) and RFB2's two 1x1 convs of the same input
+    assert len(calls) == sum(isinstance(mod, (common.C3, common.RFB2)) for mod in mt.modules()) == 9
     assert_close(det_loss.cpu(), g[f"{tag}/det_loss"], 1e-3, "det_loss")
     assert_close(seg_loss.cpu(), g[f"{tag}/seg_loss"], 1e-3, "seg_loss")
     for j in range(3):
