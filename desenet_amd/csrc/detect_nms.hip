@@ -694,7 +694,8 @@ extern "C" int dsn_seg_eval_counts(const float* logits, const int64_t* target, i
     dsn_fill_u32(out, 0u, words, st);
     const int64_t HW = (int64_t)h * w, total = (int64_t)n * HW;
     int64_t b = (total + 255) / 256;
-    hipLaunchKernelGGL(seg_eval_counts_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, st, logits, target, c, HW, total,
+    // (few, fat blocks: every block ends with one global atomic per counter, and same-address atomics serialise at ~30 ns)
+    hipLaunchKernelGGL(seg_eval_counts_kernel, dim3((unsigned)(b > 512 ? 512 : b)), dim3(256), 0, st, logits, target, c, HW, total,
                        nclass, (unsigned long long*)out);
     DSN_LAUNCH_CHECK("seg_eval_counts");
     return DSN_OK;
