@@ -118,6 +118,8 @@ PROTOTYPES = {
     "dsn_seg_ce_workspace_bytes": (i64, []),
     "dsn_seg_ce": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
     "dsn_cast": (i32, [vp, vp, i32, i64, vp]),
+    "dsn_fill32": (i32, [vp, C.c_uint32, i64, vp]),
+    "dsn_add_i64": (i32, [vp, i64, i64, vp]),
     "dsn_profile_enable": (i32, [i32]),
     "dsn_profile_collect": (i32, [vp, i32]),
     "dsn_profile_kernel_count": (i32, []),

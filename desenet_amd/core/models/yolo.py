@@ -278,6 +278,28 @@ class Model(HipModule):
         self.info()
         LOGGER.info("")
 
+    # ---- adopting an unpickled tree (attempt_load / train.py:125-128 with desenet_amd.shim installed) ------------------
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._adopt()
+
+    def _adopt(self):
+        """A Model that was unpickled (no __init__): give stock torch classes their mirrored type and rebuild this package's
+        plans.  Reference pickles hold `nn.Upsample` layers and plain `nn.Sequential` Conv2d+BN+SiLU triples inside RFB2."""
+        from .common import _ConvBnAct
+        for m in self.model:
+            if type(m) is nn.Upsample:
+                m.__class__ = Upsample
+        for m in self.modules():
+            if isinstance(m, RFB2):
+                for b in (m.branch1, m.branch2):
+                    if type(b) is nn.Sequential:
+                        b.__class__ = _ConvBnAct
+        self.__dict__.pop("_dsn_bank", None)
+        if "seg_index" not in self.__dict__:
+            self.seg_index = next((m.i for m in self.model if isinstance(m, SegMaskPSP)), len(self.model) - 2)
+        self._plan_concats()
+
     # ---- construction helpers -------------------------------------------------------------------------------------
     def _infer_strides(self, det):
         scale = []
@@ -385,7 +407,7 @@ class Model(HipModule):
                 b.__dict__["_dsn_shared_counter"] = True
             self.__dict__["_dsn_bn_counters"] = flat
         if flat is not None:
-            flat.add_(1)
+            ops.add_i64_(flat, 1)
 
     def fwd(self, x, tape=None, out=None):
         if self.training:
@@ -436,9 +458,21 @@ class Model(HipModule):
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=False):
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the input image is not part of the training path")
+        grads = self.bwd_begin(dy)
+        self.bwd_layers(tape, grads, len(self.model) - 1, 0)
+        return None
+
+    def bwd_begin(self, dy):
+        """Gradient table of a backward pass: {top-level layer index: gradient of that layer's output}."""
         d_det, d_seg = dy
-        grads = {len(self.model) - 1: d_det, self.seg_index: d_seg}
-        for m in reversed(list(self.model)):
+        return {len(self.model) - 1: d_det, self.seg_index: d_seg}
+
+    def bwd_layers(self, tape, grads, hi, lo):
+        """Walk the top-level layers hi, hi-1, ..., lo (inclusive) of a backward pass begun with bwd_begin(); the pass may be
+        continued later with a lower range (desenet_amd.graph cuts it in two around the first gradient all-reduce)."""
+        layers = list(self.model)
+        for i in range(hi, lo - 1, -1):
+            m = layers[i]
             g = grads.pop(m.i, None)
             if g is None:
                 raise RuntimeError(f"layer {m.i} ({m._type}) received no gradient")
@@ -455,7 +489,6 @@ class Model(HipModule):
                 outs = m.bwd(tape, g, have, [h is not None for h in have])
                 for s, o in zip(srcs, outs):
                     grads[s] = o
-        return None
 
     # ---- reference API ----------------------------------------------------------------------------------------------
     def fuse(self):

@@ -76,6 +76,8 @@ class ModelEMA:
     Under hipGraph capture only the launch is recorded; call `tick()` before each replay to advance `updates` and upload the
     new decay (desenet_amd.graph.GraphedTrainStep does)."""
 
+    RING = 16
+
     def __init__(self, model, decay=0.9999, updates=0):
         self.ema = deepcopy(de_parallel(model)).eval()
         self.updates = updates
@@ -109,16 +111,27 @@ class ModelEMA:
         return dict(key=tuple((v.data_ptr(), m.data_ptr()) for v, m in pairs), n=len(pairs), chunks=first, pairs=pairs,
                     descs=torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev),
                     coef=torch.zeros(2, dtype=torch.float32, device=dev),
-                    host=torch.zeros(2, dtype=torch.float32).pin_memory())
+                    # ring of pinned upload slots: graph replay lets the host run many steps ahead of the GPU, so a slot is
+                    # only rewritten after the async H2D copy that last read it has executed (event per slot)
+                    host=[torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(self.RING)],
+                    events=[None] * self.RING, slot=0)
 
     def tick(self):
         """updates += 1 and upload {d, 1 - d} for the next (possibly graph-replayed) launch."""
         self.updates += 1
         d = self.decay(self.updates)
         t = self._table
-        t["host"][0] = d                 # float(d) and float(1. - d): what ATen's scalar multiply sees
-        t["host"][1] = 1.0 - d
-        t["coef"].copy_(t["host"], non_blocking=True)
+        i = t["slot"]
+        t["slot"] = (i + 1) % self.RING
+        if t["events"][i] is not None:
+            t["events"][i].synchronize()     # the copy that last read this slot has run (RING steps ago: normally long done)
+        h = t["host"][i]
+        h[0] = d                         # float(d) and float(1. - d): what ATen's scalar multiply sees
+        h[1] = 1.0 - d
+        t["coef"].copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        t["events"][i] = ev
 
     def launch(self):
         from ... import _lib

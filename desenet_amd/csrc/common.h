@@ -157,6 +157,11 @@ __device__ __forceinline__ void bn_acc_fold(const BnAcc& f, int c, double& s, do
 static __global__ void dsn_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
+static __global__ void dsn_fill_u32x4_kernel(u32x4* __restrict__ p, uint32_t v, int64_t nv, uint32_t* __restrict__ tail, int64_t ntail) {
+    const u32x4 vv = {v, v, v, v};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) p[i] = vv;
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < ntail) tail[threadIdx.x] = v;
+}
 static inline void dsn_fill_u32(void* p, uint32_t v, int64_t n_words, hipStream_t st) {
     if (n_words <= 0) return;
     int64_t b = (n_words + 255) / 256;

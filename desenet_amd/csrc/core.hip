@@ -399,6 +399,35 @@ extern "C" int dsn_copy(const dsn_tensor* x, const dsn_tensor* y, int32_t accumu
     return DSN_OK;
 }
 
+// ---- small utilities that keep host-framework kernels out of the captured step ---------------------------------------------
+// dsn_fill32: p[0..n_words) = value (gradient buffer / accumulator arena clears; hipMemsetAsync graph nodes are avoided, see
+// common.h).  dsn_add_i64: p[i] += v (BatchNorm num_batches_tracked: every counter is a view of one int64 vector).
+extern "C" int dsn_fill32(void* p, uint32_t value, int64_t n_words, void* stream) {
+    DSN_CHECK_ARG(p && n_words >= 0 && ((uintptr_t)p % 4) == 0, "fill32: bad args");
+    if ((((uintptr_t)p) % 16) == 0 && n_words >= 4) {
+        const int64_t nv = n_words / 4;
+        int64_t b = (nv + 255) / 256;
+        hipLaunchKernelGGL(dsn_fill_u32x4_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, (hipStream_t)stream,
+                           (u32x4*)p, value, nv, (uint32_t*)p + nv * 4, n_words - nv * 4);
+    } else {
+        dsn_fill_u32(p, value, n_words, (hipStream_t)stream);
+    }
+    DSN_LAUNCH_CHECK("fill32");
+    return DSN_OK;
+}
+
+static __global__ void add_i64_kernel(int64_t* __restrict__ p, int64_t n, int64_t v) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+extern "C" int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream) {
+    DSN_CHECK_ARG(p && n >= 0, "add_i64: bad args");
+    if (n == 0) return DSN_OK;
+    hipLaunchKernelGGL(add_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int64_t*)p, n, value);
+    DSN_LAUNCH_CHECK("add_i64");
+    return DSN_OK;
+}
+
 extern "C" int dsn_ema_step(const dsn_ema_desc* descs_dev, int32_t n_tensors, int32_t n_chunks, const float* coef_dev,
                             void* stream) {
     DSN_CHECK_ARG(descs_dev && coef_dev && n_tensors > 0 && n_chunks > 0, "ema_step: bad args");

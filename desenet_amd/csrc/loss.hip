@@ -124,6 +124,10 @@ __global__ __launch_bounds__(LT) void det_match_kernel(const DetLevels L, const 
         else if (o == 2) { act = act && (fmodf(gy, 1.f) < 0.5f) && (gy > 1.f); oy = 0.5f; }
         else if (o == 3) { const float ix = (float)q.nx - gx; act = act && (fmodf(ix, 1.f) < 0.5f) && (ix > 1.f); ox = -0.5f; }
         else if (o == 4) { const float iy = (float)q.ny - gy; act = act && (fmodf(iy, 1.f) < 0.5f) && (iy > 1.f); oy = -0.5f; }
+        // a label row that names an image outside the batch or a class outside [0, nc) is skipped, never used as an index
+        // (also rejects NaNs); rows padded with w = h = 0 (a fixed-capacity label buffer under hipGraph replay) fail the
+        // anchor-ratio test above: 1 / 0 = inf >= anchor_t
+        act = act && tg[0] >= 0.f && tg[0] < (float)q.bs && tg[1] >= 0.f && tg[1] < (float)q.nc;
         Cand c;
         c.cell = -1; c.cls = 0; c.iou = 0.f;
         c.dbox[0] = c.dbox[1] = c.dbox[2] = c.dbox[3] = 0.f;
@@ -199,10 +203,11 @@ __global__ __launch_bounds__(LT) void det_obj_kernel(const DetLevels L) {
     float* __restrict__ partial = v.partial;
     __shared__ float red[LT];
     const int64_t ncell = (int64_t)q.bs * q.na * q.ny * q.nx;
+    const int ncand = 5 * q.na * q.nt;
     float s = 0.f;
     for (int64_t cell = blockIdx.x * (int64_t)LT + threadIdx.x; cell < ncell; cell += (int64_t)v.ob * LT) {
         const int own = owner[cell];
-        const float tobj = own >= 0 ? fmaxf(cands[own].iou, 0.f) : 0.f;
+        const float tobj = (own >= 0 && own < ncand) ? fmaxf(cands[own].iou, 0.f) : 0.f;   // (a stale table can never index out of range)
         float dx;
         s += bce_logits(p[cell * q.no + 4], tobj, q.obj_pw, &dx);
         float* d = dp + cell * q.no;

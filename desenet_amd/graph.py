@@ -1,15 +1,26 @@
-"""hipGraph replay of the training step: the ~1500 kernel launches of one DeSeNet-s step (weight pack, forward, losses,
-backward, optimizer) are enqueued by ONE hipGraphLaunch instead of ~1500 Python->ctypes calls (host launch cost exceeded
+"""hipGraph replay of the training step: the launches of one DeSeNet-s step (weight pack, forward, losses, backward,
+optimizer) are enqueued by ONE hipGraphLaunch instead of several hundred Python->ctypes calls (host launch cost exceeded
 device time by 1.4x in eager mode).  No tracing compiler is involved: capture records exactly the launches the eager path
-makes; every buffer the graph touches lives in its private memory pool and inputs are copied into static tensors.
+makes; every buffer the graph touches lives in its private memory pool and the batch -- images AND labels -- is copied into
+static tensors before each replay.
 
-    world_size == 1 : G = [zero flat grads | pack weights | forward | det + seg loss (HIP) | backward | optimizer step]
-    world_size  > 1 : G_a = [zero | pack | forward | losses | backward]  ->  eager RCCL all-reduce of the flat gradient
-                      buffer  ->  G_b = [optimizer step]
+    world_size == 1, accumulate == 1 : G = [zero flat grads | pack | forward | det + seg loss (HIP) | backward | SGD | EMA]
+    accumulate  > 1                  : G0 = [zero | pack | forward | losses | backward]  (first micro-batch of a window)
+                                       G1 = [       pack | forward | losses | backward]  (the others: gradients add up)
+                                       G_opt = [SGD | EMA] after the last one            (scripts/train.py:370-376)
+    world_size  > 1                  : the backward pass is captured in two halves around `split_layer`:
+                                       GA = [zero | pack | forward | losses | backward of layers >= split | their weight grads]
+                                       -> all-reduce (RCCL, asynchronous, its own stream) of the flat-buffer tail that
+                                          holds those layers' gradients
+                                       GB = [backward of layers < split | their weight gradients]   (overlaps the collective)
+                                       -> all-reduce of the head of the buffer -> wait for both -> G_opt
+Labels: `det_targets` [n, 6] rows (image, class, x, y, w, h) go into a fixed-capacity [max_targets, 6] buffer whose unused rows
+are zero (w = h = 0 fails the anchor-ratio test of build_targets, loss.py:192-195, so padded rows match nothing and the
+candidate order of the real rows is unchanged); `seg_targets` [N, H, W] int64 are copied as they are.
 """
 from __future__ import annotations
 
-from typing import Callable
+from typing import Callable, Optional
 
 import torch
 import torch.distributed as dist
@@ -19,69 +30,252 @@ from .runtime import Tape
 
 class GraphedTrainStep:
     def __init__(self, model, loss_and_grads: Callable, flat, optimizer, example_input: torch.Tensor, warmup: int = 3,
-                 ema=None):
-        """loss_and_grads(det_out, seg_out) -> (loss tensor, d_det, d_seg): HIP kernels only (capturable).
-        ema: optional desenet_amd ModelEMA, updated right after the optimizer step (scripts/train.py:374-375) inside the graph."""
+                 ema=None, det_targets: Optional[torch.Tensor] = None, seg_targets: Optional[torch.Tensor] = None,
+                 max_targets: int = 0, accumulate: int = 1, restore_after_warmup: bool = True,
+                 split_layer: Optional[int] = None):
+        """loss_and_grads(det_out, seg_out, det_targets, seg_targets) -> (loss tensor, d_det, d_seg): HIP kernels only
+        (capturable); it must read the labels from the tensors it is handed (the step's static buffers), not from a closure.
+        Legacy form: without det_targets / seg_targets the callable is invoked as loss_and_grads(det_out, seg_out) and whatever
+        labels it closes over are frozen into the graph (benchmarks with one fixed batch only).
+        accumulate: micro-batches per optimizer step (train.py:146,337 `accumulate = round(nbs / batch_size)`).
+        restore_after_warmup: the `warmup` eager steps that populate caches / workspaces / optimizer state are undone
+        afterwards (weights, BatchNorm buffers, momentum buffers, EMA), so that building the step does not train.
+        ema: optional desenet_amd ModelEMA, updated right after the optimizer step (train.py:374-375) inside the graph.
+        split_layer (world_size > 1): first top-level layer index of the second all-reduce chunk (default: the layer at which
+        about half of the parameters lie behind; 0 disables the overlap)."""
         self.model, self.loss_and_grads, self.flat, self.opt, self.ema = model, loss_and_grads, flat, optimizer, ema
         if any(m.__dict__.get("_dsn_sync") is not None for m in model.modules()):
             raise NotImplementedError("GraphedTrainStep with SyncBatchNorm: the per-layer collectives run eagerly; use eager steps")
+        if accumulate < 1:
+            raise ValueError("accumulate must be >= 1")
+        self.accumulate = int(accumulate)
+        self.micro = 0
         self.x = example_input.clone()
         dev = self.x.device
+        self.det_t = self.seg_t = None
+        if (det_targets is None) != (seg_targets is None):
+            raise ValueError("pass both det_targets and seg_targets (or neither: legacy frozen-label form)")
+        if det_targets is not None:
+            cap = max(int(max_targets), int(det_targets.shape[0]), 1)
+            self.det_t = torch.zeros((cap, 6), dtype=torch.float32, device=dev)
+            self.seg_t = seg_targets.to(device=dev, dtype=torch.int64).clone()
+            self._set_labels(det_targets, None)
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.split = self._pick_split(split_layer) if self.multi else 0
+
+        snap = self._snapshot() if restore_after_warmup else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):          # populate caches / workspaces / optimizer state outside capture
-                self._body()
+                self.flat.zero()
+                self._forward_backward()
                 self.flat.all_reduce()
                 self.opt.step()
-                if self.ema is not None:     # the warm-up steps are real training steps: the EMA follows them
+                if self.ema is not None:
                     self.ema.update(model)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if snap is not None:
+            self._restore(snap)
+            torch.cuda.synchronize(dev)
 
         self.pool = torch.cuda.graph_pool_handle()
-        self.ga, self.gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.multi else None)
+        G = torch.cuda.CUDAGraph
+        cap_kw = dict(pool=self.pool, capture_error_mode="thread_local")   # other threads (the RCCL watchdog polls events)
+        single = (not self.multi) and self.accumulate == 1
+        self.g_first = self.g_next = self.g_tail = self.g_opt = None
         with torch.no_grad():
-            # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
-            with torch.cuda.graph(self.ga, pool=self.pool, capture_error_mode="thread_local"):
-                self.loss = self._body()
-                if not self.multi:
-                    self.opt.step()
-                    if self.ema is not None:
-                        self.ema.update(self.model)
-            if self.multi:
-                with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
-                    self.opt.step()
-                    if self.ema is not None:
-                        self.ema.update(self.model)
+            if single:
+                self.g_first = G()
+                with torch.cuda.graph(self.g_first, **cap_kw):
+                    self.flat.zero()
+                    self.loss = self._forward_backward()
+                    self._optimizer()
+            else:
+                self.g_first = G()
+                tape = None
+                with torch.cuda.graph(self.g_first, **cap_kw):
+                    self.flat.zero()
+                    self.loss, tape = self._forward_backward(stop_at=self.split)
+                if self.accumulate > 1:
+                    self.g_next = G()
+                    with torch.cuda.graph(self.g_next, **cap_kw):
+                        self.loss_next, tape_n = self._forward_backward(stop_at=self.split)
+                if self.split > 0:
+                    self.g_tail = G()
+                    with torch.cuda.graph(self.g_tail, **cap_kw):
+                        self._backward_rest(tape)
+                    if self.accumulate > 1:
+                        self.g_tail_next = G()
+                        with torch.cuda.graph(self.g_tail_next, **cap_kw):
+                            self._backward_rest(tape_n)
+                del tape
+                self.g_opt = G()
+                with torch.cuda.graph(self.g_opt, **cap_kw):
+                    self._optimizer()
         torch.cuda.synchronize(dev)
 
-    def _body(self):
-        self.flat.zero()
+    # ---- pieces of a step ---------------------------------------------------------------------------------------------------
+    def _losses(self, det, seg):
+        if self.det_t is not None:
+            return self.loss_and_grads(det, seg, self.det_t, self.seg_t)
+        return self.loss_and_grads(det, seg)
+
+    def _forward_backward(self, stop_at: Optional[int] = None):
+        """forward + losses + backward (down to top-level layer `stop_at`, exclusive of the layers below it, when given).
+        Returns the loss, or (loss, tape) when stop_at is given."""
         tape = Tape()
         det, seg = self.model.fwd(self.x, tape)
-        loss, d_det, d_seg = self.loss_and_grads(det, seg)
+        loss, d_det, d_seg = self._losses(det, seg)
         tape.begin_backward()
-        self.model.bwd(tape, (d_det, d_seg), need_dx=False)
-        tape.join()                              # weight gradients run on a side stream (parallel graph branch)
+        if stop_at is None:
+            self.model.bwd(tape, (d_det, d_seg), need_dx=False)
+            self._finish_backward(tape)
+            return loss
+        tape.bwd_state = self.model.bwd_begin((d_det, d_seg))
+        self.model.bwd_layers(tape, tape.bwd_state, len(self.model.model) - 1, stop_at)
+        self._finish_backward(tape)
+        return loss, tape
+
+    def _backward_rest(self, tape):
+        self.model.bwd_layers(tape, tape.bwd_state, self.split - 1, 0)
+        self._finish_backward(tape)
+
+    @staticmethod
+    def _finish_backward(tape):
+        tape.join()                              # queued weight gradients of the layers walked so far: three launches
         for p, g in tape.grads.items():          # parameters without a pre-attached .grad slot (none with FlatGradients)
             if p.grad is None:
                 p.grad = g
             else:
                 p.grad.add_(g)
-        return loss
+        tape.grads = {}
 
-    def __call__(self, x: torch.Tensor = None):
-        if x is not None and x.data_ptr() != self.x.data_ptr():
-            self.x.copy_(x)
+    def _optimizer(self):
+        self.opt.step()
         if self.ema is not None:
-            self.ema.tick()                      # updates += 1, decay for this step -> device
-        self.ga.replay()
-        if self.multi:
-            self.flat.all_reduce()
-            self.gb.replay()
-        return self.loss
+            self.ema.update(self.model)
+
+    # ---- multi-rank: where to cut the backward pass ---------------------------------------------------------------------------
+    def _pick_split(self, split_layer):
+        layers = list(self.model.model)
+        if split_layer is not None:
+            return max(0, min(int(split_layer), len(layers) - 1))
+        counts = [sum(p.numel() for p in m.parameters() if p.requires_grad) for m in layers]
+        total, run = sum(counts), 0
+        for i in range(len(layers) - 1, 0, -1):
+            run += counts[i]
+            if run * 2 >= total:
+                return i
+        return 0
+
+    def _flat_ranges(self):
+        """(tail, head): flat-buffer element ranges of the parameters of layers >= split / < split.  FlatGradients lays the
+        parameters out in `model.parameters()` order, i.e. by top-level layer index."""
+        cache = getattr(self, "_ranges", None)
+        if cache is None:
+            first_tail = None
+            ids = {id(p) for m in list(self.model.model)[self.split:] for p in m.parameters()}
+            off = 0
+            for p in self.flat.params:
+                if id(p) in ids:
+                    if first_tail is None:
+                        first_tail = off
+                elif first_tail is not None:
+                    raise RuntimeError("flat gradient buffer is not ordered by layer: cannot split the all-reduce")
+                off += p.numel()
+            first_tail = off if first_tail is None else first_tail
+            cache = self._ranges = ((first_tail, off), (0, first_tail))
+        return cache
+
+    # ---- warm-up undo ---------------------------------------------------------------------------------------------------------
+    def _snapshot(self):
+        snap = {"model": [t.detach().clone() for t in self.model.state_dict().values()],
+                "had_opt_state": {id(p): ("momentum_buffer" in self.opt.state.get(p, {})
+                                          and self.opt.state[p]["momentum_buffer"] is not None)
+                                  for g in self.opt.param_groups for p in g["params"]},
+                "opt": {id(p): self.opt.state[p]["momentum_buffer"].detach().clone()
+                        for g in self.opt.param_groups for p in g["params"]
+                        if "momentum_buffer" in self.opt.state.get(p, {}) and self.opt.state[p]["momentum_buffer"] is not None}}
+        if self.ema is not None:
+            snap["ema"] = [t.detach().clone() for t in self.ema.ema.state_dict().values()]
+            snap["ema_updates"] = self.ema.updates
+        return snap
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for t, s in zip(self.model.state_dict().values(), snap["model"]):
+                t.copy_(s)
+            for g in self.opt.param_groups:
+                for p in g["params"]:
+                    st = self.opt.state.get(p, {})
+                    b = st.get("momentum_buffer")
+                    if b is None:
+                        continue
+                    if snap["had_opt_state"].get(id(p)):
+                        b.copy_(snap["opt"][id(p)])
+                    else:
+                        b.zero_()            # created by the warm-up: a zero buffer is torch.optim.SGD's "no buffer yet"
+            if self.ema is not None:
+                for t, s in zip(self.ema.ema.state_dict().values(), snap["ema"]):
+                    t.copy_(s)
+                self.ema.updates = snap["ema_updates"]
+            torch.autograd.graph.increment_version([p for p in self.model.parameters()])
+
+    # ---- per-step API -----------------------------------------------------------------------------------------------------------
+    def _set_labels(self, det_targets, seg_targets):
+        if det_targets is not None:
+            n = int(det_targets.shape[0])
+            if n > self.det_t.shape[0]:
+                raise ValueError(f"{n} label rows exceed this step's capacity ({self.det_t.shape[0]}); build it with a larger max_targets")
+            self.det_t.zero_()
+            if n:
+                self.det_t[:n].copy_(det_targets.to(self.det_t.dtype), non_blocking=True)
+        if seg_targets is not None:
+            self.seg_t.copy_(seg_targets, non_blocking=True)
+
+    def __call__(self, x: torch.Tensor = None, det_targets: torch.Tensor = None, seg_targets: torch.Tensor = None):
+        """One micro-batch: copies the batch into the static buffers, replays forward/backward, and -- on the last micro-batch
+        of an accumulation window -- all-reduces and steps the optimizer.  Returns the (device) loss of this micro-batch."""
+        if x is not None and x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        if det_targets is not None or seg_targets is not None:
+            if self.det_t is None:
+                raise RuntimeError("this step was built without static label buffers (legacy form): pass det_targets / "
+                                   "seg_targets to the constructor")
+            self._set_labels(det_targets, seg_targets)
+        first = self.micro == 0
+        last = self.micro == self.accumulate - 1
+        if self.g_opt is None:                   # single rank, no accumulation: one replay is the whole step
+            if self.ema is not None:
+                self.ema.tick()                  # updates += 1, decay for this step -> device
+            self.g_first.replay()
+            return self.loss
+        (self.g_first if first else self.g_next).replay()
+        loss = self.loss if first else self.loss_next
+        work = None
+        if self.split > 0:
+            if self.multi and last:
+                (lo, hi), _ = self._flat_ranges()
+                if hi > lo:
+                    work = dist.all_reduce(self.flat.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            (self.g_tail if first else self.g_tail_next).replay()
+        if last:
+            if self.multi:
+                if self.split > 0:
+                    _, (lo, hi) = self._flat_ranges()
+                    if hi > lo:
+                        dist.all_reduce(self.flat.flat[lo:hi], op=dist.ReduceOp.SUM)
+                    if work is not None:
+                        work.wait()
+                else:
+                    self.flat.all_reduce()
+            if self.ema is not None:
+                self.ema.tick()
+            self.g_opt.replay()
+        self.micro = 0 if last else self.micro + 1
+        return loss
 
 
 class GraphedInference:

@@ -32,7 +32,9 @@ def new_act(n: int, c: int, h: int, w: int, dtype, device, zero: bool = False, l
     """Logical NCHW tensor backed by a fresh dense NHWC buffer.  ldc_align > 1 rounds the pixel stride up (row padding after
     the c channels, e.g. 33 -> 40) so that 16-byte channel vectors stay aligned; the padding lanes are uninitialised."""
     ldc = (c + ldc_align - 1) // ldc_align * ldc_align
-    buf = (torch.zeros if zero else torch.empty)((n, h, w, ldc), dtype=dtype, device=device)
+    buf = torch.empty((n, h, w, ldc), dtype=dtype, device=device)
+    if zero:
+        zero_(buf) if buf.is_cuda else buf.zero_()
     return buf.permute(0, 3, 1, 2)[:, :c] if ldc != c else buf.permute(0, 3, 1, 2)
 
 
@@ -180,6 +182,23 @@ def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params, residual=None):
 
 
 _scratch = {}
+# Workspaces whose address a captured hipGraph has baked in: a later, larger eager call REPLACES the module-level buffer, and
+# the superseded one must then stay alive (and un-reused by the caching allocator) for as long as the graph may replay --
+# it is parked here for the life of the process.  (Replays and eager launches share a stream, so the graph keeps using its
+# own, old workspace in stream order while eager work moves on to the new one.)
+_graph_pinned = set()      # id() of buffers handed out during a capture
+_retired = []
+
+
+def _note_capture(buf):
+    if torch.cuda.is_current_stream_capturing():
+        _graph_pinned.add(id(buf))
+    return buf
+
+
+def _retire(buf):
+    if buf is not None and id(buf) in _graph_pinned:
+        _retired.append(buf)
 
 
 def scratch(nbytes: int, device) -> torch.Tensor:
@@ -188,8 +207,12 @@ def scratch(nbytes: int, device) -> torch.Tensor:
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing() and buf is not None:
+            raise RuntimeError("hip_ops.scratch: the workspace would have to grow during hipGraph capture; run the same "
+                               "step eagerly once before capturing")
+        _retire(buf)
         buf = _scratch[key] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
-    return buf
+    return _note_capture(buf)
 
 
 def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False, queue: "Optional[WgradQueue]" = None):
@@ -273,9 +296,13 @@ class WgradQueue:
         n = (nbytes + 255) // 256 * 256
         arena = _wgrad_arena.get(self.device)
         if arena is not None and self.offset + n <= arena.numel():
+            _note_capture(arena)
             t = arena[self.offset:self.offset + n]
             self.offset += n
             return t
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("WgradQueue: the slab arena would have to grow during hipGraph capture; run the same step "
+                               "eagerly once before capturing")
         self.extra += n                          # does not fit: a one-off buffer now, a larger arena from the next pass on
         t = torch.empty(n, dtype=torch.uint8, device=self.device)
         self.keep.append(t)
@@ -300,6 +327,7 @@ class WgradQueue:
             _lib.check(L.dsn_conv2d_wgrad_run(dev.data_ptr(), self.n, launch, stream_ptr()), "conv2d_wgrad_run")
         if self.extra and not torch.cuda.is_current_stream_capturing():
             need = self.offset + self.extra      # everything is enqueued on this stream: safe to replace the arena now
+            _retire(_wgrad_arena.get(self.device))     # (a captured graph keeps replaying into the arena it was captured with)
             _wgrad_arena[self.device] = torch.empty(int(need * 1.1) + (1 << 20), dtype=torch.uint8, device=self.device)
         self.n, self.keep, self.offset, self.extra, self.host = 0, [], 0, 0, None
 
@@ -449,16 +477,25 @@ class _BnArena:
 
     def __init__(self, device):
         self.buf = torch.zeros(self.BYTES, dtype=torch.uint8, device=device)
-        self.cursor = self.BYTES       # exhausted until the first begin()
+        self.cursor = 0
+        self.active = False            # no slots until the first begin()
+        self.high = 0                  # high-water mark of handed-out bytes: a captured clear must cover every later replay
 
     def begin(self):
-        self.buf.zero_()
+        # only what the previous step handed out is dirty (the rest is still zero from the allocation / the last clear)
+        self.high = max(self.high, (self.cursor + 15) // 16 * 16)
+        if self.high:
+            zero_(self.buf[:self.high])
         self.cursor = 0
+        self.active = True
 
     def take(self, nbytes):
         n = (nbytes + 255) // 256 * 256
-        if self.cursor + n > self.BYTES:
+        if not self.active or self.cursor + n > self.BYTES:
             return None
+        if torch.cuda.is_current_stream_capturing() and self.cursor + n > self.high:
+            # the clear recorded at the start of this capture covers [0, high): a slot beyond it would never be re-zeroed
+            raise RuntimeError("BatchNorm accumulator arena grew during hipGraph capture; run the same step eagerly first")
         t = self.buf[self.cursor:self.cursor + n]
         self.cursor += n
         return t
@@ -824,6 +861,24 @@ def nms(pred: torch.Tensor, conf_thres, iou_thres, multi_label=False, agnostic=F
     _lib.check(L.dsn_nms(p.data_ptr(), bs, n, nc, float(conf_thres), float(iou_thres), int(multi_label), int(agnostic),
                          mask, max_det, out.data_ptr(), cnt.data_ptr(), ws.data_ptr(), nbytes, stream_ptr()), "nms")
     return out, cnt
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """t.zero_() as a library launch (keeps ATen fill kernels / memset nodes out of the captured step).  t: contiguous, a
+    multiple of 4 bytes."""
+    _require_gpu(t)
+    nbytes = t.numel() * t.element_size()
+    if not t.is_contiguous() or nbytes % 4 or t.data_ptr() % 4:
+        return t.zero_()
+    _lib.check(_lib.lib().dsn_fill32(t.data_ptr(), 0, nbytes // 4, stream_ptr()), "fill32")
+    return t
+
+
+def add_i64_(t: torch.Tensor, value: int) -> torch.Tensor:
+    _require_gpu(t)
+    assert t.dtype == torch.int64 and t.is_contiguous()
+    _lib.check(_lib.lib().dsn_add_i64(t.data_ptr(), t.numel(), int(value), stream_ptr()), "add_i64")
+    return t
 
 
 def cast(src: torch.Tensor, dtype) -> torch.Tensor:

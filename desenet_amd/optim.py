@@ -46,7 +46,11 @@ class FusedSGD(torch.optim.Optimizer):
                                       nesterov=nesterov))
         self._table = None
         self._uploaded = None
-        self._first = True
+        # `first` (kernel: buf = g' instead of mom*buf + (1-damp)*g') is only ever needed with dampening != 0: a momentum
+        # buffer created as zeros gives mom*0 + (1-0)*g' = g', torch.optim.SGD's first step, without any flag -- so buffers
+        # restored by load_state_dict (resume: train.py `optimizer.load_state_dict(ckpt['optimizer'])`) and buffers created
+        # later (add_param_group) each do the right thing per parameter.  Decided per table build in _build().
+        self._first = False
 
     # ---- device-side tables ---------------------------------------------------------------------------------------------
     def _build(self):
@@ -54,6 +58,7 @@ class FusedSGD(torch.optim.Optimizer):
         chunk = L.dsn_sgd_chunk()
         entries = []
         dev = None
+        fresh = existing = 0
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None:
@@ -65,9 +70,20 @@ class FusedSGD(torch.optim.Optimizer):
                 st = self.state[p]
                 if "momentum_buffer" not in st or st["momentum_buffer"] is None:
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    fresh += 1
+                else:
+                    existing += 1
+                    b = st["momentum_buffer"]
+                    if b.dtype != torch.float32 or not b.is_contiguous() or b.device != p.device:
+                        st["momentum_buffer"] = b.to(device=p.device, dtype=torch.float32).contiguous()
                 entries.append((p, p.grad, st["momentum_buffer"], gi))
         if not entries:
             return None
+        self._first = False
+        if any(float(g["dampening"]) != 0.0 and float(g["momentum"]) != 0.0 for g in self.param_groups):
+            if fresh and existing:
+                raise NotImplementedError("FusedSGD with dampening != 0: new and restored momentum buffers in one optimizer")
+            self._first = bool(fresh)
         descs = (_lib.dsn_sgd_desc * len(entries))()
         first = 0
         for i, (p, g, b, gi) in enumerate(entries):
@@ -121,3 +137,16 @@ class FusedSGD(torch.optim.Optimizer):
         if self._first and not capturing:
             self._first = False        # momentum buffers now hold g': later steps blend (uploaded before the next launch)
         return loss
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict, then rebuild the device table around the restored momentum buffers (they
+        are blended into, never overwritten, by the next step -- as torch.optim.SGD does for parameters that have a buffer)."""
+        super().load_state_dict(state_dict)
+        self._table = None
+        self._uploaded = None
+        self._first = False
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._table = None
+        self._uploaded = None

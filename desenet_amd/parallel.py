@@ -34,7 +34,11 @@ class FlatGradients:
 
     def zero(self):
         """One memset instead of one per parameter; keeps the .grad views attached."""
-        self.flat.zero_()
+        if self.flat.is_cuda:
+            from . import hip_ops
+            hip_ops.zero_(self.flat)              # a library launch (no ATen fill kernel / memset node inside a captured step)
+        else:
+            self.flat.zero_()
         for p in self.params:          # optimizers / zero_grad(set_to_none=True) may have detached a view
             if p.grad is None or p.grad.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
                 raise RuntimeError("a parameter's .grad was replaced; use FlatGradients.zero() instead of zero_grad()")

@@ -374,6 +374,12 @@ int dsn_seg_argmax_nearest(const float* logits, float* out, int32_t n, int32_t c
 /* dst[i] = (dtype) src[i]  (flat fp32 master -> bf16 copy) */
 int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream);
 
+/* p[0 .. n_words) = value (32-bit words; p 4-byte aligned): `optimizer.zero_grad()` on the flat gradient buffer
+ * (scripts/train.py:378) and the per-step accumulator clears, as a kernel (no memset graph nodes). */
+int dsn_fill32(void* p, uint32_t value, int64_t n_words, void* stream);
+/* p[i] += value for n int64 elements: BatchNorm's `num_batches_tracked += 1` for every layer in one launch. */
+int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream);
+
 /* ---- live profiler (bench.py roofline): HIP events recorded on the launch stream around the hot kernels ------------
  * dsn_profile_enable(1) starts recording, (0) stops; dsn_profile_collect waits for the recorded events and returns, per
  * kernel id, {launches, total_ms, total_algorithmic_flops, total_algorithmic_bytes}. */
