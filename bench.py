@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-ema", action="store_true", help="train: leave out the rank-0 ModelEMA update (train.py:374)")
     ap.add_argument("--eager", action="store_true", help="train: launch every kernel from Python instead of hipGraph replay")
+    ap.add_argument("--accumulate", type=int, default=1, help="train: micro-batches per optimizer step (train.py:146; 1 = step every batch)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the extra `also` sections (config 2 inference, config 5 DeSeNet-m 1280) after the headline")
+    ap.add_argument("--also-only", action="store_true", help=argparse.SUPPRESS)      # child run of an `also` section
     return ap.parse_args()
 
 
@@ -168,6 +172,33 @@ def roofline_from_profile(prof, steps, dtype):
     return roof, table
 
 
+def also_sections():
+    """The other single-GPU configurations of BASELINE.json, measured by child runs of this script right after the headline
+    (fresh processes: no shared caches with the timed region above): config 2 (fused fp32 inference + NMS, batch 16) and
+    config 5's per-GPU shape (DeSeNet-m, 1280x1280, batch 4, bf16 training step)."""
+    import subprocess
+    runs = {"config2_infer_fp32_b16": ["--mode", "infer", "--steps", "30", "--warmup", "8"],
+            "config5_m1280_bf16_b4": ["--model", "m", "--img", "1280", "--batch", "4", "--steps", "12", "--warmup", "4"]}
+    out = {}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--also-only", *extra]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-400:]}
+                continue
+            j = json.loads(line[-1])
+            out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                         "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "workload": j["config"]["workload"],
+                         "roofline": j["roofline"], "kernels": j.get("kernels"), "wall_s": time.perf_counter() - t0}
+        except Exception as e:      # never lose the headline line to a failing side section
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        log(f"also[{name}]: {out[name].get('value', out[name].get('error'))}")
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -224,29 +255,39 @@ def main():
             det_loss, _ = compute_loss(det_pred, det_t)
             return det_loss * DETGAIN + compute_seg_loss(seg_pred, seg_t) * SEGGAIN
 
-        def loss_and_grads(det_pred, seg_pred):      # same losses, gradients straight from the kernels (graph-capturable)
-            out, d_det = compute_loss.forward_backward(det_pred, det_t, gain=DETGAIN)
-            sout, d_seg = compute_seg_loss.forward_backward(seg_pred, seg_t)
-            return out[0] + sout[0] * SEGGAIN, d_det, (d_seg if SEGGAIN == 1 else d_seg * SEGGAIN)
+        def loss_and_grads(det_pred, seg_pred, det_labels, seg_labels):
+            # same losses, gradients straight from the kernels (graph-capturable); labels come from the step's static buffers
+            out, d_det = compute_loss.forward_backward(det_pred, det_labels, gain=DETGAIN)
+            sout, d_seg = compute_seg_loss.forward_backward(seg_pred, seg_labels)
+            return (out, sout), d_det, (d_seg if SEGGAIN == 1 else d_seg * SEGGAIN)
+
+        micro = [0]
 
         def eager_step():
-            flat.zero()
+            if micro[0] == 0:
+                flat.zero()
             det_pred, seg_pred = model(x)
             loss_fn(det_pred, seg_pred).backward()
-            flat.all_reduce()
-            opt.step()
-            if ema is not None:
-                ema.update(model)
+            micro[0] = (micro[0] + 1) % a.accumulate
+            if micro[0] == 0:
+                flat.all_reduce()
+                opt.step()
+                if ema is not None:
+                    ema.update(model)
 
         step = eager_step
         mode_note = "eager launches"
         if not a.eager:
             try:
                 from desenet_amd.graph import GraphedTrainStep
-                graphed = GraphedTrainStep(model, loss_and_grads, flat, opt, x, ema=ema)
-                step = lambda: graphed()
-                mode_note = ("one hipGraph replay per step (u8 input /255 + pack + fwd + losses + bwd + SGD + EMA)" if world == 1 else
-                             "two hipGraph replays per step (u8 input /255 + pack + fwd + losses + bwd | SGD (+ EMA on rank 0)) around the eager all-reduce")
+                graphed = GraphedTrainStep(model, loss_and_grads, flat, opt, x, ema=ema, det_targets=det_t, seg_targets=seg_t,
+                                           max_targets=max(256, int(det_t.shape[0])), accumulate=a.accumulate)
+                # every replay is handed the batch (images + labels are copied into the step's static buffers, as a loader
+                # would; here the same resident synthetic batch each time)
+                step = lambda: graphed(x, det_t, seg_t)
+                mode_note = ("one hipGraph replay per step (u8 input /255 + pack + fwd + losses + bwd + SGD + EMA)" if world == 1 and a.accumulate == 1 else
+                             f"hipGraph replays: fwd + losses + bwd halves around the asynchronous RCCL all-reduce of the flat-buffer tail "
+                             f"(split at layer {graphed.split}), then SGD (+ EMA on rank 0); accumulate {a.accumulate}")
             except Exception as e:   # keep the bench alive, but say so loudly
                 log(f"hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
     else:
@@ -337,6 +378,8 @@ def main():
             "config": {"workload": workload, "batch_per_gpu": batch, "img": a.img, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": table,
         }
+        if world == 1 and train and a.model == "s" and not a.no_also and not a.also_only:
+            out["also"] = also_sections()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,264 @@
+"""desenet_amd.graph.GraphedTrainStep on the MI355X: the captured step must be the reference's step (scripts/train.py:329-376)
+for every batch it is handed -- new images AND new labels per replay, gradient accumulation over `accumulate` micro-batches,
+optimizer resume -- and must survive eager work that regrows the shared workspaces.  fp32, 2 x 128 x 128 batches."""
+import copy
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from desenet_amd.synth import synth_images, synth_targets, synthetic_checkpoint
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+SIZE, BS = 128, 2
+
+
+def _model():
+    import desenet_amd
+    from desenet_amd.core.models.yolo import Model
+    from desenet_amd.core.utils.hyp import scale_hyp
+    desenet_amd.set_compute_dtype(torch.float32)
+    m = Model("desenet_s.yaml", ch=3, nc=6)
+    sd = m.state_dict()
+    synthetic_checkpoint(sd)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.hyp = scale_hyp(6, SIZE)
+    return m
+
+
+def _batch(seed, n_boxes=None):
+    x = synth_images(BS, SIZE, seed).cuda()
+    det_t, seg_t = synth_targets(BS, SIZE, seed)
+    if n_boxes is not None:
+        det_t = det_t[:n_boxes]
+    return x, det_t.cuda(), seg_t.cuda()
+
+
+def _setup(m, fused=True):
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from desenet_amd.optim import FusedSGD
+    from desenet_amd.parallel import FlatGradients, sgd_param_groups
+    flat = FlatGradients(m.parameters())
+    opt = (FusedSGD if fused else torch.optim.SGD)(sgd_param_groups(m), lr=0.01, momentum=0.937, nesterov=True)
+    return flat, opt, ComputeLoss(m), SegmentationLosses()
+
+
+def _eager_micro(m, cl, sl, batch):
+    from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN
+    x, det_t, seg_t = batch
+    det, seg = m(x)
+    loss = cl(det, det_t)[0] * DETGAIN + sl(seg, seg_t) * SEGGAIN
+    loss.backward()
+    return loss.detach()
+
+
+def _lg(cl, sl):
+    from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN
+
+    def loss_and_grads(det, seg, det_labels, seg_labels):
+        out, d_det = cl.forward_backward(det, det_labels, gain=DETGAIN)
+        sout, d_seg = sl.forward_backward(seg, seg_labels)
+        return (out, sout), d_det, d_seg
+    return loss_and_grads
+
+
+def _loss_value(pair):
+    from desenet_amd.core.utils.hyp import SEGGAIN
+    out, sout = pair
+    return float(out[0] + sout[0] * SEGGAIN)
+
+
+def _assert_same_weights(a, b, tol, what):
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert rel_err(sb[k].cpu(), sa[k].cpu()) < tol, (what, k)
+        else:
+            assert torch.equal(sa[k].cpu(), sb[k].cpu()), (what, k)
+
+
+def test_every_replay_trains_on_the_labels_it_is_given():
+    """Three steps on three different batches (8, 3 and 5 label rows, different masks): graph replays == eager steps, and the
+    per-step losses differ from batch to batch (a step frozen on its capture labels would repeat the first loss pattern)."""
+    from desenet_amd.graph import GraphedTrainStep
+    batches = [_batch(21), _batch(22, 3), _batch(23, 5)]
+    me = _model()
+    flat, opt, cl, sl = _setup(me)
+    eager_losses = []
+    for b in batches:
+        flat.zero()
+        eager_losses.append(float(_eager_micro(me, cl, sl, b)))
+        opt.step()
+    mg = _model()
+    flat_g, opt_g, clg, slg = _setup(mg)
+    step = GraphedTrainStep(mg, _lg(clg, slg), flat_g, opt_g, batches[0][0], det_targets=batches[0][1],
+                            seg_targets=batches[0][2], max_targets=64)
+    graph_losses = [_loss_value(step(*b)) for b in batches]
+    for le, lgv in zip(eager_losses, graph_losses):
+        assert abs(le - lgv) <= 2e-3 * abs(le), (eager_losses, graph_losses)
+    _assert_same_weights(me, mg, 5e-2, "labels")
+    with pytest.raises(ValueError):
+        step(batches[0][0], torch.zeros(65, 6, device="cuda"), batches[0][2])
+
+
+def test_gradient_accumulation_matches_the_eager_loop():
+    """accumulate = 2 (train.py:146,370-376): gradients of two micro-batches add up, ONE optimizer step per window; two windows."""
+    from desenet_amd.graph import GraphedTrainStep
+    batches = [_batch(31), _batch(32, 4), _batch(33), _batch(34, 2)]
+    me = _model()
+    flat, opt, cl, sl = _setup(me)
+    for i, b in enumerate(batches):
+        if i % 2 == 0:
+            flat.zero()
+        _eager_micro(me, cl, sl, b)
+        if i % 2 == 1:
+            opt.step()
+    mg = _model()
+    flat_g, opt_g, clg, slg = _setup(mg)
+    step = GraphedTrainStep(mg, _lg(clg, slg), flat_g, opt_g, batches[0][0], det_targets=batches[0][1],
+                            seg_targets=batches[0][2], max_targets=32, accumulate=2)
+    w0 = copy.deepcopy(mg.state_dict())
+    step(*batches[0])
+    torch.cuda.synchronize()
+    assert all(torch.equal(v, w0[k]) for k, v in mg.state_dict().items() if "conv.weight" in k), \
+        "no optimizer step inside an accumulation window"
+    for b in batches[1:]:
+        step(*b)
+    _assert_same_weights(me, mg, 5e-2, "accumulate")
+
+
+def test_fused_sgd_resume_blends_restored_momentum_like_torch():
+    """step, save, load into a NEW FusedSGD, step: the restored momentum buffers must be blended (torch.optim.SGD takes
+    `buf = grad` only for parameters without a buffer), not overwritten by the raw gradient."""
+    from desenet_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (64,), (33, 64, 1, 1), (33,)]
+
+    def make():
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+        return ps, [dict(params=ps[1:3], weight_decay=0.0), dict(params=[ps[0], ps[3]], weight_decay=5e-4),
+                    dict(params=[ps[4]], weight_decay=0.0)]
+
+    grads = [[torch.randn(s, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 * st + i))
+              for i, s in enumerate(shapes)] for st in range(3)]
+    pr, gr = make()
+    ref = torch.optim.SGD(gr, lr=0.02, momentum=0.9, nesterov=True)
+    for st in range(3):
+        for p, g in zip(pr, grads[st]):
+            p.grad = g.clone()
+        ref.step()
+    ph, gh = make()
+    opt = FusedSGD(gh, lr=0.02, momentum=0.9, nesterov=True)
+    for p, g in zip(ph, grads[0]):
+        p.grad = g.clone()
+    opt.step()
+    state = copy.deepcopy(opt.state_dict())
+    opt2 = FusedSGD(gh, lr=0.02, momentum=0.9, nesterov=True)      # resume: a fresh optimizer object over the same parameters
+    opt2.load_state_dict(state)
+    for st in (1, 2):
+        for p, g in zip(ph, grads[st]):
+            p.grad = g.clone()
+        opt2.step()
+    for a, b in zip(pr, ph):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+    for a, b in zip(pr, ph):
+        assert torch.allclose(ref.state[a]["momentum_buffer"], opt2.state[b]["momentum_buffer"], rtol=1e-6, atol=1e-6)
+
+
+def test_graph_keeps_its_workspaces_when_eager_work_outgrows_them():
+    """Capture at batch 2, then run a larger eager backward (batch 6: the shared weight-gradient arena and scratch are
+    re-allocated), then replay: the graph still owns the buffers it was captured with and gives the eager result."""
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.graph import GraphedTrainStep
+    b0 = _batch(41)
+    me = _model()
+    flat, opt, cl, sl = _setup(me)
+    flat.zero()
+    _eager_micro(me, cl, sl, b0)
+    opt.step()
+    mg = _model()
+    flat_g, opt_g, clg, slg = _setup(mg)
+    step = GraphedTrainStep(mg, _lg(clg, slg), flat_g, opt_g, b0[0], det_targets=b0[1], seg_targets=b0[2], max_targets=32)
+    arena0 = ops._wgrad_arena.get(torch.device("cuda", torch.cuda.current_device()))
+    # DeSeNet-m (6x the weights: split-K slabs scale with the weight matrices) at a larger batch and image
+    import os
+    from desenet_amd.core.models.yolo import Model
+    from desenet_amd.synth import hash_fill_state_dict
+    big = Model(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "desenet_amd", "cfg", "desenet_m.yaml"),
+                ch=3, nc=6)
+    sdb = big.state_dict()
+    hash_fill_state_dict(sdb)
+    big.load_state_dict(sdb)
+    big = big.cuda().train()
+    big.hyp = me.hyp
+    flat_b, _, clb, slb = _setup(big)
+    xb = synth_images(6, 192, 5).cuda()
+    dtb, stb = synth_targets(6, 192, 5)
+    flat_b.zero()
+    _eager_micro(big, clb, slb, (xb, dtb.cuda(), stb.cuda()))
+    flat_b.zero()
+    _eager_micro(big, clb, slb, (xb, dtb.cuda(), stb.cuda()))       # (the arena is replaced at the end of the pass that outgrew it)
+    torch.cuda.synchronize()
+    arena1 = ops._wgrad_arena.get(torch.device("cuda", torch.cuda.current_device()))
+    assert arena0 is not None and arena1 is not arena0, "the larger eager backward was expected to replace the arena"
+    assert any(t is arena0 for t in ops._retired), "a graph-referenced arena must be parked, not freed"
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]     # would land in a freed arena
+    step(*b0)
+    del junk
+    _assert_same_weights(me, mg, 5e-2, "workspace")
+
+
+# ---- two ranks, one GPU (gloo rendezvous, CUDA tensors): the product's multi-rank step ------------------------------------
+def _worker(rank, world, port, path, split):
+    import torch.distributed as dist
+    from desenet_amd.graph import GraphedTrainStep
+    from desenet_amd.parallel import broadcast_parameters
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        m = _model()
+        broadcast_parameters(m)
+        flat, opt, cl, sl = _setup(m)
+        batches = [_batch(50 + 2 * s + rank, 6 - rank) for s in range(2)]
+        step = GraphedTrainStep(m, _lg(cl, sl), flat, opt, batches[0][0], det_targets=batches[0][1],
+                                seg_targets=batches[0][2], max_targets=32, split_layer=split)
+        assert step.multi and (step.split > 0) == (split != 0)
+        for b in batches:
+            step(*b)
+        torch.cuda.synchronize()
+        torch.save({k: v.cpu() for k, v in m.state_dict().items()}, os.path.join(path, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("split", [None, 0])
+def test_two_rank_graph_step_equals_sum_of_rank_gradients(split):
+    """GraphedTrainStep with world_size 2 (backward captured in two halves around the first, asynchronous all-reduce when
+    split != 0): parameters after two steps equal a single process that accumulates both ranks' batches per step (SUM of rank
+    gradients, train.py:356-358) -- and both ranks hold identical parameters."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, port, d, split), nprocs=2, join=True)
+        r = [torch.load(os.path.join(d, f"r{i}.pt")) for i in range(2)]
+    me = _model()
+    flat, opt, cl, sl = _setup(me)
+    for s in range(2):
+        flat.zero()
+        for rank in range(2):
+            _eager_micro(me, cl, sl, _batch(50 + 2 * s + rank, 6 - rank))
+        opt.step()
+    sd = me.state_dict()
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point or "running_" in k:
+            continue                        # BatchNorm running statistics are per rank (no --sync-bn), as in the reference
+        assert torch.equal(r[0][k], r[1][k]), k
+        assert rel_err(r[0][k], v.cpu()) < 5e-2, k

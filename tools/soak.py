@@ -25,18 +25,18 @@ det_t, seg_t = det_t.to(dev), seg_t.to(dev)
 ema = ModelEMA(m)
 
 
-def lg(det, seg):
-    out, d_det = cl.forward_backward(det, det_t, gain=DETGAIN)
-    sout, d_seg = sl.forward_backward(seg, seg_t)
-    return out[0] + sout[0] * SEGGAIN, d_det, d_seg
+def lg(det, seg, det_labels, seg_labels):
+    out, d_det = cl.forward_backward(det, det_labels, gain=DETGAIN)
+    sout, d_seg = sl.forward_backward(seg, seg_labels)
+    return (out, sout), d_det, d_seg
 
 
-step = GraphedTrainStep(m, lg, flat, opt, x, ema=ema)
+step = GraphedTrainStep(m, lg, flat, opt, x, ema=ema, det_targets=det_t, seg_targets=seg_t, max_targets=256)
 losses = []
 for i in range(400):
-    loss = step()
+    out, sout = step(x, det_t, seg_t)
     if i % 50 == 0 or i == 399:
-        losses.append(float(loss))
+        losses.append(float(out[0] + sout[0] * SEGGAIN))
         print(f"step {i:4d} loss {losses[-1]:.4f}", flush=True)
 assert all(l == l and abs(l) < 1e6 for l in losses), losses
 assert losses[-1] < losses[0], losses
