@@ -42,6 +42,26 @@ class dsn_pack_desc(C.Structure):
                 ("ci", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("ci_pad", C.c_int32), ("co_pad", C.c_int32)]
 
 
+class dsn_lazy_seg(C.Structure):
+    _fields_ = [("c0", C.c_int32), ("c1", C.c_int32), ("ch0", C.c_int32), ("p0", C.c_int32), ("acc_c", C.c_int32),
+                ("act", C.c_int32), ("acc", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("scale", C.c_void_p),
+                ("shift", C.c_void_p), ("count", C.c_double), ("eps", C.c_float), ("_pad", C.c_float)]
+
+
+LAZY_MAXSEG = 6
+
+
+class dsn_lazy_in(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("_pad", C.c_int32), ("seg", dsn_lazy_seg * LAZY_MAXSEG)]
+
+
+class dsn_bn_final(C.Structure):
+    _fields_ = [("acc", C.c_void_p), ("acc_c", C.c_int32), ("ch0", C.c_int32), ("n", C.c_int32), ("_pad", C.c_int32),
+                ("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float)]
+
+
 TP = C.POINTER(dsn_tensor)
 CP = C.POINTER(dsn_conv_params)
 vp, i32, i64, f32, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_double
@@ -117,7 +137,13 @@ PROTOTYPES = {
                            vp, i64, vp]),
     "dsn_seg_ce_workspace_bytes": (i64, []),
     "dsn_seg_ce": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
+    "dsn_seg_ce_up_workspace_bytes": (i64, [i32, i32, i32, i32, i32]),
+    "dsn_seg_ce_up": (i32, [TP, vp, i32, i32, i32, f32, vp, TP, vp, i64, vp]),
     "dsn_cast": (i32, [vp, vp, i32, i64, vp]),
+    "dsn_conv2d_fwd_lazy": (i32, [TP, vp, vp, vp, TP, TP, CP, vp, i64, vp]),
+    "dsn_conv2d_wgrad_plan_lazy": (i32, [TP, vp, TP, vp, i32, i32, CP, vp, i64, vp]),
+    "dsn_bn_finalize_multi": (i32, [vp, i32, vp]),
+    "dsn_lazy_materialize": (i32, [TP, vp, TP, vp, TP, vp]),
     "dsn_fill32": (i32, [vp, C.c_uint32, i64, vp]),
     "dsn_add_i64": (i32, [vp, i64, i64, vp]),
     "dsn_profile_enable": (i32, [i32]),

@@ -105,9 +105,42 @@ def _bn_sync(bn):
     return (group, world) if world > 1 else None
 
 
+import os as _os
+# Which consumers apply a deferred transform themselves.  The implicit-GEMM kernels re-stage every input element once per
+# filter tap and per output-channel tile, and SiLU costs ~38 VALU cycles per element per wave (v_exp_f32 + v_rcp_f32 are
+# quarter rate): measured on MI355X, a 3x3 consumer that transforms in its loader is VALU-bound and 2x slower (the 64x64 tile:
+# 16.7 -> 32.8 us), the all-taps weight gradient 4x.  1x1 consumers re-apply only once per output-channel tile: there the removed
+# BatchNorm pass was expected to outweigh the extra VALU work -- measured (profiles/r02c_*): it does not either; the 1x1 consumers
+# got 40 % slower and the queued 1x1 weight gradients 2x (x is re-staged once per output-channel tile), 5.01 -> 5.47 ms per step.
+# Default 0: nothing is deferred (every block materialises z with one elementwise launch, as before); DSN_LAZY_TAPS=1 / 9 turn the
+# 1x1 / every consumer on for experiments, and the kernels stay bit-exact against the materialised path (tests/test_lazy_gpu.py).
+_LAZY_MAX_TAPS = int(_os.environ.get("DSN_LAZY_TAPS", "0"))
+
+
+def _lazy_operand(tape, x, taps=1):
+    """(x', lazy descriptor | None): x itself plus the descriptor of its deferred-BatchNorm segments when the convolution kernels
+    can (and should: see _LAZY_MAX_TAPS) apply them while staging x; otherwise a materialised copy of x and None."""
+    if tape is None:
+        return x, None
+    lz = tape.lazy_in(x)
+    if lz is None:
+        return x, None
+    if lz is False or taps > max(_LAZY_MAX_TAPS, 1 if getattr(tape, "lazy_force", False) else 0) or not ops.lazy_input_ok(x):
+        return tape.materialize(x), None
+    return x, lz
+
+
+def _defer_ok(bn, out, co, bias, sync) -> bool:
+    """Can this BatchNorm's output stay raw / be produced through the deferred path (16-byte channel vectors everywhere)?"""
+    return bias is None and sync is None and co <= 1024 and co % 8 == 0 and ops._vec16(out)
+
+
 def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, training: bool, tape=None, out=None,
-                   residual=None, q1: bool = False, ci_pad: Optional[int] = None):
-    """x: NHWC-backed activation (channels may be zero-padded up to ci_pad).  Returns z (written into `out` if given)."""
+                   residual=None, q1: bool = False, ci_pad: Optional[int] = None, lazy_out: bool = False):
+    """x: NHWC-backed activation (channels may be zero-padded up to ci_pad).  Returns z (written into `out` if given).
+    lazy_out (training, with a tape): the caller guarantees that every consumer of the result is a convolution of this package
+    reading it through the same tape -- the block then writes the RAW conv output into `out`, tags it as deferred and skips the
+    BatchNorm + activation pass (runtime.LazyRec).  Without it the result is materialised as usual."""
     k, s, p, d = _conv_geom(conv)
     n, co, ho, wo = out_shape(conv, x)
     dtype = x.dtype
@@ -123,20 +156,51 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     # training (or eval-mode forward that must stay differentiable)
     w, bias = packed_fwd(conv, dtype, ci_pad, None)
     plain = skip_bn and act == ACT_NONE and residual is None
-    y = out if plain else ops.new_act(n, co, ho, wo, dtype, x.device)
-    stats = None
     sync = _bn_sync(bn) if train_bn else None
+    x, lz = _lazy_operand(tape, x, k * k)
+    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
+    if train_bn and tape is not None and _defer_ok(bn, out, co, bias, sync):
+        # deferred path: conv (+ BatchNorm sums in its epilogue) and nothing else when the output may stay raw; otherwise ONE
+        # elementwise launch materialises z (+ shortcut).  Saved statistics / running averages: end-of-forward finalisation.
+        defer = lazy_out and residual is None and (_LAZY_MAX_TAPS > 0 or lazy_out == "force")
+        y = out if defer else ops.new_act(n, co, ho, wo, dtype, x.device)
+        acc, _ = ops.conv2d_fwd_acc(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz)
+        stats = torch.empty((4, co), dtype=torch.float32, device=x.device)
+        count = n * ho * wo
+        if defer:
+            tape.lazy_tag(out, acc, co, 0, count, bn, act, stats)
+        else:
+            me = _self_lazy(acc, co, 0, 0, co, count, bn, act)
+            res, lres = residual, None
+            if residual is not None:
+                lres = tape.lazy_in(residual)
+                if lres is False or (lres is not None and not ops.lazy_input_ok(residual)):
+                    res, lres = tape.materialize(residual), None
+            ops.lazy_materialize(y, me, out, res, lres)
+            tape.lazy_pending_only(acc, co, 0, co, count, bn, stats)
+        if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
+            bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
+        rec.update(y=y, scale=stats[0], shift=stats[1], mean=stats[2], rstd=stats[3], frozen=False, sync=None)
+        tape.push(rec)
+        return out
+    if residual is not None and tape is not None:
+        residual = tape.materialize(residual)
+    y = out if plain else ops.new_act(n, co, ho, wo, dtype, x.device)
+    rec["y"] = y
+    stats = None
     if train_bn and bias is None and co <= 1024:
         # BatchNorm statistics come out of the conv epilogue (fp32 accumulators) and are folded in the prologue of the
         # BN + act kernel: conv -> BN -> act is two launches, y is read once
+        if lz is not None:
+            x, lz = tape.materialize(x), None
+            rec["x"] = x
         stats = ops.conv2d_fwd_bnstats(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), bn.weight, bn.bias, bn.running_mean,
                                        bn.running_var, bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps,
                                        act, residual, out, sync=sync)
     else:
         if sync is not None:
             raise NotImplementedError("SyncBatchNorm after a biased or > 1024-channel convolution (not in DeSeNet)")
-        ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE))
-    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, y=y, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
+        ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz)
     if plain:
         pass
     elif skip_bn:
@@ -164,6 +228,23 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     return out
 
 
+def _self_lazy(acc, acc_c, ch0, c0, c1, count, bn, act, second=None):
+    """dsn_lazy_in describing a conv's OWN fresh output: channels [c0, c1) <- accumulator channels ch0.. of `bn`; `second` =
+    (split, bn2): channels >= split belong to a second BatchNorm module (the merged C3 pair)."""
+    from . import _lib
+    lz = _lib.dsn_lazy_in()
+    parts = [(c0, c1, ch0, bn)] if second is None else [(c0, second[0], ch0, bn), (second[0], c1, ch0 + second[0] - c0, second[1])]
+    lz.nseg = len(parts)
+    for i, (a, b, ch, m) in enumerate(parts):
+        sg = lz.seg[i]
+        sg.c0, sg.c1, sg.ch0, sg.p0, sg.acc_c, sg.act = a, b, ch, 0, acc_c, act
+        sg.acc = acc.data_ptr()
+        sg.gamma = m.weight.data_ptr() if m.weight is not None else None
+        sg.beta = m.bias.data_ptr() if m.bias is not None else None
+        sg.count, sg.eps = float(count), float(m.eps)
+    return lz
+
+
 def pair_ready(blk_a, blk_b, x, tape, dtype):
     """Can blk_a | blk_b (Conv modules: 1x1 conv + BN + act on the SAME input) run as one merged convolution right now?
     Needs the model's WeightBank to have packed them back to back for the current weights, training-mode BatchNorm on a map
@@ -184,19 +265,41 @@ def pair_ready(blk_a, blk_b, x, tape, dtype):
     return hit
 
 
-def pair_block_fwd(x, blk_a, blk_b, hit, tape, out):
-    """z[:, :coA] = blk_a(x), z[:, coA:] = blk_b(x) as ONE convolution + ONE BatchNorm/act launch (`out`: coA+coB channels)."""
+def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
+    """z[:, :coA] = blk_a(x), z[:, coA:] = blk_b(x) as ONE convolution (`out`: coA+coB channels).  lazy_out: both halves stay
+    raw in `out`, tagged as deferred (two BatchNorm modules over one accumulator); otherwise one elementwise launch
+    materialises them."""
     ca, cb, ba, bb = blk_a.conv, blk_b.conv, blk_a.bn, blk_b.bn
     _, _, wf, _ = hit
     n, _, h, w = x.shape
-    co = ca.out_channels + cb.out_channels
+    coa = ca.out_channels
+    co = coa + cb.out_channels
     act = act_code(blk_a.act)
-    y = ops.new_act(n, co, h, w, x.dtype, x.device)
     sync = _bn_sync(ba)
-    mom = ba.momentum if ba.momentum is not None else BN_MOMENTUM
-    scale, shift, mean, rstd = ops.conv2d_fwd_bnstats(
-        x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), ba.weight, ba.bias, ba.running_mean, ba.running_var, mom, ba.eps, act,
-        None, out, sync=sync, second=(ca.out_channels, bb.weight, bb.bias, bb.running_mean, bb.running_var, None, None))
+    x, lz = _lazy_operand(tape, x)
+    if _defer_ok(ba, out, co, None, sync) and coa % 8 == 0:
+        lazy_out = bool(lazy_out) and (_LAZY_MAX_TAPS > 0 or lazy_out == "force")
+        y = out if lazy_out else ops.new_act(n, co, h, w, x.dtype, x.device)
+        acc, _ = ops.conv2d_fwd_acc(x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), lazy=lz)
+        stats = torch.empty((4, co), dtype=torch.float32, device=x.device)
+        count = n * h * w
+        if lazy_out:
+            tape.lazy_tag(out[:, :coa], acc, co, 0, count, ba, act, stats, o0=0)
+            tape.lazy_tag(out[:, coa:], acc, co, coa, count, bb, act, stats, o0=coa)
+        else:
+            ops.lazy_materialize(y, _self_lazy(acc, co, 0, 0, co, count, ba, act, second=(coa, bb)), out)
+            tape.lazy_pending_only(acc, co, 0, coa, count, ba, stats, o0=0)
+            tape.lazy_pending_only(acc, co, coa, co - coa, count, bb, stats, o0=coa)
+        scale, shift, mean, rstd = stats[0], stats[1], stats[2], stats[3]
+        sync = None
+    else:
+        if lz is not None:
+            x = tape.materialize(x)
+        y = ops.new_act(n, co, h, w, x.dtype, x.device)
+        mom = ba.momentum if ba.momentum is not None else BN_MOMENTUM
+        scale, shift, mean, rstd = ops.conv2d_fwd_bnstats(
+            x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), ba.weight, ba.bias, ba.running_mean, ba.running_var, mom, ba.eps, act,
+            None, out, sync=sync, second=(coa, bb.weight, bb.bias, bb.running_mean, bb.running_var, None, None))
     for bn in (ba, bb):
         if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
             bn.num_batches_tracked.add_(1)
@@ -222,8 +325,7 @@ def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
     q = tape.wgrad_queue(x.device)
     for conv, sl in ((ca, dy[:, :coa]), (cb, dy[:, coa:])):
         if conv.weight.requires_grad:
-            ops.conv2d_wgrad(x, sl, _grad_slot(conv.weight), conv.in_channels, ops.conv_params(1, 1, 0, 1, accumulate=True),
-                             oihw=True, queue=q)
+            _wgrad(tape, x, sl, _grad_slot(conv.weight), conv.in_channels, ops.conv_params(1, 1, 0, 1, accumulate=True), q)
     if not need_dx:
         return None
     if dx is None:
@@ -231,6 +333,18 @@ def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
         acc = False
     ops.conv2d_dgrad(dy, hit[3], dx, ops.conv_params(1, 1, 0, 1, accumulate=acc))
     return dx
+
+
+def _wgrad(tape, x, dy, g, ci, params, queue):
+    """dW (+)= wgrad(x, dy) into the OIHW gradient g.  x may carry deferred-BatchNorm segments: the queued kernels apply them
+    while staging x (scale / shift arrays of the finalised forward pass); shapes they cannot take get a materialised x."""
+    lz = tape.lazy_in(x, backward=True)
+    if lz is not None and (lz is False or queue is None or not ops.lazy_input_ok(x)):
+        x, lz = tape.materialize(x, backward=True), None
+    try:
+        ops.conv2d_wgrad(x, dy, g, ci, params, oihw=True, queue=queue, lazy=lz)
+    except ops.LazyUnsupported:
+        ops.conv2d_wgrad(tape.materialize(x, backward=True), dy, g, ci, params, oihw=True, queue=queue)
 
 
 class _NullCtx:
@@ -286,8 +400,8 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
             co, ci, kh, kw = conv.weight.shape
             slot = _grad_slot(conv.weight)
             g = slot if slot is not None else torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device)
-            ops.conv2d_wgrad(x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None), oihw=True,
-                             queue=tape.wgrad_queue(x.device) if (side is None and conv.weight not in tape.grads) else None)
+            _wgrad(tape, x, dy, g, ci, ops.conv_params(k, s, p, d, accumulate=slot is not None),
+                   tape.wgrad_queue(x.device) if (side is None and conv.weight not in tape.grads) else None)
             if slot is None:
                 tape.add_grad(conv.weight, g)
         if conv.bias is not None and conv.bias.requires_grad and not getattr(dz, "_dsn_bias_done", False):

@@ -68,11 +68,13 @@ class Conv(HipModule):
     def fused(self) -> bool:
         return not hasattr(self, "bn")
 
-    def fwd(self, x, tape=None, out=None, residual=None, ci_pad=None):
+    def fwd(self, x, tape=None, out=None, residual=None, ci_pad=None, lazy_out=False):
+        """lazy_out: leave the result as the raw conv output, tagged as deferred on the tape (conv_impl.conv_block_fwd) -- only a
+        caller that knows every consumer is a convolution of this package may ask for it."""
         x = _as_input(x)
         bn = None if self.fused else self.bn
         return conv_block_fwd(x, self.conv, bn, act_code(self.act), self.training, tape, out, residual,
-                              q1=not self.fused, ci_pad=ci_pad)
+                              q1=not self.fused, ci_pad=ci_pad, lazy_out=lazy_out)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, residual=None):
         return conv_block_bwd(tape, dy, dx, acc, need_dx, residual)
@@ -89,10 +91,11 @@ class Bottleneck(HipModule):
         self.cv2 = Conv(c_, c2, 3, 1, g=g)
         self.add = shortcut and c1 == c2
 
-    def fwd(self, x, tape=None, out=None):
+    def fwd(self, x, tape=None, out=None, lazy_out=False):
         x = _as_input(x)
-        t = self.cv1.fwd(x, tape)
-        return self.cv2.fwd(t, tape, out, residual=x if self.add else None)   # shortcut add fused in the epilogue
+        t = self.cv1.fwd(x, tape, lazy_out=True)                 # consumed by cv2 only: BN + SiLU ride in its operand staging
+        # the shortcut is added by the pass that materialises z (a deferred x is transformed there as well)
+        return self.cv2.fwd(t, tape, out, residual=x if self.add else None, lazy_out=lazy_out and not self.add)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         dt = self.cv2.bwd(tape, dy)
@@ -111,7 +114,7 @@ class C3(HipModule):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
-    def fwd(self, x, tape=None, out=None):
+    def fwd(self, x, tape=None, out=None, lazy_out=False):
         x = _as_input(x)
         c_ = self.cv1.conv.out_channels
         n, _, h, w = x.shape
@@ -122,19 +125,21 @@ class C3(HipModule):
             # merged block writes the last two thirds, the bottleneck chain reads the last third and its final block writes
             # the first, cv3 reads the first two thirds -- every operand is a channel slice, nothing is copied.
             cat3 = ops.new_act(n, 3 * c_, h, w, x.dtype, x.device)
-            pair_block_fwd(x, self.cv2, self.cv1, hit, tape, cat3[:, c_:])
+            # every consumer inside the block is a convolution (Bottleneck.cv1, cv3) or the materialising pass of a shortcut:
+            # the pair and the chain's last output stay raw
+            pair_block_fwd(x, self.cv2, self.cv1, hit, tape, cat3[:, c_:], lazy_out=True)
             a = cat3[:, 2 * c_:]
             for i, b in enumerate(blocks):
-                a = b.fwd(a, tape, cat3[:, :c_] if i == len(blocks) - 1 else None)
-            z = self.cv3.fwd(cat3[:, :2 * c_], tape, out)
+                a = b.fwd(a, tape, cat3[:, :c_] if i == len(blocks) - 1 else None, lazy_out=True)
+            z = self.cv3.fwd(cat3[:, :2 * c_], tape, out, lazy_out=lazy_out)
             tape.push("c3-merged")
             return z
         cat = ops.new_act(n, 2 * c_, h, w, x.dtype, x.device)
-        a = self.cv1.fwd(x, tape, cat[:, :c_] if not blocks else None)
+        a = self.cv1.fwd(x, tape, cat[:, :c_] if not blocks else None, lazy_out=True)
         for i, b in enumerate(blocks):
-            a = b.fwd(a, tape, cat[:, :c_] if i == len(blocks) - 1 else None)
-        self.cv2.fwd(x, tape, cat[:, c_:])
-        z = self.cv3.fwd(cat, tape, out)
+            a = b.fwd(a, tape, cat[:, :c_] if i == len(blocks) - 1 else None, lazy_out=True)
+        self.cv2.fwd(x, tape, cat[:, c_:], lazy_out=True)
+        z = self.cv3.fwd(cat, tape, out, lazy_out=lazy_out)
         if tape is not None:
             tape.push("c3-plain")
         return z
@@ -168,18 +173,18 @@ class SPP(HipModule):
         self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
         self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
 
-    def fwd(self, x, tape=None, out=None):
+    def fwd(self, x, tape=None, out=None, lazy_out=False):
         x = _as_input(x)
         c_ = self.cv1.conv.out_channels
         n, _, h, w = x.shape
         cat = ops.new_act(n, c_ * (len(self.m) + 1), h, w, x.dtype, x.device)
-        x0 = self.cv1.fwd(x, tape, cat[:, :c_])
+        x0 = self.cv1.fwd(x, tape, cat[:, :c_])                  # (the max pools read z: materialised)
         idxs = [torch.empty((n, h, w, c_), dtype=torch.int32, device=x.device) if tape is not None else None for _ in self.m]
         ops.maxpool_s1_multi(x0, [cat[:, i * c_:(i + 1) * c_] for i in range(1, len(self.m) + 1)],
                              [int(mp.kernel_size) for mp in self.m], idxs)          # one launch, x0 read once
         if tape is not None:
             tape.push(idxs)
-        return self.cv2.fwd(cat, tape, out)
+        return self.cv2.fwd(cat, tape, out, lazy_out=lazy_out)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         c_ = self.cv1.conv.out_channels
@@ -198,7 +203,7 @@ class Focus(HipModule):
         super().__init__()
         self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
 
-    def fwd(self, x, tape=None, out=None):
+    def fwd(self, x, tape=None, out=None, lazy_out=False):
         if not x.is_cuda:
             raise RuntimeError("desenet_amd kernels run on an MI355X only: got a CPU tensor (there is no CPU fallback)")
         dt = compute_dtype()
@@ -207,7 +212,7 @@ class Focus(HipModule):
         cpad = (4 * c + vec - 1) // vec * vec          # 12 -> 12 (fp32) / 16 (bf16): 16-byte channel vectors
         s2d = ops.new_act(n, cpad, h // 2, w // 2, dt, x.device)
         ops.focus_s2d(x, s2d)
-        return self.conv.fwd(s2d, tape, out, ci_pad=cpad)
+        return self.conv.fwd(s2d, tape, out, ci_pad=cpad, lazy_out=lazy_out)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         if need_dx:
@@ -308,8 +313,8 @@ class _ConvBnAct(nn.Sequential):
     def forward(self, x):
         return run_module(self, x)
 
-    def fwd(self, x, tape=None, out=None):
-        return conv_block_fwd(_as_input(x), self[0], self[1], ACT_SILU, self.training, tape, out)
+    def fwd(self, x, tape=None, out=None, lazy_out=False):
+        return conv_block_fwd(_as_input(x), self[0], self[1], ACT_SILU, self.training, tape, out, lazy_out=lazy_out)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         return conv_block_bwd(tape, dy, dx, acc, need_dx)
@@ -329,7 +334,7 @@ class RFB2(HipModule):
         self.branch3 = nn.Sequential(Conv(in_planes, inter, k=1, s=1))
         self.ConvLinear = Conv(4 * inter, out_planes, k=1, s=1)
 
-    def fwd(self, x, tape=None, out=None):
+    def fwd(self, x, tape=None, out=None, lazy_out=False):
         x = _as_input(x)
         i = self.branch1[0].in_channels
         n, _, h, w = x.shape
@@ -338,16 +343,17 @@ class RFB2(HipModule):
             # training: branch3's and branch0's first 1x1 read the same x -> ONE convolution + ONE BatchNorm launch writing
             # [x3 | t] into the tail of a 5i-wide buffer [x0 | x1 | x2 | x3 | t]; ConvLinear reads the first four fifths
             cat = ops.new_act(n, 5 * i, h, w, x.dtype, x.device)
-            pair_block_fwd(x, self.branch3[0], self.branch0[0], hit, tape, cat[:, 3 * i:])
+            # every intermediate of the block feeds convolutions only (branch chain, ConvLinear): all of them stay raw
+            pair_block_fwd(x, self.branch3[0], self.branch0[0], hit, tape, cat[:, 3 * i:], lazy_out=True)
             t = cat[:, 4 * i:]
         else:
             cat = ops.new_act(n, 4 * i, h, w, x.dtype, x.device)     # [x0 | x1 | x2 | x3]
-            self.branch3[0].fwd(x, tape, cat[:, 3 * i:])
-            t = self.branch0[0].fwd(x, tape)
-        x0 = self.branch0[1].fwd(t, tape, cat[:, :i])
-        x1 = self.branch1.fwd(x0, tape, cat[:, i:2 * i])
-        self.branch2.fwd(x1, tape, cat[:, 2 * i:3 * i])
-        z = self.ConvLinear.fwd(cat[:, :4 * i], tape, out)
+            self.branch3[0].fwd(x, tape, cat[:, 3 * i:], lazy_out=True)
+            t = self.branch0[0].fwd(x, tape, lazy_out=True)
+        x0 = self.branch0[1].fwd(t, tape, cat[:, :i], lazy_out=True)
+        x1 = self.branch1.fwd(x0, tape, cat[:, i:2 * i], lazy_out=True)
+        self.branch2.fwd(x1, tape, cat[:, 2 * i:3 * i], lazy_out=True)
+        z = self.ConvLinear.fwd(cat[:, :4 * i], tape, out, lazy_out=lazy_out)
         if tape is not None:
             tape.push("rfb-merged" if hit is not None else "rfb-plain")
         return z

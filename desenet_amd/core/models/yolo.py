@@ -65,7 +65,7 @@ class SegMaskPSP(HipModule):
         n, _, h, w = x8.shape
         dt, dev = x8.dtype, x8.device
         cat = ops.new_act(n, 3 * c, h, w, dt, dev)                      # [m8 | up2(m16) | up4(m32)]
-        self.m8[0].fwd(x8, tape, cat[:, :c])
+        self.m8[0].fwd(x8, tape, cat[:, :c], lazy_out=True)              # read by RFB2's 1x1 convs only: stays raw
         f16 = self.m16[0].fwd(x16, tape)
         ops.bilinear_ac(f16, cat[:, c:2 * c])
         f32 = self.m32[0].fwd(x32, tape)
@@ -75,21 +75,33 @@ class SegMaskPSP(HipModule):
         self.out[1].fwd(pp[:, :c], tape, pp)
         y = self.out[2].fwd(pp, tape)
         logits = conv_block_fwd(y, self.out[3], None, ACT_NONE, self.training, tape)
+        if tape is not None and self.__dict__.get("_dsn_lowres_out") and self.c_out == 2:
+            # fused-loss mode (desenet_amd.graph.GraphedTrainStep): hand out the 1/8-resolution logits; the x8 bilinear of
+            # yolo.py:183 happens inside the loss kernel and the gradient comes back at this resolution
+            logits._dsn_seg_upsample = (8 * h, 8 * w)
+            tape.push((f16.shape, f32.shape, logits.shape, dt, True))
+            return logits
         seg = torch.empty((n, self.c_out, 8 * h, 8 * w), dtype=torch.float32, device=dev)   # caller-facing NCHW fp32
         ops.bilinear_ac(logits, seg, out_nchw=True)
         if tape is not None:
-            tape.push((f16.shape, f32.shape, logits.shape, dt))
+            tape.push((f16.shape, f32.shape, logits.shape, dt, False))
         return seg
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
-        s16, s32, sl, dt = tape.pop()
+        s16, s32, sl, dt, lowres = tape.pop()
         dev = dy.device
         c = self.m8[0].conv.out_channels
-        g = dy if (dy.dtype == torch.float32 and dy.is_contiguous()) else dy.float().contiguous()
         # rows padded with zeros to the 16-byte vector (2 -> 4 / 8 classes): the classifier's weight and input gradients take the
         # vector paths (and the weight gradient joins the grouped launch) instead of the scalar-load ones
         vec = 4 if dt == torch.float32 else 8
-        dlog = ops.bilinear_ac_bwd(g, ops.new_act(*sl, dt, dev, zero=True, ldc_align=vec), dy_nchw=True)
+        if lowres:
+            if tuple(dy.shape) != tuple(sl) or not getattr(dy, "_dsn_zero_padded", False):
+                raise RuntimeError("SegMaskPSP handed out low-resolution logits (fused seg loss): its backward expects the "
+                                   "gradient SegmentationLosses.forward_backward returned for them")
+            dlog = dy
+        else:
+            g = dy if (dy.dtype == torch.float32 and dy.is_contiguous()) else dy.float().contiguous()
+            dlog = ops.bilinear_ac_bwd(g, ops.new_act(*sl, dt, dev, zero=True, ldc_align=vec), dy_nchw=True)
         dlog._dsn_zero_padded = True
         d_y = conv_block_bwd(tape, dlog)
         dpp = self.out[2].bwd(tape, d_y)
@@ -335,6 +347,29 @@ class Model(HipModule):
                 chans[m.i] = sum(sizes)
             else:
                 chans[m.i] = self._out_channels(m, chans)
+        self._plan_deferred()
+
+    def _plan_deferred(self):
+        """Which top-level layers may leave their output as a raw, deferred-BatchNorm tensor (runtime.LazyRec): layers of a type
+        that can (Conv, Focus, C3, SPP) whose EVERY consumer in the graph applies the transform itself -- convolution-fronted
+        layers (Conv, C3, SPP, Detect, SegMaskPSP) directly, or through Concat layers, which only build views."""
+        consumers = {m.i: [] for m in self.model}
+        for m in self.model:
+            srcs = [m.i - 1] if m.f == -1 else ([m.f] if isinstance(m.f, int) else [m.i + j if j < 0 else j for j in m.f])
+            for s_ in srcs:
+                if 0 <= s_ < m.i:
+                    consumers[s_].append(m)
+
+        def accepts(m, seen=()):
+            if isinstance(m, (Conv, C3, SPP, Detect, SegMaskPSP)):
+                return True
+            if isinstance(m, Concat) and m.i not in seen:
+                cs = consumers[m.i]
+                return bool(cs) and all(accepts(c, seen + (m.i,)) for c in cs)
+            return False
+
+        self._lazy_plan = {m.i: bool(consumers[m.i]) and isinstance(m, (Conv, Focus, C3, SPP))
+                           and all(accepts(c) for c in consumers[m.i]) for m in self.model}
 
     @staticmethod
     def _out_channels(m, chans):
@@ -431,8 +466,11 @@ class Model(HipModule):
                 if buf is None:
                     buf = cats[cat_i] = ops.new_act(n, ctot, h, w, self._dtype_of(x), self._device_of(x))
                 dst = buf[:, c0:c0 + c]
-            x = m.fwd(x, tape, dst) if dst is not None else m.fwd(x, tape)
+            kw = {"lazy_out": True} if (tape is not None and self._lazy_plan.get(m.i)) else {}
+            x = m.fwd(x, tape, dst, **kw) if dst is not None else m.fwd(x, tape, **kw)
             y.append(x if m.i in self.save else None)
+        if tape is not None:
+            tape.finalize_forward()       # ONE launch: saved statistics + running averages of every BatchNorm of this pass
         return x, y[self.seg_index]
 
     @staticmethod

@@ -94,5 +94,11 @@ class SegmentationLosses(nn.CrossEntropyLoss):
         return _SegCEFn.apply(pred, target, self.ignore_index)
 
     def forward_backward(self, pred, target):
-        """(out [2] = {mean CE, 1/valid}, d loss / d pred) without autograd."""
+        """(out [2] = {mean CE, 1/valid}, d loss / d pred) without autograd.  `pred` may be the seg head's LOW-resolution logits
+        (SegMaskPSP under desenet_amd.graph.GraphedTrainStep(fuse_seg_loss=True): tagged `_dsn_seg_upsample = (H, W)`): the x8
+        bilinear up-sampling of yolo.py:183 is then fused with the cross entropy (dsn_seg_ce_up) and the returned gradient is the
+        low-resolution one the head's backward expects."""
+        up = getattr(pred, "_dsn_seg_upsample", None)
+        if up is not None:
+            return ops.seg_ce_up(pred, target, up, self.ignore_index)
         return ops.seg_ce(pred, target, self.ignore_index, want_grad=True)

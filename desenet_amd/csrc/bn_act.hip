@@ -280,6 +280,103 @@ __global__ __launch_bounds__(THREADS) void ew2_kernel(const T* __restrict__ a, i
     }
 }
 
+// ---- deferred BatchNorm: materialise z = act(y*scale + shift) [+ residual] with constants folded from the accumulators -----
+// The same elementwise pass as ew2_kernel<FwdF>, but driven by dsn_lazy_in descriptors (common.h): the input -- and the optional
+// residual, a Bottleneck shortcut that is itself a deferred tensor -- may be concats of raw pre-BN segments and ordinary ones.
+// No side effects: saved statistics and running averages are written once per step by bn_finalize_multi_kernel.
+template <typename T, int V, bool HAS_R>
+__global__ __launch_bounds__(THREADS) void lazy_ew_kernel(const T* __restrict__ a, int64_t ald, const T* __restrict__ r, int64_t rld,
+                                                          T* __restrict__ o, int64_t old_, Strip s, const LazyIn la, const LazyIn lr) {
+    __shared__ __attribute__((aligned(16))) float sc[HAS_R ? 2 : 1][PRO_MAXC], sh[HAS_R ? 2 : 1][PRO_MAXC];
+    __shared__ unsigned char act8[HAS_R ? 2 : 1][PRO_MAXC / 8];
+    lazy_table(la, s.C, sc[0], sh[0], act8[0], THREADS);
+    if (HAS_R) lazy_table(lr, s.C, sc[HAS_R ? 1 : 0], sh[HAS_R ? 1 : 0], act8[HAS_R ? 1 : 0], THREADS);
+    __syncthreads();
+    const int ncv = s.C / V;
+    const int TX = ncv < THREADS ? ncv : THREADS;
+    const int TY = THREADS / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    if (ty >= TY) return;
+    const int64_t p0 = blockIdx.x * s.per_block;
+    const int64_t p1 = (p0 + s.per_block < s.P) ? p0 + s.per_block : s.P;
+    for (int cv = tx; cv < ncv; cv += TX) {
+        float asc[V], ash[V], rsc[V], rsh[V];
+        ldvec<V>(sc[0] + cv * V, asc); ldvec<V>(sh[0] + cv * V, ash);
+        const int aact = act8[0][(cv * V) >> 3];
+        int ract = 0;
+        if (HAS_R) { ldvec<V>(sc[HAS_R ? 1 : 0] + cv * V, rsc); ldvec<V>(sh[HAS_R ? 1 : 0] + cv * V, rsh); ract = act8[HAS_R ? 1 : 0][(cv * V) >> 3]; }
+        const T* ap = a + cv * V;
+        const T* rp = HAS_R ? r + cv * V : nullptr;
+        T* op = o + cv * V;
+        auto one = [&](const float (&va)[V], const float (&vr)[V], int64_t p) {
+            float vo[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float u = apply_act(va[k] * asc[k] + ash[k], aact);
+                // a deferred residual is what its own materialisation would have stored: rounded to T before the add
+                if (HAS_R) u += to_f32<T>(from_f32<T>(apply_act(vr[k] * rsc[k] + rsh[k], ract)));
+                vo[k] = u;
+            }
+            VecIO<T, V>::store(op + p * old_, vo);
+        };
+        int64_t p = p0 + ty;
+        for (; p + (UNROLL - 1) * TY < p1; p += UNROLL * TY) {
+            float va[UNROLL][V], vr[UNROLL][V];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                VecIO<T, V>::load(ap + (p + u * TY) * ald, va[u]);
+                if (HAS_R) VecIO<T, V>::load(rp + (p + u * TY) * rld, vr[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) one(va[u], vr[u], p + u * TY);
+        }
+        for (; p < p1; p += TY) {
+            float va[V], vr[V];
+            VecIO<T, V>::load(ap + p * ald, va);
+            if (HAS_R) VecIO<T, V>::load(rp + p * rld, vr);
+            one(va, vr, p);
+        }
+    }
+}
+
+// saved statistics + running averages of up to FINAL_MAX BatchNorm modules per launch (end of the forward pass)
+constexpr int FINAL_MAX = 28;
+struct FinalTable {
+    int32_t n, pad;
+    int32_t first[FINAL_MAX + 1];     // first block of each entry (256 channels per block)
+    dsn_bn_final e[FINAL_MAX];
+};
+__global__ __launch_bounds__(256) void bn_finalize_multi_kernel(const FinalTable t) {
+    int l = 0;
+    while (l + 1 < t.n && t.first[l + 1] <= (int)blockIdx.x) ++l;
+    const dsn_bn_final& e = t.e[l];
+    const int c = ((int)blockIdx.x - t.first[l]) * 256 + threadIdx.x;
+    if (c >= e.n) return;
+    const double* a0 = (const double*)e.acc;
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < BN_NREP; ++r) {
+        const double* a = a0 + (size_t)r * 2 * e.acc_c;
+        s += a[e.ch0 + c];
+        ss += a[e.acc_c + e.ch0 + c];
+    }
+    const double mean = s / e.count;
+    double var = ss / e.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)e.eps));
+    const float g = e.gamma ? e.gamma[c] : 1.f, b = e.beta ? e.beta[c] : 0.f;
+    const float sc = g * rstd;
+    e.scale[c] = sc;
+    e.shift[c] = b - (float)mean * sc;
+    e.mean[c] = (float)mean;
+    e.rstd[c] = rstd;
+    if (e.running_mean) {
+        const double unbiased = e.count > 1.0 ? var * e.count / (e.count - 1.0) : var;
+        e.running_mean[c] = (1.f - e.momentum) * e.running_mean[c] + e.momentum * (float)mean;
+        e.running_var[c] = (1.f - e.momentum) * e.running_var[c] + e.momentum * (float)unbiased;
+    }
+}
+
 // ---- finalize kernels: one wave per channel folds the per-block rows in fp64 ------------------------------------------------
 __device__ __forceinline__ void fold_rows(const float* __restrict__ partial, int nblocks, int C, int c, int lane,
                                           double& s, double& ss) {
@@ -621,6 +718,70 @@ extern "C" int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const f
     if (rc) return rc;
     return dsn_bn_act_bwd_apply(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate, workspace,
                                 workspace_bytes, 0.0, 1.f, nullptr, stream);
+}
+
+static int lazy_check(const dsn_lazy_in* l, const dsn_tensor* t, const char* what) {
+    if (!l) return DSN_OK;
+    DSN_CHECK_ARG(l->nseg >= 0 && l->nseg <= DSN_LAZY_MAXSEG, "%s: %d segments", what, l->nseg);
+    for (int i = 0; i < l->nseg; ++i) {
+        const dsn_lazy_seg& s = l->seg[i];
+        DSN_CHECK_ARG(s.c0 >= 0 && s.c1 > s.c0 && s.c1 <= t->c, "%s: segment %d covers [%d, %d) of %d channels", what, i, s.c0, s.c1, t->c);
+        if (s.c0 % 8 || s.c1 % 8) DSN_FAIL(DSN_EUNSUPPORTED, "%s: segment bounds must be multiples of 8", what);
+        DSN_CHECK_ARG(!s.acc || (s.count > 0 && s.acc_c >= s.ch0 + (s.c1 - s.c0)), "%s: bad accumulator in segment %d", what, i);
+        DSN_CHECK_ARG((s.scale == nullptr) == (s.shift == nullptr), "%s: scale/shift must come in pairs", what);
+    }
+    return DSN_OK;
+}
+
+// z = lazy(x) [+ lazy(residual)]: materialises a deferred-BatchNorm tensor (or concat) -- see lazy_ew_kernel.
+extern "C" int dsn_lazy_materialize(const dsn_tensor* x, const dsn_lazy_in* lx, const dsn_tensor* residual,
+                                    const dsn_lazy_in* lres, const dsn_tensor* z, void* stream) {
+    DSN_CHECK_ARG(tensor_ok(x) && tensor_ok(z) && same_shape(x, z), "lazy_materialize: invalid tensors");
+    if (residual) DSN_CHECK_ARG(tensor_ok(residual) && same_shape(x, residual), "lazy_materialize: residual mismatch");
+    int rc = lazy_check(lx, x, "lazy_materialize");
+    if (rc) return rc;
+    if (residual && (rc = lazy_check(lres, residual, "lazy_materialize (residual)"))) return rc;
+    if (x->c > PRO_MAXC || !vec_ok(x) || !vec_ok(z) || (residual && !vec_ok(residual)))
+        DSN_FAIL(DSN_EUNSUPPORTED, "lazy_materialize: needs 16-byte channel vectors and at most %d channels", PRO_MAXC);
+    const LazyIn la = lx ? *lx : LazyIn{}, lr = (residual && lres) ? *lres : LazyIn{};
+    const int64_t P = npix(x);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(KID_BN_ACT_FWD, 0.0, (double)P * x->c * (x->dtype == DSN_F32 ? 4.0 : 2.0) * (residual ? 3 : 2), st);
+    DSN_DISPATCH_DTYPE(x->dtype, T, {
+        constexpr int VV = VW<T>::N;
+        int nb;
+        Strip s = make_strip(P, x->c, VV, 16384, &nb);
+        if (residual)
+            hipLaunchKernelGGL((lazy_ew_kernel<T, VV, true>), dim3(nb), dim3(THREADS), 0, st, (const T*)x->ptr, x->ldc,
+                               (const T*)residual->ptr, residual->ldc, (T*)z->ptr, z->ldc, s, la, lr);
+        else
+            hipLaunchKernelGGL((lazy_ew_kernel<T, VV, false>), dim3(nb), dim3(THREADS), 0, st, (const T*)x->ptr, x->ldc,
+                               (const T*)nullptr, (int64_t)0, (T*)z->ptr, z->ldc, s, la, lr);
+    });
+    DSN_LAUNCH_CHECK("lazy_materialize");
+    return DSN_OK;
+}
+
+extern "C" int dsn_bn_finalize_multi(const dsn_bn_final* entries, int32_t n, void* stream) {
+    DSN_CHECK_ARG(entries && n > 0, "bn_finalize_multi: bad arguments");
+    for (int base = 0; base < n; base += FINAL_MAX) {
+        FinalTable t{};
+        t.n = n - base < FINAL_MAX ? n - base : FINAL_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const dsn_bn_final& e = entries[base + i];
+            DSN_CHECK_ARG(e.acc && e.n > 0 && e.acc_c >= e.ch0 + e.n && e.count > 0 && e.scale && e.shift && e.mean && e.rstd &&
+                              (e.running_mean == nullptr) == (e.running_var == nullptr),
+                          "bn_finalize_multi: bad entry %d", base + i);
+            t.e[i] = e;
+            t.first[i] = blocks;
+            blocks += (e.n + 255) / 256;
+        }
+        t.first[t.n] = blocks;
+        hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+        DSN_LAUNCH_CHECK("bn_finalize_multi");
+    }
+    return DSN_OK;
 }
 
 extern "C" int dsn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, int32_t act, const dsn_tensor* dy, void* stream) {

@@ -150,6 +150,79 @@ __device__ __forceinline__ void bn_acc_fold(const BnAcc& f, int c, double& s, do
 }
 #endif
 
+// ---- deferred BatchNorm + activation ("lazy" inputs) ------------------------------------------------------------------------
+// A training-mode Conv block may leave its output as the RAW convolution result y (plus the per-channel fp64 sums in its BnAcc)
+// instead of running the BN + act pass: every consumer that is a convolution applies z = act(y * scale + shift) while it stages
+// its input operand (igemm: registers -> LDS; wgrad: the x operand), so z never travels through HBM.  A consumer's input may be a
+// concat of several such tensors (and of ordinary, already materialised ones): up to DSN_LAZY_MAXSEG channel segments.
+//   acc != NULL : forward, before the producer's statistics have been finalised -- the consumer folds the accumulators itself
+//                 (every block, redundantly, exactly as ew_prologue does: identical scale / shift bits)
+//   acc == NULL : scale / shift arrays (written by dsn_bn_finalize_multi at the end of the forward pass) -- backward (wgrad)
+//   both NULL   : identity segment
+// Channel c of the consumer's input inside [c0, c1) is accumulator channel ch0 + (c - c0) and parameter index p0 + (c - c0).
+#if defined(__HIPCC__)
+typedef dsn_lazy_seg LazySeg;
+typedef dsn_lazy_in LazyIn;
+// per-channel (scale, shift) of segment s for its local channel k (0-based inside the segment)
+__device__ __forceinline__ void lazy_fold(const LazySeg& s, int k, float& sc, float& sh) {
+    if (s.acc) {
+        const double* a0 = (const double*)s.acc;
+        double sum = 0.0, ssq = 0.0;
+#pragma unroll
+        for (int r = 0; r < BN_NREP; ++r) {
+            const double* a = a0 + (size_t)r * 2 * s.acc_c;
+            sum += a[s.ch0 + k];
+            ssq += a[s.acc_c + s.ch0 + k];
+        }
+        const double mean = sum / s.count;
+        double var = ssq / s.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)s.eps));
+        const float g = s.gamma ? s.gamma[s.p0 + k] : 1.f, b = s.beta ? s.beta[s.p0 + k] : 0.f;
+        sc = g * rstd;
+        sh = b - (float)mean * sc;
+    } else if (s.scale) {
+        sc = s.scale[s.p0 + k];
+        sh = s.shift[s.p0 + k];
+    } else {
+        sc = 1.f;
+        sh = 0.f;
+    }
+}
+// fill sc[0..C), sh[0..C) and act8[0..C/8) (activation code per 8-channel group) in LDS; all threads of the block call it
+__device__ __forceinline__ void lazy_table(const LazyIn& lz, int C, float* sc, float* sh, unsigned char* act8, int nthreads) {
+    for (int c = threadIdx.x; c < C; c += nthreads) {
+        float a = 1.f, b = 0.f;
+        int act = DSN_ACT_NONE;
+        for (int s = 0; s < lz.nseg; ++s)
+            if (c >= lz.seg[s].c0 && c < lz.seg[s].c1) {
+                lazy_fold(lz.seg[s], c - lz.seg[s].c0, a, b);
+                act = lz.seg[s].act;
+            }
+        sc[c] = a;
+        sh[c] = b;
+        if ((c & 7) == 0) act8[c >> 3] = (unsigned char)act;
+    }
+}
+// z = act(y * sc + sh) on one 16-byte vector of T (8 bf16 / 4 fp32); `valid` false -> zeros (padding taps stay zero AFTER the
+// activation).  The fp32 arithmetic and the final rounding are those of the elementwise BN + act kernel (bn_act.hip: FwdF).
+template <typename T> __device__ __forceinline__ u32x4 lazy_apply(u32x4 v, const float* sc, const float* sh, int act, bool valid);
+template <> __device__ __forceinline__ u32x4 lazy_apply<float>(u32x4 v, const float* sc, const float* sh, int act, bool valid) {
+    const f32x4 y = __builtin_bit_cast(f32x4, v);
+    f32x4 z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = valid ? apply_act(y[k] * sc[k] + sh[k], act) : 0.f;
+    return __builtin_bit_cast(u32x4, z);
+}
+template <> __device__ __forceinline__ u32x4 lazy_apply<bf16_t>(u32x4 v, const float* sc, const float* sh, int act, bool valid) {
+    const bf16x8 y = __builtin_bit_cast(bf16x8, v);
+    bf16x8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = valid ? (bf16_t)apply_act((float)y[k] * sc[k] + sh[k], act) : (bf16_t)0.f;
+    return __builtin_bit_cast(u32x4, z);
+}
+#endif
+
 #if defined(__HIPCC__)
 // 32-bit fill as a KERNEL.  hipMemsetAsync nodes captured into a hipGraph were observed (ROCm 7.2, gfx950) not to take effect
 // reliably on replay for small, 4-byte-aligned ranges inside a larger workspace (stale contents -> garbage indices), so the

@@ -391,6 +391,150 @@ __global__ __launch_bounds__(LT) void seg_ce_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- x8 bilinear (align_corners) + cross entropy, forward AND backward, without the full-resolution logits ---------------------
+// SegMaskPSP ends in Conv2d(c_hid, n_segcls, 1) at 1/8 resolution followed by nn.Upsample(scale 8, bilinear, align_corners=True)
+// (yolo.py:182-183), and training feeds that N x C x H x W fp32 tensor straight into nn.CrossEntropyLoss (loss.py:242-243):
+// 26 MB written, read twice, and 26 MB of gradient written and read back -- five launches, ~100 us.  Here ONE kernel walks the
+// high-resolution pixels, interpolates the C logits on the fly from an LDS copy of the 2-3 low-resolution rows it needs (the
+// arithmetic of bilinear_kernel: same coordinates, same weights, same order of operations), evaluates the loss AND its gradient
+// (softmax - onehot), and folds the gradient through the interpolation weights into the low-resolution grid (LDS atomics per
+// block, then one global atomic per touched element); a second small kernel divides by the number of valid pixels, rounds to the
+// storage type and restores the accumulator's zeros.  fp32 atomics: the summation order of the gradient is not fixed (1e-7).
+struct Lerp2 { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp2 lerp_ac(int o, float scale, int in) {     // = resample.hip: lerp_coord
+    const float sc = scale * (float)o;
+    Lerp2 r;
+    r.i0 = (int)sc;
+    if (r.i0 > in - 1) r.i0 = in - 1;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = sc - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+constexpr int SCU_ROWS = 4;        // low-resolution rows a band of <= 8 output rows may touch (checked on the host)
+// One block = one band of `RB` output rows of one image.  Stage 1: every thread evaluates its pixels (interpolation from an LDS
+// copy of the low-resolution rows, softmax, loss) and parks the gradient w.r.t. the INTERPOLATED logits in LDS.  Stage 2 folds it
+// back through the separable interpolation weights as two GATHERS (first along x, then along y): no atomics inside the block,
+// a fixed summation order; only the hand-over of the (<= 4 x wl x C) band result to the global accumulator uses atomics, because
+// neighbouring bands share low-resolution rows.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void seg_ce_up_kernel(const T* __restrict__ lg, int64_t ld, int hl, int wl, int H, int W, int RB,
+                                                        float sh, float sw, const int64_t* __restrict__ target, int ignore,
+                                                        float* __restrict__ gacc, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_gh = s_dyn;                            // [RB][W][C]
+    float* s_tx = s_gh + (size_t)RB * W * C;        // [RB][wl][C]
+    float* s_lg = s_tx + (size_t)RB * wl * C;       // [SCU_ROWS][wl][C]
+    __shared__ float red[2][256];
+    const int nb = (H + RB - 1) / RB;
+    const int n = blockIdx.x / nb, band = blockIdx.x - n * nb;
+    const int Y0 = band * RB;
+    const int rows = (Y0 + RB <= H) ? RB : H - Y0;
+    const int ylo0 = lerp_ac(Y0, sh, hl).i0;
+    for (int i = threadIdx.x; i < SCU_ROWS * wl * C; i += 256) {
+        const int c = i % C, x = (i / C) % wl, r = i / (C * wl);
+        const int yl = ylo0 + r;
+        s_lg[i] = yl < hl ? to_f32<T>(lg[(((int64_t)n * hl + yl) * wl + x) * ld + c]) : 0.f;
+    }
+    __syncthreads();
+    float s = 0.f, cnt = 0.f;
+    const int64_t* tg = target + ((int64_t)n * H + Y0) * W;
+    for (int p = threadIdx.x; p < rows * W; p += 256) {
+        const int yr = p / W, X = p - yr * W;
+        const int64_t t = tg[p];
+        float gh[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) gh[c] = 0.f;
+        if (!(t == ignore || t < 0 || t >= C)) {
+            const Lerp2 a = lerp_ac(Y0 + yr, sh, hl), b = lerp_ac(X, sw, wl);
+            const float* l0 = s_lg + (size_t)(a.i0 - ylo0) * wl * C;
+            const float* l1 = s_lg + (size_t)(a.i1 - ylo0) * wl * C;
+            float v[C], m = -INFINITY, lt = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                v[c] = a.l0 * (b.l0 * l0[b.i0 * C + c] + b.l1 * l0[b.i1 * C + c]) + a.l1 * (b.l0 * l1[b.i0 * C + c] + b.l1 * l1[b.i1 * C + c]);
+                m = fmaxf(m, v[c]);
+                if (c == t) lt = v[c];
+            }
+            float z = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) z += expf(v[c] - m);
+            s += logf(z) + m - lt;
+            cnt += 1.f;
+            const float iz = 1.f / z;
+#pragma unroll
+            for (int c = 0; c < C; ++c) gh[c] = expf(v[c] - m) * iz - (c == t ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s_gh[(size_t)p * C + c] = gh[c];
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = cnt;
+    __syncthreads();
+    // stage 2a: along x.  Low-resolution column xl receives l0 from the pixels whose left neighbour it is and l1 from those whose
+    // right neighbour it is: sw * X in [xl - 1, xl + 1)
+    const float isw = 1.f / sw;
+    for (int i = threadIdx.x; i < rows * wl * C; i += 256) {
+        const int c = i % C, xl = (i / C) % wl, yr = i / (C * wl);
+        int xlo = (int)((float)(xl - 1) * isw) - 1, xhi = (int)((float)(xl + 1) * isw) + 1;
+        xlo = xlo < 0 ? 0 : xlo;
+        xhi = xhi > W - 1 ? W - 1 : xhi;
+        float acc = 0.f;
+        const float* row = s_gh + (size_t)yr * W * C + c;
+        for (int X = xlo; X <= xhi; ++X) {
+            const Lerp2 b = lerp_ac(X, sw, wl);
+            const float wgt = (b.i0 == xl ? b.l0 : 0.f) + (b.i1 == xl ? b.l1 : 0.f);
+            acc += wgt * row[(size_t)X * C];
+        }
+        s_tx[i] = acc;
+    }
+    for (int t = 128; t > 0; t >>= 1) {
+        if ((int)threadIdx.x < t) { red[0][threadIdx.x] += red[0][threadIdx.x + t]; red[1][threadIdx.x] += red[1][threadIdx.x + t]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
+    // stage 2b: along y, then the band's contribution to the (zero-initialised) global accumulator
+    for (int i = threadIdx.x; i < SCU_ROWS * wl * C; i += 256) {
+        const int r = i / (C * wl), yl = ylo0 + r;
+        if (yl >= hl) continue;
+        float acc = 0.f;
+        for (int yr = 0; yr < rows; ++yr) {
+            const Lerp2 a = lerp_ac(Y0 + yr, sh, hl);
+            const float wgt = (a.i0 == yl ? a.l0 : 0.f) + (a.i1 == yl ? a.l1 : 0.f);
+            acc += wgt * s_tx[(size_t)yr * wl * C + (i - r * wl * C)];
+        }
+        if (acc != 0.f) unsafeAtomicAdd(&gacc[(int64_t)n * hl * wl * C + (int64_t)yl * wl * C + (i - r * wl * C)], acc);
+    }
+}
+// out[0] = mean CE, out[1] = 1 / valid; dlog (storage type, NHWC rows of `ld` elements, padding lanes zero) = gain * gacc / valid;
+// gacc is reset to zero (the accumulator is a "zero once" workspace).
+template <typename T>
+__global__ __launch_bounds__(256) void seg_ce_up_finalize_kernel(const float* __restrict__ partial, int np, float* __restrict__ gacc,
+                                                                 int64_t npx, int C, T* __restrict__ dlog, int64_t ld, float gain,
+                                                                 float* __restrict__ out) {
+    __shared__ double rs[2][256];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) { s += (double)partial[2 * i]; c += (double)partial[2 * i + 1]; }
+    rs[0][threadIdx.x] = s; rs[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int t = 128; t > 0; t >>= 1) {
+        if ((int)threadIdx.x < t) { rs[0][threadIdx.x] += rs[0][threadIdx.x + t]; rs[1][threadIdx.x] += rs[1][threadIdx.x + t]; }
+        __syncthreads();
+    }
+    const double cs = rs[1][0];
+    const float inv = cs > 0.0 ? (float)(1.0 / cs) : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = cs > 0.0 ? (float)(rs[0][0] / cs) : 0.f;
+        out[1] = inv;
+    }
+    for (int64_t px = blockIdx.x * 256ll + threadIdx.x; px < npx; px += (int64_t)gridDim.x * 256) {
+        for (int k = 0; k < (int)ld; ++k) {
+            float v = 0.f;
+            if (k < C) { v = gacc[px * C + k] * inv * gain; gacc[px * C + k] = 0.f; }
+            dlog[px * ld + k] = from_f32<T>(v);
+        }
+    }
+}
+
 inline int lgrid(int64_t total, int cap) {
     int64_t b = (total + LT - 1) / LT;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -469,6 +613,51 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
 }
 
 extern "C" int64_t dsn_seg_ce_workspace_bytes(void) { return (int64_t)(2 * 1024 + 4) * sizeof(float); }
+
+// Fused nn.Upsample(scale_factor, 'bilinear', align_corners=True) + CrossEntropyLoss(ignore_index), loss and gradient (see
+// seg_ce_up_kernel).  logits: the LOW-resolution classifier output (NHWC, c classes); target: [n, H, W] int64; dlogits: gradient
+// w.r.t. `logits` (same n, h, w; c channels + zeroed row padding up to its ldc), scaled by `gain`.
+// workspace: dsn_seg_ce_up_workspace_bytes(n, h, w, c, H) bytes whose first n*h*w*c floats are ZERO on entry (the call restores
+// them).  DSN_EUNSUPPORTED unless c == 2 (DeSeNet: se_nc 2), w <= 160 and the scale factor is >= 3.
+extern "C" int64_t dsn_seg_ce_up_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c, int32_t H) {
+    const int64_t nb = (int64_t)n * ((H + 3) / 4);          // (bands of 4 or 8 output rows)
+    return ((int64_t)n * h * w * c + 2 * nb + 64) * (int64_t)sizeof(float);
+}
+extern "C" int dsn_seg_ce_up(const dsn_tensor* logits, const int64_t* target, int32_t H, int32_t W, int32_t ignore_index,
+                             float gain, float* out, const dsn_tensor* dlogits, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+    DSN_CHECK_ARG(tensor_ok(logits) && tensor_ok(dlogits) && target && out && workspace && H > 1 && W > 1, "seg_ce_up: bad arguments");
+    DSN_CHECK_ARG(dlogits->n == logits->n && dlogits->h == logits->h && dlogits->w == logits->w && dlogits->c == logits->c &&
+                      dlogits->dtype == logits->dtype, "seg_ce_up: gradient tensor must have the logits' shape");
+    const int n = logits->n, hl = logits->h, wl = logits->w, C = logits->c;
+    // a band of RB output rows may touch floor(scale * (RB - 1)) + 3 low-resolution rows at most; LDS: RB rows of the output width
+    const int RB = W <= 640 ? 8 : 4;
+    const size_t lds = ((size_t)RB * W * C + (size_t)RB * wl * C + (size_t)SCU_ROWS * wl * C) * sizeof(float);
+    if (C != 2 || lds > 96 * 1024 || (float)(hl - 1) / (float)(H - 1) * (float)(RB - 1) + 3.f > (float)SCU_ROWS)
+        DSN_FAIL(DSN_EUNSUPPORTED, "seg_ce_up: %d classes, width %d, %dx%d -> %dx%d needs the unfused path", C, wl, hl, wl, H, W);
+    if (workspace_bytes < dsn_seg_ce_up_workspace_bytes(n, hl, wl, C, H)) DSN_FAIL(DSN_EWORKSPACE, "seg_ce_up: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* gacc = (float*)workspace;
+    float* partial = gacc + (int64_t)n * hl * wl * C;
+    const int nb = n * ((H + RB - 1) / RB);
+    const float sh = (float)(hl - 1) / (float)(H - 1), sw = (float)(wl - 1) / (float)(W - 1);
+    const int64_t npx = (int64_t)n * hl * wl;
+    DSN_DISPATCH_DTYPE(logits->dtype, T, {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((seg_ce_up_kernel<T, 2>), dim3(nb), dim3(256), lds, st, (const T*)logits->ptr, logits->ldc, hl, wl, H, W, RB,
+                           sh, sw, target, ignore_index, gacc, partial);
+        hipLaunchKernelGGL(seg_ce_up_finalize_kernel<T>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, partial, nb, gacc, npx, C,
+                           (T*)dlogits->ptr, dlogits->ldc, gain, out);
+    });
+    DSN_LAUNCH_CHECK("seg_ce_up");
+    return DSN_OK;
+}
 
 // logits: contiguous NCHW fp32; target: int64 [N,H,W]; out (device) [0] = mean CE over valid pixels, [1] = 1/valid count;
 // dlogits (may be NULL): d(out[0]) / d(logits), same layout as logits.

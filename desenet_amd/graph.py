@@ -32,7 +32,7 @@ class GraphedTrainStep:
     def __init__(self, model, loss_and_grads: Callable, flat, optimizer, example_input: torch.Tensor, warmup: int = 3,
                  ema=None, det_targets: Optional[torch.Tensor] = None, seg_targets: Optional[torch.Tensor] = None,
                  max_targets: int = 0, accumulate: int = 1, restore_after_warmup: bool = True,
-                 split_layer: Optional[int] = None):
+                 split_layer: Optional[int] = None, fuse_seg_loss: bool = True):
         """loss_and_grads(det_out, seg_out, det_targets, seg_targets) -> (loss tensor, d_det, d_seg): HIP kernels only
         (capturable); it must read the labels from the tensors it is handed (the step's static buffers), not from a closure.
         Legacy form: without det_targets / seg_targets the callable is invoked as loss_and_grads(det_out, seg_out) and whatever
@@ -41,6 +41,9 @@ class GraphedTrainStep:
         restore_after_warmup: the `warmup` eager steps that populate caches / workspaces / optimizer state are undone
         afterwards (weights, BatchNorm buffers, momentum buffers, EMA), so that building the step does not train.
         ema: optional desenet_amd ModelEMA, updated right after the optimizer step (train.py:374-375) inside the graph.
+        fuse_seg_loss: the seg head hands the loss its 1/8-resolution logits and SegmentationLosses.forward_backward fuses the x8
+        bilinear up-sampling (yolo.py:183) with the cross entropy, forward and backward -- the N x 2 x 640 x 640 fp32 logits and
+        their gradient are never written.  Needs a loss_and_grads built on SegmentationLosses.forward_backward.
         split_layer (world_size > 1): first top-level layer index of the second all-reduce chunk (default: the layer at which
         about half of the parameters lie behind; 0 disables the overlap)."""
         self.model, self.loss_and_grads, self.flat, self.opt, self.ema = model, loss_and_grads, flat, optimizer, ema
@@ -50,6 +53,7 @@ class GraphedTrainStep:
             raise ValueError("accumulate must be >= 1")
         self.accumulate = int(accumulate)
         self.micro = 0
+        self.fuse_seg_loss = bool(fuse_seg_loss)
         self.x = example_input.clone()
         dev = self.x.device
         self.det_t = self.seg_t = None
@@ -126,7 +130,14 @@ class GraphedTrainStep:
         """forward + losses + backward (down to top-level layer `stop_at`, exclusive of the layers below it, when given).
         Returns the loss, or (loss, tape) when stop_at is given."""
         tape = Tape()
-        det, seg = self.model.fwd(self.x, tape)
+        heads = [m for m in self.model.modules() if type(m).__name__ == "SegMaskPSP"] if self.fuse_seg_loss else []
+        for m in heads:
+            m.__dict__["_dsn_lowres_out"] = True
+        try:
+            det, seg = self.model.fwd(self.x, tape)
+        finally:
+            for m in heads:
+                m.__dict__.pop("_dsn_lowres_out", None)
         loss, d_det, d_seg = self._losses(det, seg)
         tape.begin_backward()
         if stop_at is None:

@@ -52,6 +52,34 @@ typedef struct {
     int32_t accumulate;  /* 1: out += result (gradient fan-in)            */
 } dsn_conv_params;
 
+/* ---- deferred BatchNorm + activation ("lazy" input of a convolution) ------------------------------------------------
+ * In training a Conv block computes z = act(bn(conv(x))) (common.py:53) with batch statistics: the statistics of the WHOLE
+ * tensor must exist before a single z can be formed.  Instead of a separate BN + act pass over HBM, a block may leave its
+ * RAW convolution output y in place (plus the per-channel fp64 sums its epilogue produced, dsn_conv2d_fwd_bnacc) and let every
+ * CONSUMING convolution apply z = act(y*scale + shift) while it stages its input operand.  The consumer's input is described
+ * as up to DSN_LAZY_MAXSEG channel segments (a concat of lazy tensors and ordinary ones -- common.py:145,185,545,693).
+ *   input channel c in [c0, c1): accumulator channel ch0 + (c - c0), parameter index p0 + (c - c0)
+ *   acc != NULL : fold the sums here (count, eps, gamma, beta -- NULL gamma/beta = 1 / 0); else scale/shift arrays (both NULL:
+ *   identity).  act = DSN_ACT_* applied after the affine map.  Channels outside every segment pass through unchanged. */
+#define DSN_LAZY_MAXSEG 6
+typedef struct {
+    int32_t       c0, c1;       /* channel range of the consumer's input */
+    int32_t       ch0, p0;      /* first accumulator channel / first parameter index of the range */
+    int32_t       acc_c;        /* channel count of the accumulator buffer ([DSN_BN_NREP][2][acc_c] doubles) */
+    int32_t       act;
+    const void*   acc;
+    const float*  gamma;
+    const float*  beta;
+    const float*  scale;
+    const float*  shift;
+    double        count;        /* pixels per channel behind the sums */
+    float         eps, _pad;
+} dsn_lazy_seg;
+typedef struct {
+    int32_t      nseg, _pad;
+    dsn_lazy_seg seg[DSN_LAZY_MAXSEG];
+} dsn_lazy_in;
+
 int         dsn_version(void);
 const char* dsn_last_error(void);
 
@@ -352,6 +380,15 @@ int dsn_det_loss(const float* const* p, float* const* dp, const int32_t* ny, con
 int64_t dsn_seg_ce_workspace_bytes(void);
 int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
                int32_t ignore_index, float* out, float* dlogits, void* workspace, int64_t workspace_bytes, void* stream);
+/* nn.Upsample(scale_factor, 'bilinear', align_corners=True) (yolo.py:183) + CrossEntropyLoss(ignore_index) (loss.py:242-243)
+ * fused, loss AND gradient, from the LOW-resolution classifier output: the N x C x H x W fp32 logits (and their gradient) are never
+ * formed.  logits / dlogits: NHWC tensors of the same shape (dlogits' row padding is zeroed); target [n, H, W] int64;
+ * out[0] = mean CE, out[1] = 1 / valid pixels; dlogits = gain * d out[0] / d logits.  workspace: dsn_seg_ce_up_workspace_bytes
+ * bytes whose first n*h*w*c floats are ZERO on entry (restored on exit).  DSN_EUNSUPPORTED unless c == 2, w <= 160, scale >= 3:
+ * use dsn_bilinear_ac + dsn_seg_ce + dsn_bilinear_ac_bwd. */
+int64_t dsn_seg_ce_up_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c, int32_t H);
+int dsn_seg_ce_up(const dsn_tensor* logits, const int64_t* target, int32_t H, int32_t W, int32_t ignore_index, float gain,
+                  float* out, const dsn_tensor* dlogits, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- evaluation arithmetic (scripts/val.py:101-122; core/utils/metrics.py:247-269,350-388) ----------------------------
  * dsn_box_iou: out[n][m] = IoU of xyxy boxes, the reference's operation order (bit-exact matching in process_batch).
@@ -379,6 +416,45 @@ int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream
 int dsn_fill32(void* p, uint32_t value, int64_t n_words, void* stream);
 /* p[i] += value for n int64 elements: BatchNorm's `num_batches_tracked += 1` for every layer in one launch. */
 int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream);
+
+/* ---- convolution with a deferred-BatchNorm input, and the end-of-forward finalisation ---------------------------------------
+ * dsn_conv2d_fwd_lazy: dsn_conv2d_fwd / dsn_conv2d_fwd_bnacc whose input x holds raw pre-BN values for the channel segments of
+ *   `lazy` (NULL or nseg == 0: plain input).  acc != NULL: also emit the BatchNorm sums of y (dsn_conv2d_fwd_bnacc; bias NULL,
+ *   act NONE, no residual).  DSN_EUNSUPPORTED when the layer cannot take the 16-byte staging paths, has more than 1024 input
+ *   channels or segment bounds that are not multiples of the vector width: materialise x (dsn_bn_act_fwd_acc) and call the plain
+ *   entry point.
+ * dsn_bn_finalize_multi: for n BatchNorm modules whose sums are complete, write scale = g*rstd, shift = b - mean*scale, mean, rstd
+ *   (saved for the backward pass) and update the running statistics (torch_utils.py:164-165 momentum 0.03, unbiased variance) --
+ *   ONE launch per 32 modules at the end of the forward pass instead of one per layer.  entries: HOST array. */
+typedef struct {
+    const void*  acc;            /* [DSN_BN_NREP][2][acc_c] doubles */
+    int32_t      acc_c, ch0;     /* accumulator channel count, first channel of this module */
+    int32_t      n, _pad;        /* channels of this module */
+    double       count;
+    const float* gamma;
+    const float* beta;
+    float*       running_mean;   /* may be NULL (with running_var) */
+    float*       running_var;
+    float*       scale;          /* outputs, n floats each */
+    float*       shift;
+    float*       mean;
+    float*       rstd;
+    float        momentum, eps;
+} dsn_bn_final;
+int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy, const void* w_packed, const float* bias,
+                        const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc, int64_t acc_bytes,
+                        void* stream);
+int dsn_bn_finalize_multi(const dsn_bn_final* entries_host, int32_t n, void* stream);
+/* dsn_conv2d_wgrad_plan with a deferred-BatchNorm x operand: lx segments carry scale / shift arrays (acc NULL; the backward pass
+ * runs after dsn_bn_finalize_multi); the queued kernels apply z = act(x*scale + shift) while staging x.  DSN_EUNSUPPORTED when
+ * the layer cannot take the grouped 16-byte paths: materialise x and plan / run the plain form. */
+int dsn_conv2d_wgrad_plan_lazy(const dsn_tensor* x, const dsn_lazy_in* lx, const dsn_tensor* dy, float* dw, int32_t ci_pad,
+                               int32_t oihw, const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* job_out);
+/* z = act(x*scale + shift) per segment of lx (NULL: copy) [+ the same of `residual` under lres: a Bottleneck shortcut,
+ * common.py:111, rounded to the storage type before the add exactly as a materialised shortcut would be].  No side effects on
+ * BatchNorm state.  DSN_EUNSUPPORTED without 16-byte channel vectors or above 1024 channels. */
+int dsn_lazy_materialize(const dsn_tensor* x, const dsn_lazy_in* lx, const dsn_tensor* residual, const dsn_lazy_in* lres,
+                         const dsn_tensor* z, void* stream);
 
 /* ---- live profiler (bench.py roofline): HIP events recorded on the launch stream around the hot kernels ------------
  * dsn_profile_enable(1) starts recording, (0) stops; dsn_profile_collect waits for the recorded events and returns, per

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from desenet_amd.synth import synth_targets
-from tests.util import assert_close
+from tests.util import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 ANCHORS = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]).float().view(3, 3, 2) \
@@ -119,3 +119,28 @@ def test_losses_replay_in_a_graph():
         graph.replay()
         assert_close(res.cpu(), want, 1e-6, f"replay {i}")
         keep.append([torch.randn(n, device=dev) for n in (7, 1000, 100000, 3000000)])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (8, 80, 80), (1, 20, 36)])
+def test_seg_ce_fused_with_the_x8_bilinear(dtype, tol, n, h, w):
+    """dsn_seg_ce_up (x8 bilinear, align_corners=True, + cross entropy, loss and gradient from the 1/8-resolution logits) against
+    the three-kernel form it replaces -- bilinear_ac -> seg_ce -> bilinear_ac_bwd -- which is itself pinned to ATen / the reference
+    (test_seg_ce_vs_aten, G3 goldens), including ignored pixels."""
+    from desenet_amd import hip_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(n * 100 + h)
+    lg = ops.as_act((torch.randn((n, 2, h, w), device="cuda", generator=g) * 2.0).to(dtype))
+    H, W = 8 * h, 8 * w
+    tgt = (torch.rand((n, H, W), device="cuda", generator=g) > 0.7).long()
+    tgt[0, :3, :5] = -1                                            # ignore_index
+    full = torch.empty((n, 2, H, W), dtype=torch.float32, device="cuda")
+    ops.bilinear_ac(lg, full, out_nchw=True)
+    out_ref, dfull = ops.seg_ce(full, tgt, -1, want_grad=True)
+    vec = 4 if dtype == torch.float32 else 8
+    dl_ref = ops.bilinear_ac_bwd(dfull, ops.new_act(n, 2, h, w, dtype, "cuda", zero=True, ldc_align=vec), dy_nchw=True)
+    out, dl = ops.seg_ce_up(lg, tgt, (H, W), -1)
+    assert abs(float(out[0]) - float(out_ref[0])) <= 1e-5 * abs(float(out_ref[0])) and float(out[1]) == float(out_ref[1])
+    assert rel_err(dl.float().cpu(), dl_ref.float().cpu()) < tol
+    assert float(ops.padded_view(dl)[:, 2:].abs().max()) == 0.0, "row padding of the gradient must be zero"
+    out2, dl2 = ops.seg_ce_up(lg, tgt, (H, W), -1)                 # the accumulator workspace was restored to zero
+    assert rel_err(dl2.float().cpu(), dl.float().cpu()) < tol and float(out2[0]) == float(out[0])     # (fp32 atomics: order varies)

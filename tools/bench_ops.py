@@ -28,6 +28,23 @@ LAYERS = [  # name, N, Ci, H, W, Co, k, s
 ]
 
 
+LAYERS_M = [  # DeSeNet-m (config 5): batch 4, 1280x1280 -- the layers that carry its FLOPs
+    ("m bneck 128->128 k3 @160", 4, 128, 160, 160, 128, 3, 1),
+    ("m bneck 256->256 k3 @80", 4, 256, 80, 80, 256, 3, 1),
+    ("m bneck 512->512 k3 @40", 4, 512, 40, 40, 512, 3, 1),
+    ("m bneck 64->64 k3 @320", 4, 64, 320, 320, 64, 3, 1),
+    ("m ffm 512->256 k3 @160", 4, 512, 160, 160, 256, 3, 1),
+    ("m l3 128->256 k3s2 @320", 4, 128, 320, 320, 256, 3, 2),
+    ("m l5 256->512 k3s2 @160", 4, 256, 160, 160, 512, 3, 2),
+    ("m c3 cv3 256->256 k1 @160", 4, 256, 160, 160, 256, 1, 1),
+    ("m c3 pair 512->512 k1 @80", 4, 512, 80, 80, 512, 1, 1),
+    ("m c3 cv1 256->256 k1 @80", 4, 256, 80, 80, 256, 1, 1),
+    ("m c3 cv1 128->128 k1 @160", 4, 128, 160, 160, 128, 1, 1),
+    ("m rfb 768->128 k1 @160", 4, 768, 160, 160, 128, 1, 1),
+    ("m spp 2048->1024 k1 @40", 4, 2048, 40, 40, 1024, 1, 1),
+]
+
+
 def timeit(fn, iters=30):
     for _ in range(3):
         fn()
@@ -78,7 +95,8 @@ def main():
     only = sys.argv[2] if len(sys.argv) > 2 else None
     if which == "bn":
         return bench_bn()
-    for name, n, ci, h, w, co, k, s in LAYERS:
+    import os
+    for name, n, ci, h, w, co, k, s in (LAYERS_M if os.environ.get("DSN_BENCH_SET") == "m" else LAYERS):
         if only and only not in name:
             continue
         pad = k // 2
