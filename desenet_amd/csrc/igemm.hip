@@ -653,23 +653,10 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     // grid is small -- at most ~1.75 blocks of 64x64 per CU, so the larger LDS footprint costs no occupancy and the deeper
     // prefetch is all gain (3x3 on 20x20 / 40x40 maps: 16.8 -> 13.9, 23.7 -> 19.8, 14.8 -> 12.9 us; 1x1 512 -> 256 @20: 7.4 ->
     // 5.7) -- and loses on the large-grid layers (1x1 128 -> 64 @80: 7.3 -> 9.3 us: three resident blocks instead of four).
+    // The 128x128 tile (96 KB: one block per CU) lost with the ring on every config-5 layer (65.7 -> 87.9 us on 3x3 128 -> 128 @160)
+    // and a 4-stage ring lost to the 3-stage one everywhere (a third fewer resident blocks): neither is built.
     // DSN_IGEMM_GL = 0 (never) | 3 (always) overrides.
     static const int gl_env = [] { const char* e = getenv("DSN_IGEMM_GL"); return e ? atoi(e) : -1; }();
-    if constexpr (BM == 128 && BN == 128) {
-        // the 128x128 tile (config 5's 3x3 layers): tuning knob DSN_IGEMM_GL128 = 3 | 4 stages (96 / 128 KB of LDS: one block per CU)
-        static const int gl128 = [] { const char* e = getenv("DSN_IGEMM_GL128"); return e ? atoi(e) : 0; }();
-        if (!lazy && !par && vec && uni && (gl128 == 3 || gl128 == 4)) {
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void*)(igemm_kernel<T, MI, NI, WGM, WGN, 2, false, false, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-                attr = true;
-            }
-            if (gl128 == 3) hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
-            else hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, false, 3, 4>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
-            DSN_LAUNCH_CHECK("igemm 128x128 (LDS-DMA)");
-            return DSN_OK;
-        }
-    }
     if constexpr (BM % 32 == 0 && BN % 32 == 0 && BM * BN <= 128 * 64) {
         const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
         const bool want = gl_env >= 0 ? gl_env == 3 : (blocks <= 448 && g.Ktot * (int)sizeof(T) >= 512);
