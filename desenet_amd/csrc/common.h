@@ -242,6 +242,12 @@ static inline void dsn_fill_u32(void* p, uint32_t v, int64_t n_words, hipStream_
 }
 #endif
 
+// conv3x3.hip: the halo-tile kernel for 3x3 / stride-1 convolutions (forward and data gradient).  Returns 1 when the layer is not
+// one it takes (nothing launched), 0 when it ran, another status on failure.  finp: BatchNorm accumulators for the epilogue or NULL.
+struct BnAcc;
+int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #define DSN_DISPATCH_DTYPE(dt, T, ...)                 \

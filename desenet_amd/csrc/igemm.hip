@@ -748,6 +748,10 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
         DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == y->dtype && residual->n == y->n &&
                           residual->h == y->h && residual->w == y->w && residual->c == y->c,
                       "conv fwd: residual shape mismatch");
+    if (!stats && !(lz && lz->nseg > 0)) {      // 3x3 / stride 1 with whole 64-channel slabs: the halo-tile kernel (conv3x3.hip)
+        rc = dsn_conv3x3_halo_try(x, w, bias, residual, y, p, 0, finp, stream);
+        if (rc != 1) return rc;
+    }
     Geom g{};
     g.M = (int32_t)npix(y); g.Hd = y->h; g.Wd = y->w;
     g.Hs = x->h; g.Ws = x->w; g.Cs = x->c; g.Cd = y->c;
@@ -861,6 +865,8 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
         DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == dx->dtype && residual->n == dx->n && residual->h == dx->h &&
                           residual->w == dx->w && residual->c == dx->c && p->stride == 1,
                       "conv dgrad: residual must have dx's shape (stride-1 convolutions only)");
+    rc = dsn_conv3x3_halo_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream);
+    if (rc != 1) return rc;
     Geom g{};
     g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;
     g.Hs = dy->h; g.Ws = dy->w; g.Cs = dy->c; g.Cd = dx->c;

@@ -57,6 +57,11 @@ CONV_CASES = [
     (1, 6, 7, 5, 10, 3, 1, 1, 1),        # scalar-load path (Ci % 4 != 0)
     (2, 192, 12, 12, 64, 3, 1, 1, 1),    # long K, few tiles: in-block split-K with an ODD chunk count (27 bf16 chunks)
     (1, 128, 16, 16, 64, 3, 1, 2, 2),    # the same path, dilated taps
+    # conv3x3.hip (halo-tile kernel: 3x3 / stride 1, whole 128-byte channel slabs, maps that are multiples of 8)
+    (2, 64, 16, 24, 96, 3, 1, 1, 1),     # two images, ragged output-channel tile
+    (2, 64, 16, 16, 64, 3, 1, 3, 3),     # dilation 3 (14 x 14 halo)
+    (1, 256, 8, 16, 128, 3, 1, 1, 1),    # four bf16 slabs: halo prefetch of the next slab
+    (3, 128, 8, 8, 32, 3, 1, 2, 2),      # one patch per image, narrow output
 ]
 
 
@@ -167,7 +172,7 @@ def test_wgrad_queue_matches_single_layer(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 16, 9, 7, 24), (4, 64, 20, 20, 64), (8, 16, 64, 64, 32)])
+@pytest.mark.parametrize("shape", [(2, 16, 9, 7, 24), (4, 64, 20, 20, 64), (8, 16, 64, 64, 32), (2, 64, 16, 24, 96)])
 def test_conv_bn_act_fused_statistics(ops, shape, dtype):
     """dsn_conv2d_fwd_bnacc + dsn_bn_act_fwd_acc (statistics out of the conv epilogue, folded in the prologue of the BN + act
     kernel) against conv -> BatchNorm2d(train) -> SiLU from ATen; accumulator slots come from the per-step arena."""
