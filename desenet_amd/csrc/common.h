@@ -248,6 +248,9 @@ struct BnAcc;
 int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                          const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream);
 
+int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #define DSN_DISPATCH_DTYPE(dt, T, ...)                 \

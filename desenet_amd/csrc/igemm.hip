@@ -751,6 +751,8 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
     if (!stats && !(lz && lz->nseg > 0)) {      // 3x3 / stride 1 with whole 64-channel slabs: the halo-tile kernel (conv3x3.hip)
         rc = dsn_conv3x3_halo_try(x, w, bias, residual, y, p, 0, finp, stream);
         if (rc != 1) return rc;
+        rc = dsn_conv1x1_dma_try(x, w, bias, residual, y, p, 0, finp, stream);      // 1x1 with <= 4 channel slabs
+        if (rc != 1) return rc;
     }
     Geom g{};
     g.M = (int32_t)npix(y); g.Hd = y->h; g.Wd = y->w;
@@ -866,6 +868,8 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
                           residual->w == dx->w && residual->c == dx->c && p->stride == 1,
                       "conv dgrad: residual must have dx's shape (stride-1 convolutions only)");
     rc = dsn_conv3x3_halo_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream);
+    if (rc != 1) return rc;
+    rc = dsn_conv1x1_dma_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream);
     if (rc != 1) return rc;
     Geom g{};
     g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;

@@ -1,6 +1,8 @@
 """Deferred BatchNorm + activation (include/desenet_hip.h: dsn_lazy_in) on the MI355X: a convolution / weight gradient that
 applies z = act(y*scale + shift) while staging its operand must produce EXACTLY what it produces from the materialised z (same
-fp32 arithmetic, same rounding to the storage type, zero padding after the activation) -- bit for bit, every staging variant:
+fp32 arithmetic, same rounding to the storage type, zero padding after the activation) -- bit for bit for the weight gradients
+(same kernel on both sides) and up to the K summation order for the convolutions (the materialised side may take the halo-tile or
+one-trip kernels of conv3x3.hip, the deferred side the implicit-GEMM kernel), every staging variant:
 uniform-tap chunks (Cs a multiple of the chunk), per-thread tap decode (Cs = 16 / 32), 1x1 / 3x3 / stride 2 / dilation, and a
 consumer input that is a concat of two deferred tensors and an ordinary one.  The module- and net-level goldens then hold the whole
 deferred forward/backward to the reference."""
@@ -13,6 +15,10 @@ pytestmark = pytest.mark.gpu
 def _rand(shape, dtype, seed, scale=1.0):
     g = torch.Generator(device="cuda").manual_seed(seed)
     return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max())
 
 
 def _producer(ops, tape, n, ci, co, h, w, dtype, seed, act, buf=None, c0=0):
@@ -75,11 +81,14 @@ def test_lazy_conv_and_wgrad_equal_the_materialised_path(dtype, k, stride, dil, 
         p = ops.conv_params(k, stride, pad, dil, ACT_NONE)
         y_ref = ops.conv2d_fwd(z, wp, None, None, ops.new_act(n, co, ho, wo, dtype, "cuda"), p)
         y_lazy = ops.conv2d_fwd(buf, wp, None, None, ops.new_act(n, co, ho, wo, dtype, "cuda"), p, lazy=lz)
-        assert torch.equal(y_ref, y_lazy), float((y_ref.float() - y_lazy.float()).abs().max())
+        # (same values staged; the materialised operand may run on another kernel of the library -- conv3x3.hip's halo-tile / one-trip
+        #  kernels do not take deferred inputs -- whose K order differs: equal up to fp32 summation order / one bf16 rounding)
+        tol = 2e-5 if dtype == torch.float32 else 1e-2
+        assert _rel(y_lazy, y_ref) < tol, _rel(y_lazy, y_ref)
         # with BatchNorm sums in the epilogue (training form)
         y2 = ops.new_act(n, co, ho, wo, dtype, "cuda")
         acc, nb = ops.conv2d_fwd_acc(buf, wp, y2, p, lazy=lz)
-        assert torch.equal(y2, y_ref)
+        assert _rel(y2, y_ref) < tol
         # weight gradient: queued kernels with the finalised scale / shift arrays vs the materialised operand
         dy = ops.as_act(_rand((n, co, ho, wo), dtype, 7))
         lzb = tape.lazy_in(buf, backward=True)

@@ -452,7 +452,7 @@ def test_config5_full_size_bf16_step_vs_fp32():
                 if p.grad is not None:
                     assert torch.isfinite(p.grad).all(), k
                     gn += float(p.grad.double().pow(2).sum())
-            res[dtype] = (float(det_loss), float(seg_loss), gn ** 0.5, items.detach().cpu())
+            res[dtype] = (float(det_loss.detach()), float(seg_loss.detach()), gn ** 0.5, items.detach().cpu())
             del m, det_pred, seg_pred
             torch.cuda.empty_cache()
     finally:
