@@ -115,19 +115,35 @@ import os as _os
 # Default 0: nothing is deferred (every block materialises z with one elementwise launch, as before); DSN_LAZY_TAPS=1 / 9 turn the
 # 1x1 / every consumer on for experiments, and the kernels stay bit-exact against the materialised path (tests/test_lazy_gpu.py).
 _LAZY_MAX_TAPS = int(_os.environ.get("DSN_LAZY_TAPS", "0"))
+# Third form (DSN_LAZY_Z=1): the LDS-DMA kernels (conv3x3.hip) hold a block's whole input tile in LDS before the first MFMA, so the
+# transform can be applied ONCE per block there, with the materialised tile stored on the way (dsn_conv2d_fwd_lazy_z) -- no second
+# read of y and 29 fewer launches per DeSeNet-s step.  Measured (profiles/r02g_*): bit-exact, but slower as well, 4.77 -> 5.04 ms per
+# step: each block has to fold the fp64 accumulators of ALL its input channels before it can transform (16 L2 loads + an fp64
+# rsqrt per channel, queued behind the LDS-DMA), then runs the SiLU pass at two resident blocks per CU, once per output-channel
+# tile -- the one-trip 1x1 kernel with 256 input channels went from 10.7 to 33 us, more than the 7 us elementwise launch it replaced
+# (producer-side finalisation was measured in round 1: ~7 us of device-scope round trips at the kernel's tail).  Default 0.
+_LAZY_Z = int(_os.environ.get("DSN_LAZY_Z", "0"))
 
 
 def _lazy_operand(tape, x, taps=1):
-    """(x', lazy descriptor | None): x itself plus the descriptor of its deferred-BatchNorm segments when the convolution kernels
-    can (and should: see _LAZY_MAX_TAPS) apply them while staging x; otherwise a materialised copy of x and None."""
+    """(x', lazy descriptor | None, z | None): x itself plus the descriptor of its deferred-BatchNorm segments when the convolution
+    can apply them while staging x -- with z, a fresh tensor that receives the materialised x on the way -- otherwise a
+    materialised copy of x, None and None."""
     if tape is None:
-        return x, None
+        return x, None, None
     lz = tape.lazy_in(x)
     if lz is None:
-        return x, None
-    if lz is False or taps > max(_LAZY_MAX_TAPS, 1 if getattr(tape, "lazy_force", False) else 0) or not ops.lazy_input_ok(x):
-        return tape.materialize(x), None
-    return x, lz
+        return x, None, None
+    if lz is False or not ops.lazy_input_ok(x):
+        return tape.materialize(x), None, None
+    z = tape.lazy_copy(x)
+    if z is not None:
+        return z, None, None
+    if taps <= max(_LAZY_MAX_TAPS, 1 if getattr(tape, "lazy_force", False) else 0):
+        return x, lz, None
+    if _LAZY_Z:
+        return x, lz, ops.new_act(*x.shape, x.dtype, x.device)
+    return tape.materialize(x), None, None
 
 
 def _defer_ok(bn, out, co, bias, sync) -> bool:
@@ -157,14 +173,18 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     w, bias = packed_fwd(conv, dtype, ci_pad, None)
     plain = skip_bn and act == ACT_NONE and residual is None
     sync = _bn_sync(bn) if train_bn else None
-    x, lz = _lazy_operand(tape, x, k * k)
-    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
+    x, lz, zx = _lazy_operand(tape, x, k * k)
+    # (zx: the convolution below also writes the materialised x there -- that is what the weight gradient reads)
+    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x if zx is None else zx, ci_pad=ci_pad, geom=(k, s, p, d),
+               plain=plain)
     if train_bn and tape is not None and _defer_ok(bn, out, co, bias, sync):
         # deferred path: conv (+ BatchNorm sums in its epilogue) and nothing else when the output may stay raw; otherwise ONE
         # elementwise launch materialises z (+ shortcut).  Saved statistics / running averages: end-of-forward finalisation.
-        defer = lazy_out and residual is None and (_LAZY_MAX_TAPS > 0 or lazy_out == "force")
+        defer = lazy_out and residual is None and (_LAZY_MAX_TAPS > 0 or _LAZY_Z or lazy_out == "force")
         y = out if defer else ops.new_act(n, co, ho, wo, dtype, x.device)
-        acc, _ = ops.conv2d_fwd_acc(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz)
+        acc, _ = ops.conv2d_fwd_acc(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz, z_out=zx)
+        if zx is not None:
+            tape.lazy_register_copy(x, zx)
         stats = torch.empty((4, co), dtype=torch.float32, device=x.device)
         count = n * ho * wo
         if defer:
@@ -172,7 +192,9 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
         else:
             me = _self_lazy(acc, co, 0, 0, co, count, bn, act)
             res, lres = residual, None
-            if residual is not None:
+            if residual is not None and tape.lazy_copy(residual) is not None:
+                res = tape.lazy_copy(residual)          # (an earlier consumer materialised it on the way)
+            elif residual is not None:
                 lres = tape.lazy_in(residual)
                 if lres is False or (lres is not None and not ops.lazy_input_ok(residual)):
                     res, lres = tape.materialize(residual), None
@@ -192,7 +214,7 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
         # BatchNorm statistics come out of the conv epilogue (fp32 accumulators) and are folded in the prologue of the
         # BN + act kernel: conv -> BN -> act is two launches, y is read once
         if lz is not None:
-            x, lz = tape.materialize(x), None
+            x, lz, zx = tape.materialize(x), None, None
             rec["x"] = x
         stats = ops.conv2d_fwd_bnstats(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), bn.weight, bn.bias, bn.running_mean,
                                        bn.running_var, bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps,
@@ -200,7 +222,9 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     else:
         if sync is not None:
             raise NotImplementedError("SyncBatchNorm after a biased or > 1024-channel convolution (not in DeSeNet)")
-        ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz)
+        ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz, z_out=zx)
+        if zx is not None:
+            tape.lazy_register_copy(x, zx)
     if plain:
         pass
     elif skip_bn:
@@ -276,11 +300,14 @@ def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
     co = coa + cb.out_channels
     act = act_code(blk_a.act)
     sync = _bn_sync(ba)
-    x, lz = _lazy_operand(tape, x)
+    x, lz, zx = _lazy_operand(tape, x)
     if _defer_ok(ba, out, co, None, sync) and coa % 8 == 0:
-        lazy_out = bool(lazy_out) and (_LAZY_MAX_TAPS > 0 or lazy_out == "force")
+        lazy_out = bool(lazy_out) and (_LAZY_MAX_TAPS > 0 or _LAZY_Z or lazy_out == "force")
         y = out if lazy_out else ops.new_act(n, co, h, w, x.dtype, x.device)
-        acc, _ = ops.conv2d_fwd_acc(x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), lazy=lz)
+        acc, _ = ops.conv2d_fwd_acc(x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), lazy=lz, z_out=zx)
+        if zx is not None:
+            tape.lazy_register_copy(x, zx)
+            x = zx
         stats = torch.empty((4, co), dtype=torch.float32, device=x.device)
         count = n * h * w
         if lazy_out:
@@ -294,7 +321,7 @@ def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
         sync = None
     else:
         if lz is not None:
-            x = tape.materialize(x)
+            x, zx = tape.materialize(x), None
         y = ops.new_act(n, co, h, w, x.dtype, x.device)
         mom = ba.momentum if ba.momentum is not None else BN_MOMENTUM
         scale, shift, mean, rstd = ops.conv2d_fwd_bnstats(

@@ -245,11 +245,15 @@ static inline void dsn_fill_u32(void* p, uint32_t v, int64_t n_words, hipStream_
 // conv3x3.hip: the halo-tile kernel for 3x3 / stride-1 convolutions (forward and data gradient).  Returns 1 when the layer is not
 // one it takes (nothing launched), 0 when it ran, another status on failure.  finp: BatchNorm accumulators for the epilogue or NULL.
 struct BnAcc;
+// lz + z (forward only): s carries deferred-BatchNorm segments; the kernel applies them once per block in LDS and stores the
+// materialised activation to z.
 int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
-                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream);
+                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
+                         const dsn_tensor* z = nullptr);
 
 int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
-                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream);
+                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
+                        const dsn_tensor* z = nullptr);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

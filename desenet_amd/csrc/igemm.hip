@@ -738,9 +738,20 @@ int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const 
 
 int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual, const dsn_tensor* y,
                   const dsn_conv_params* p, float* stats, int* tiles_m_out, void* stream, const BnAcc* finp = nullptr,
-                  const LazyIn* lz = nullptr) {
+                  const LazyIn* lz = nullptr, const dsn_tensor* z = nullptr) {
     int rc = check_common(x, w, y, p);
     if (rc) return rc;
+    if (z && lz && lz->nseg > 0 && !stats) {
+        // deferred input WITH a destination for the materialised activation: the LDS-DMA kernels transform the tile once per block
+        // in LDS and store z on the way; any other layer materialises z with the elementwise kernel and convolves that
+        rc = dsn_conv3x3_halo_try(x, w, bias, residual, y, p, 0, finp, stream, lz, z);
+        if (rc != 1) return rc;
+        rc = dsn_conv1x1_dma_try(x, w, bias, residual, y, p, 0, finp, stream, lz, z);
+        if (rc != 1) return rc;
+        rc = dsn_lazy_materialize(x, lz, nullptr, nullptr, z, stream);
+        if (rc) return rc;
+        return conv_fwd_impl(z, w, bias, residual, y, p, stats, tiles_m_out, stream, finp, nullptr, nullptr);
+    }
     const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     DSN_CHECK_ARG(ho == y->h && wo == y->w, "conv fwd: output is %dx%d, expected %dx%d", y->h, y->w, ho, wo);
@@ -801,10 +812,12 @@ extern "C" int dsn_conv2d_fwd_bnacc(const dsn_tensor* x, const void* w, const ds
 
 // Convolution whose input carries deferred BatchNorm + activation segments (include/desenet_hip.h: dsn_lazy_in).  acc != NULL:
 // also emit the BatchNorm sums of y (plain convolution only), as dsn_conv2d_fwd_bnacc does.
-extern "C" int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy, const void* w, const float* bias,
-                                   const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc,
-                                   int64_t acc_bytes, void* stream) {
+static int conv2d_fwd_lazy_impl(const dsn_tensor* x, const dsn_lazy_in* lazy, const dsn_tensor* z, const void* w, const float* bias,
+                                const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc,
+                                int64_t acc_bytes, void* stream) {
     DSN_CHECK_ARG(x && y && p, "conv2d_fwd_lazy: null argument");
+    if (z) DSN_CHECK_ARG(tensor_ok(z) && z->dtype == x->dtype && z->n == x->n && z->h == x->h && z->w == x->w && z->c == x->c,
+                         "conv2d_fwd_lazy_z: z must have the shape of x");
     if (lazy) {
         DSN_CHECK_ARG(lazy->nseg >= 0 && lazy->nseg <= DSN_LAZY_MAXSEG, "conv2d_fwd_lazy: %d segments", lazy->nseg);
         for (int i = 0; i < lazy->nseg; ++i) {
@@ -820,9 +833,25 @@ extern "C" int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy,
         DSN_CHECK_ARG(p->act == DSN_ACT_NONE && !p->accumulate && !bias && !residual, "conv2d_fwd_lazy: BatchNorm sums need a plain convolution");
         if (acc_bytes < bn_acc_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "conv2d_fwd_lazy: accumulator buffer too small");
         BnAcc f{(double*)acc, y->c, (double)npix(y)};
-        return conv_fwd_impl(x, w, nullptr, nullptr, y, p, nullptr, nullptr, stream, &f, lazy);
+        return conv_fwd_impl(x, w, nullptr, nullptr, y, p, nullptr, nullptr, stream, &f, lazy, z);
     }
-    return conv_fwd_impl(x, w, bias, residual, y, p, nullptr, nullptr, stream, nullptr, lazy);
+    return conv_fwd_impl(x, w, bias, residual, y, p, nullptr, nullptr, stream, nullptr, lazy, z);
+}
+
+extern "C" int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy, const void* w, const float* bias,
+                                   const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc,
+                                   int64_t acc_bytes, void* stream) {
+    return conv2d_fwd_lazy_impl(x, lazy, nullptr, w, bias, residual, y, p, acc, acc_bytes, stream);
+}
+
+// The same, and z = the materialised input (act(bn(x)) on the deferred segments, x elsewhere) is written as a side effect: by the
+// convolution kernel itself where it stages whole tiles through LDS (3x3 / stride 1 and 1x1 with 64-channel slabs), by one
+// elementwise launch ahead of the convolution otherwise.
+extern "C" int dsn_conv2d_fwd_lazy_z(const dsn_tensor* x, const dsn_lazy_in* lazy, const dsn_tensor* z, const void* w,
+                                     const float* bias, const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p,
+                                     void* acc, int64_t acc_bytes, void* stream) {
+    DSN_CHECK_ARG(z && lazy && lazy->nseg > 0, "conv2d_fwd_lazy_z: needs a deferred input and a destination for z");
+    return conv2d_fwd_lazy_impl(x, lazy, z, w, bias, residual, y, p, acc, acc_bytes, stream);
 }
 
 // Stride-2 3x3 (pad 1) input gradient as ONE stride-1 2x2 convolution over dy with 4*Ci output columns + depth-to-space store:

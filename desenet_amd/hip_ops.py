@@ -139,11 +139,17 @@ def conv_out_hw(h, w, k, stride, pad, dil):
     return ((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
 
 
-def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params, lazy=None):
-    """lazy: dsn_lazy_in describing deferred-BatchNorm segments of x (runtime.Tape.lazy_in) -- applied while x is staged."""
+def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params, lazy=None, z_out=None):
+    """lazy: dsn_lazy_in describing deferred-BatchNorm segments of x (runtime.Tape.lazy_in) -- applied while x is staged.
+    z_out (with lazy): the materialised x is written there on the way (dsn_conv2d_fwd_lazy_z)."""
     L = _lib.lib()
     dx, dy = desc(x, raw=lazy is not None), desc(y)
     dr = desc(residual) if residual is not None else None
+    if lazy is not None and z_out is not None:
+        dz = desc(z_out)
+        _lib.check(L.dsn_conv2d_fwd_lazy_z(C.byref(dx), C.byref(lazy), C.byref(dz), w_packed.data_ptr(), _p(bias), _ref(dr),
+                                           C.byref(dy), C.byref(p), None, 0, stream_ptr()), "conv2d_fwd_lazy_z")
+        return y
     if lazy is not None:
         _lib.check(L.dsn_conv2d_fwd_lazy(C.byref(dx), C.byref(lazy), w_packed.data_ptr(), _p(bias), _ref(dr), C.byref(dy),
                                          C.byref(p), None, 0, stream_ptr()), "conv2d_fwd_lazy")
@@ -158,12 +164,17 @@ def lazy_input_ok(x) -> bool:
     return _vec16(x) and x.shape[1] % 8 == 0 and x.shape[1] <= 1024
 
 
-def conv2d_fwd_acc(x, w_packed, y, p: dsn_conv_params, lazy=None):
+def conv2d_fwd_acc(x, w_packed, y, p: dsn_conv_params, lazy=None, z_out=None):
     """Training forward of a BN'd convolution WITHOUT the BN + act pass: y = conv(x) (x may carry deferred segments) and the
-    per-channel fp64 sums of y in a fresh accumulator slot.  Returns (acc tensor, acc bytes)."""
+    per-channel fp64 sums of y in a fresh accumulator slot.  Returns (acc tensor, acc bytes).  z_out: see conv2d_fwd."""
     L = _lib.lib()
     dx, dy = desc(x, raw=lazy is not None), desc(y)
     acc, nbytes = bn_acc(y.shape[1], y.device)
+    if lazy is not None and z_out is not None:
+        dz = desc(z_out)
+        _lib.check(L.dsn_conv2d_fwd_lazy_z(C.byref(dx), C.byref(lazy), C.byref(dz), w_packed.data_ptr(), None, None,
+                                           C.byref(dy), C.byref(p), acc.data_ptr(), nbytes, stream_ptr()), "conv2d_fwd_lazy_z")
+        return acc, nbytes
     _lib.check(L.dsn_conv2d_fwd_lazy(C.byref(dx), C.byref(lazy) if lazy is not None else None, w_packed.data_ptr(), None, None,
                                      C.byref(dy), C.byref(p), acc.data_ptr(), nbytes, stream_ptr()), "conv2d_fwd_lazy")
     return acc, nbytes

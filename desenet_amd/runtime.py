@@ -191,6 +191,16 @@ class Tape:
             self.lazy_copies[key] = z
         return z
 
+    def lazy_copy(self, x):
+        """The materialised copy of the deferred tensor x made earlier in this forward pass, or None."""
+        return self.lazy_copies.get((self._range(x), False))
+
+    def lazy_register_copy(self, x, z):
+        """z holds act(bn(x)) for the deferred view x (written by a convolution on the way: dsn_conv2d_fwd_lazy_z)."""
+        rng = self._range(x)
+        self.lazy_copies[(rng, False)] = z
+        self.lazy_copies[(rng, True)] = z
+
     def finalize_forward(self):
         """End of the forward pass: ONE launch (per 28 modules) writes every pending BatchNorm's saved statistics and updates its
         running averages (torch_utils.py:164-165)."""

@@ -444,6 +444,14 @@ typedef struct {
 int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy, const void* w_packed, const float* bias,
                         const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc, int64_t acc_bytes,
                         void* stream);
+/* dsn_conv2d_fwd_lazy + z: the materialised input (act(bn(x)) on the deferred segments of `lazy`, x elsewhere; shape of x) is
+ * written to z as a side effect -- by the convolution kernel itself where it stages whole tiles through LDS (3x3 / stride 1 and
+ * 1x1 / stride 1 with whole 128-byte channel slabs: the tile is transformed once per block, in LDS), by one elementwise launch
+ * ahead of the convolution for every other layer.  Replaces the BatchNorm + SiLU pass between two Conv modules
+ * (reference core/models/common.py:38-57: Conv.forward = act(bn(conv(x)))). */
+int dsn_conv2d_fwd_lazy_z(const dsn_tensor* x, const dsn_lazy_in* lazy, const dsn_tensor* z, const void* w_packed,
+                          const float* bias, const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p,
+                          void* acc, int64_t acc_bytes, void* stream);
 int dsn_bn_finalize_multi(const dsn_bn_final* entries_host, int32_t n, void* stream);
 /* dsn_conv2d_wgrad_plan with a deferred-BatchNorm x operand: lx segments carry scale / shift arrays (acc NULL; the backward pass
  * runs after dsn_bn_finalize_multi); the queued kernels apply z = act(x*scale + shift) while staging x.  DSN_EUNSUPPORTED when

@@ -107,6 +107,70 @@ def test_lazy_conv_and_wgrad_equal_the_materialised_path(dtype, k, stride, dil, 
         desenet_amd.set_compute_dtype(torch.float32)
 
 
+ZCASES = [  # k, dil, h, w, co, channel layout of the consumer input (bf16: 64-channel slabs, fp32: 32-channel slabs)
+    (1, 1, 13, 11, 48, [("L", 64)]),
+    (1, 1, 16, 16, 128, [("L", 64), ("L", 64)]),
+    (1, 1, 20, 20, 72, [("L", 64), ("P", 64), ("L", 128)]),
+    (3, 1, 13, 11, 48, [("L", 64)]),
+    (3, 1, 16, 24, 136, [("L", 64), ("L", 64)]),
+    (3, 2, 17, 9, 64, [("P", 64), ("L", 64)]),
+    (3, 3, 12, 12, 64, [("L", 64)]),
+    (3, 1, 9, 9, 40, [("L", 32)]),                  # no whole slab in bf16: elementwise launch + plain convolution inside the entry
+    (5, 1, 9, 9, 40, [("L", 64)]),                  # not a kernel that stages whole tiles: the same fallback
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,dil,h,w,co,layout", ZCASES)
+def test_conv_that_materialises_its_deferred_input_on_the_way(dtype, k, dil, h, w, co, layout):
+    """dsn_conv2d_fwd_lazy_z: the halo-tile / one-trip kernels transform the raw tile once per block in LDS and store z as a side
+    effect.  z must be bit-identical to the elementwise materialisation, and y to the same kernel run on that z."""
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.hip_ops import ACT_NONE, ACT_SILU
+    from desenet_amd.runtime import Tape
+    desenet_amd.set_compute_dtype(dtype)
+    try:
+        n = 3
+        ctot = sum(c for _, c in layout)
+        tape = Tape()
+        buf = ops.new_act(n, ctot + 8, h, w, dtype, "cuda")[:, :ctot]        # (a channel slice: row stride != channels)
+        c0 = 0
+        for j, (kind, c) in enumerate(layout):
+            if kind == "L":
+                _producer(ops, tape, n, 24, c, h, w, dtype, 10 * j + 3, ACT_SILU if j % 2 == 0 else ACT_NONE, buf, c0)
+            else:
+                ops.copy(ops.as_act(_rand((n, c, h, w), dtype, 10 * j + 5)), buf[:, c0:c0 + c])
+            c0 += c
+        lz = tape.lazy_in(buf)
+        z_ref = tape.materialize(buf)
+        wp = ops.pack_weight_fwd(_rand((co, ctot, k, k), torch.float32, 99, 0.2), dtype)
+        pad = dil * (k // 2)
+        p = ops.conv_params(k, 1, pad, dil, ACT_NONE)
+        y_ref = ops.new_act(n, co, h, w, dtype, "cuda")
+        acc_ref, _ = ops.conv2d_fwd_acc(z_ref, wp, y_ref, p)
+        z = ops.new_act(n, ctot + 16, h, w, dtype, "cuda")[:, 8:8 + ctot]
+        z.fill_(7.0)
+        y = ops.new_act(n, co, h, w, dtype, "cuda")
+        acc, _ = ops.conv2d_fwd_acc(buf, wp, y, p, lazy=lz, z_out=z)
+        torch.cuda.synchronize()
+        assert torch.equal(z, z_ref), float((z.float() - z_ref.float()).abs().max())
+        assert torch.equal(y, y_ref), _rel(y, y_ref)
+        assert torch.allclose(acc, acc_ref, rtol=1e-12, atol=0)
+        # with bias / activation / residual in the epilogue (the inference-style entry)
+        bias = torch.rand(co, device="cuda") - 0.5
+        res = ops.as_act(_rand((n, co, h, w), dtype, 17))
+        p2 = ops.conv_params(k, 1, pad, dil, ACT_SILU)
+        y2_ref = ops.conv2d_fwd(z_ref, wp, bias, res, ops.new_act(n, co, h, w, dtype, "cuda"), p2)
+        z2 = ops.new_act(n, ctot, h, w, dtype, "cuda")
+        y2 = ops.conv2d_fwd(buf, wp, bias, res, ops.new_act(n, co, h, w, dtype, "cuda"), p2, lazy=lz, z_out=z2)
+        torch.cuda.synchronize()
+        assert torch.equal(z2, z_ref) and torch.equal(y2, y2_ref)
+        tape.finalize_forward()
+    finally:
+        desenet_amd.set_compute_dtype(torch.float32)
+
+
 def test_finalize_multi_matches_the_per_layer_statistics():
     """dsn_bn_finalize_multi (one launch for all layers) writes what dsn_bn_stats writes per layer: scale, shift, mean, rstd and
     the running averages (momentum 0.03, unbiased variance)."""
