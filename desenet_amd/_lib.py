@@ -55,6 +55,19 @@ class dsn_lazy_in(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("_pad", C.c_int32), ("seg", dsn_lazy_seg * LAZY_MAXSEG)]
 
 
+BNRED_MAXSEG = 2
+
+
+class dsn_bnred_seg(C.Structure):
+    _fields_ = [("c0", C.c_int32), ("c1", C.c_int32), ("ch0", C.c_int32), ("acc_c", C.c_int32), ("act", C.c_int32),
+                ("_pad", C.c_int32), ("y", C.c_void_p), ("yld", C.c_int64), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("acc", C.c_void_p)]
+
+
+class dsn_bnred(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("_pad", C.c_int32), ("seg", dsn_bnred_seg * BNRED_MAXSEG)]
+
+
 class dsn_bn_final(C.Structure):
     _fields_ = [("acc", C.c_void_p), ("acc_c", C.c_int32), ("ch0", C.c_int32), ("n", C.c_int32), ("_pad", C.c_int32),
                 ("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
@@ -74,6 +87,8 @@ PROTOTYPES = {
     "dsn_conv2d_dgrad": (i32, [TP, vp, TP, CP, vp]),
     "dsn_conv2d_dgrad_res": (i32, [TP, vp, TP, CP, TP, vp]),
     "dsn_conv2d_dgrad_s2": (i32, [TP, vp, TP, CP, vp]),
+    "dsn_conv2d_dgrad_bnred": (i32, [TP, vp, TP, CP, TP, vp, vp]),
+    "dsn_conv2d_dgrad_s2_bnred": (i32, [TP, vp, TP, CP, vp, vp]),
     "dsn_conv2d_stats_rows": (i32, [i64]),
     "dsn_conv2d_fwd_stats": (i32, [TP, vp, TP, CP, vp, vp, vp]),
     "dsn_wgrad_job_bytes": (i64, []),
@@ -103,6 +118,7 @@ PROTOTYPES = {
     "dsn_bn_act_fwd": (i32, [TP, vp, vp, i32, TP, TP, vp]),
     "dsn_bn_act_bwd": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, vp]),
     "dsn_bn_act_bwd_reduce": (i32, [TP, TP, vp, vp, vp, vp, i32, vp, i64, vp]),
+    "dsn_bn_act_bwd_reduce_into": (i32, [TP, TP, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
     "dsn_bn_act_bwd_apply": (i32, [TP, TP, vp, vp, vp, vp, i32, TP, vp, vp, i32, vp, i64, f64, f32, vp, vp]),
     "dsn_act_bwd": (i32, [TP, TP, i32, TP, vp]),
     "dsn_focus_s2d": (i32, [vp, i32, i32, i32, i32, TP, vp]),

@@ -173,10 +173,11 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     w, bias = packed_fwd(conv, dtype, ci_pad, None)
     plain = skip_bn and act == ACT_NONE and residual is None
     sync = _bn_sync(bn) if train_bn else None
+    x_in = x
     x, lz, zx = _lazy_operand(tape, x, k * k)
     # (zx: the convolution below also writes the materialised x there -- that is what the weight gradient reads)
-    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x if zx is None else zx, ci_pad=ci_pad, geom=(k, s, p, d),
-               plain=plain)
+    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x if zx is None else zx, x_in=x_in, ci_pad=ci_pad,
+               geom=(k, s, p, d), plain=plain)
     if train_bn and tape is not None and _defer_ok(bn, out, co, bias, sync):
         # deferred path: conv (+ BatchNorm sums in its epilogue) and nothing else when the output may stay raw; otherwise ONE
         # elementwise launch materialises z (+ shortcut).  Saved statistics / running averages: end-of-forward finalisation.
@@ -204,6 +205,7 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
             bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
         rec.update(y=y, scale=stats[0], shift=stats[1], mean=stats[2], rstd=stats[3], frozen=False, sync=None)
         tape.push(rec)
+        tape.bn_register(out, rec)
         return out
     if residual is not None and tape is not None:
         residual = tape.materialize(residual)
@@ -239,6 +241,8 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
         if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
             bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
         rec.update(scale=scale, shift=shift, mean=mean, rstd=rstd, frozen=False, sync=sync)
+        if tape is not None:
+            tape.bn_register(out, rec)
     else:
         # eval-mode BN kept differentiable (running statistics are constants): z = act(y*scale + shift)
         g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_var)
@@ -300,6 +304,7 @@ def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
     co = coa + cb.out_channels
     act = act_code(blk_a.act)
     sync = _bn_sync(ba)
+    x_in = x
     x, lz, zx = _lazy_operand(tape, x)
     if _defer_ok(ba, out, co, None, sync) and coa % 8 == 0:
         lazy_out = bool(lazy_out) and (_LAZY_MAX_TAPS > 0 or _LAZY_Z or lazy_out == "force")
@@ -330,12 +335,63 @@ def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
     for bn in (ba, bb):
         if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
             bn.num_batches_tracked.add_(1)
-    tape.push(dict(pair=(blk_a, blk_b), x=x, y=y, act=act, scale=scale, shift=shift, mean=mean, rstd=rstd, sync=sync))
+    rec = dict(pair=(blk_a, blk_b), x=x, x_in=x_in, y=y, act=act, scale=scale, shift=shift, mean=mean, rstd=rstd, sync=sync)
+    tape.push(rec)
+    tape.bn_register(out, rec)           # (both modules: channel k of `out` is channel k of the merged BatchNorm pass)
     return out
 
 
-def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
-    """Backward of pair_block_fwd: one BN/act backward over the merged tensor, two queued weight-gradient jobs, one dgrad."""
+_BNRED = int(_os.environ.get("DSN_BNRED", "1"))
+
+
+def _bnred_plan(tape, x_in, dx, residual):
+    """The input-gradient launch about to write dx completes dz for the BatchNorm block(s) whose output the view x_in is (the
+    caller vouches for that: fuse_up): (dsn_bnred, marks) so that their backward sums ride in its epilogue, or (None, ()) when the
+    blocks / layouts cannot take it (more than two blocks, SyncBatchNorm, channel ranges that are not whole 16-byte vectors)."""
+    if not _BNRED or tape is None or x_in is None:
+        return None, ()
+    hits = tape.bn_producers(x_in)
+    if not hits or len(hits) > 2:       # DSN_BNRED_MAXSEG
+        return None, ()
+    vec = 4 if dx.dtype == torch.float32 else 8
+    if not ops._vec16(dx) or dx.shape[1] % vec or (residual is not None and not ops._vec16(residual)):
+        return None, ()
+    segs, marks = [], []
+    for c0, c1, prec, k0 in hits:
+        y = prec.get("y")
+        if prec.get("sync") is not None or prec.get("frozen") or y is None or "scale" not in prec or y.dtype != dx.dtype:
+            return None, ()
+        ctot, k1 = y.shape[1], k0 + (c1 - c0)
+        if c0 % vec or c1 % vec or k0 % vec or ctot % vec or not ops._vec16(y) or tuple(y.shape[2:]) != tuple(dx.shape[2:]):
+            return None, ()
+        if any(a < k1 and k0 < b for a, b in prec.get("bnred_cov", ())):
+            return None, ()                 # (somebody already summed these channels: this launch is not what completes them)
+        acc = prec.get("bnred_acc")
+        if acc is None:
+            acc = ops.bn_acc(ctot, y.device)[0]
+        segs.append((c0, c1, y[:, k0:k1], prec["scale"][k0:k1], prec["shift"][k0:k1], prec["mean"][k0:k1], prec["rstd"][k0:k1],
+                     prec["act"], acc, ctot, k0))
+        marks.append((prec, acc, k0, k1))
+    return ops.bnred(segs), marks
+
+
+def _bnred_commit(marks):
+    for prec, acc, k0, k1 in marks:
+        prec["bnred_acc"] = acc
+        prec.setdefault("bnred_cov", []).append((k0, k1))
+
+
+def _bnred_pre(rec):
+    """(accumulator, covered channel ranges) left by the consumers' dgrad launches of THIS backward pass, consumed here (a second
+    backward over the same tape starts from scratch)."""
+    acc = rec.pop("bnred_acc", None)
+    cov = rec.pop("bnred_cov", None)
+    return (acc, cov) if acc is not None else None
+
+
+def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, fuse_up: bool = False):
+    """Backward of pair_block_fwd: one BN/act backward over the merged tensor, two queued weight-gradient jobs, one dgrad.
+    fuse_up: see conv_block_bwd."""
     rec = tape.pop()
     blk_a, blk_b = rec["pair"]
     ca, cb, ba, bb = blk_a.conv, blk_b.conv, blk_a.bn, blk_b.bn
@@ -348,7 +404,7 @@ def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
     dy = ops.new_act(*y.shape, dtype, y.device)
     ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, _grad_slot(ba.weight),
                    _grad_slot(ba.bias), accumulate=True, sync=rec["sync"],
-                   second=(coa, None, None, None, None, _grad_slot(bb.weight), _grad_slot(bb.bias)))
+                   second=(coa, None, None, None, None, _grad_slot(bb.weight), _grad_slot(bb.bias)), pre=_bnred_pre(rec))
     q = tape.wgrad_queue(x.device)
     for conv, sl in ((ca, dy[:, :coa]), (cb, dy[:, coa:])):
         if conv.weight.requires_grad:
@@ -358,7 +414,9 @@ def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True):
     if dx is None:
         dx = ops.new_act(*x.shape, dtype, x.device)
         acc = False
-    ops.conv2d_dgrad(dy, hit[3], dx, ops.conv_params(1, 1, 0, 1, accumulate=acc))
+    red, marks = _bnred_plan(tape, rec.get("x_in"), dx, None) if fuse_up else (None, ())
+    ops.conv2d_dgrad(dy, hit[3], dx, ops.conv_params(1, 1, 0, 1, accumulate=acc), red=red)
+    _bnred_commit(marks)
     return dx
 
 
@@ -392,9 +450,13 @@ def _grad_slot(p):
     return g
 
 
-def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, residual=None):
+def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, residual=None, fuse_up: bool = False):
     """Backward of conv_block_fwd.  dz: gradient of the block output (the caller routes dz to a shortcut itself).
     residual: a tensor of dx's shape added to the input gradient in the dgrad epilogue (a shortcut's gradient).
+    fuse_up: the caller vouches that the dx this call writes (with `residual` and, if acc, what dx already holds) is the COMPLETE
+    gradient of the block's input -- no other contribution follows.  Where that input is the output of BatchNorm block(s) of this
+    tape, their backward sums are then formed in the dgrad epilogue (dsn_conv2d_dgrad_bnred) and their own backward skips its
+    reduction launch.
     A dz whose rows are padded with ZEROS up to a multiple of the vector width (ops.new_act(ldc_align=...), padding cleared by
     its producer -- Detect.bwd does this for its 33-channel heads) takes the 16-byte paths: the weight gradient ignores the
     padding lanes, the input gradient runs over the padded K axis with zero-padded weights."""
@@ -416,7 +478,7 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
         dg = gw if direct else torch.empty_like(rec["scale"])
         db = gb if direct else torch.empty_like(rec["scale"])
         ops.bn_act_bwd(dz, y, rec["scale"], rec["shift"], rec["mean"], rec["rstd"], act, dy, dg, db, accumulate=direct,
-                       sync=rec.get("sync"))
+                       sync=rec.get("sync"), pre=_bnred_pre(rec))
         if not direct:
             tape.add_grad(bn.weight, dg)
             tape.add_grad(bn.bias, db)
@@ -454,10 +516,14 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
         s2 = _cache(conv).get(("dgrad_s2", dtype)) if (k, s, p, d) == (3, 2, 1, 1) else None
         if s2 is not None and s2[0] == _ver(conv.weight) and dy.shape[1] % vec == 0 and dx.shape[1] % vec == 0:
             # stride-2 3x3: one 2x2 stride-1 conv over dy + depth-to-space store (weights packed by the model's WeightBank)
-            ops.conv2d_dgrad_s2(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc))
+            red, marks = _bnred_plan(tape, rec.get("x_in"), dx, None) if (fuse_up and residual is None) else (None, ())
+            ops.conv2d_dgrad_s2(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc), red=red)
         else:
-            ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc), residual=residual)
+            red, marks = _bnred_plan(tape, rec.get("x_in"), dx, residual) if fuse_up else (None, ())
+            ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc), residual=residual,
+                             red=red)
             residual = None
+        _bnred_commit(marks)
     if residual is not None:                       # (paths without a fused epilogue add: not taken by Bottleneck's 1x1)
         ops.copy(residual, dx, accumulate=True)
     return dx

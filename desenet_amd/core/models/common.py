@@ -76,8 +76,9 @@ class Conv(HipModule):
         return conv_block_fwd(x, self.conv, bn, act_code(self.act), self.training, tape, out, residual,
                               q1=not self.fused, ci_pad=ci_pad, lazy_out=lazy_out)
 
-    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, residual=None):
-        return conv_block_bwd(tape, dy, dx, acc, need_dx, residual)
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, residual=None, fuse_up=False):
+        """fuse_up: this call completes the gradient of the block's input (conv_impl.conv_block_bwd)."""
+        return conv_block_bwd(tape, dy, dx, acc, need_dx, residual, fuse_up)
 
     def forward_fuse(self, x):   # reference API (common.py:55-56); the fused state is detected from the missing `bn`
         return self.forward(x)
@@ -97,10 +98,10 @@ class Bottleneck(HipModule):
         # the shortcut is added by the pass that materialises z (a deferred x is transformed there as well)
         return self.cv2.fwd(t, tape, out, residual=x if self.add else None, lazy_out=lazy_out and not self.add)
 
-    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
-        dt = self.cv2.bwd(tape, dy)
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
+        dt = self.cv2.bwd(tape, dy, fuse_up=True)               # (cv1's output has no other consumer: dt is complete)
         # shortcut: d x = dy + d cv1 -- dy rides in the epilogue of cv1's input gradient (no copy / add pass)
-        return self.cv1.bwd(tape, dt, dx, acc, need_dx, residual=dy if (self.add and need_dx) else None)
+        return self.cv1.bwd(tape, dt, dx, acc, need_dx, residual=dy if (self.add and need_dx) else None, fuse_up=fuse_up)
 
 
 class C3(HipModule):
@@ -144,25 +145,28 @@ class C3(HipModule):
             tape.push("c3-plain")
         return z
 
-    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
+        """Inside the block every intermediate has exactly one consumer, so each input-gradient launch completes the gradient of its
+        producer(s) and carries their BatchNorm backward sums (fuse_up=True); the block's own input gradient does when the caller
+        says so."""
         c_ = self.cv1.conv.out_channels
         if tape.pop() == "c3-merged":
             # gradient buffer [d m(..) | d cv2 | d cv1]: cv3's dgrad fills the first two thirds, the chain's first block the
             # last one; the merged block reads the last two thirds
             n, _, h, w = dy.shape
             d3 = ops.new_act(n, 3 * c_, h, w, dy.dtype, dy.device)
-            self.cv3.bwd(tape, dy, d3[:, :2 * c_], False)
+            self.cv3.bwd(tape, dy, d3[:, :2 * c_], False, fuse_up=True)
             da = d3[:, :c_]
             blocks = list(self.m)
             for i, b in enumerate(reversed(blocks)):
-                da = b.bwd(tape, da, d3[:, 2 * c_:], False) if i == len(blocks) - 1 else b.bwd(tape, da)
-            return pair_block_bwd(tape, d3[:, c_:], dx, acc, need_dx)
-        dcat = self.cv3.bwd(tape, dy)
+                da = b.bwd(tape, da, d3[:, 2 * c_:], False, fuse_up=True) if i == len(blocks) - 1 else b.bwd(tape, da, fuse_up=True)
+            return pair_block_bwd(tape, d3[:, c_:], dx, acc, need_dx, fuse_up=fuse_up)
+        dcat = self.cv3.bwd(tape, dy, fuse_up=True)
         dx = self.cv2.bwd(tape, dcat[:, c_:], dx, acc, need_dx)
         da = dcat[:, :c_]
         for b in reversed(list(self.m)):
-            da = b.bwd(tape, da)
-        return self.cv1.bwd(tape, da, dx, True, need_dx)
+            da = b.bwd(tape, da, fuse_up=True)
+        return self.cv1.bwd(tape, da, dx, True, need_dx, fuse_up=fuse_up)
 
 
 class SPP(HipModule):
@@ -186,14 +190,14 @@ class SPP(HipModule):
             tape.push(idxs)
         return self.cv2.fwd(cat, tape, out, lazy_out=lazy_out)
 
-    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
         c_ = self.cv1.conv.out_channels
-        dcat = self.cv2.bwd(tape, dy)
+        dcat = self.cv2.bwd(tape, dy)          # (cv1's output also feeds the pools: its gradient is completed by the scatter below)
         idxs = tape.pop()
         d0 = dcat[:, :c_]
         ops.maxpool_s1_bwd_multi([dcat[:, i * c_:(i + 1) * c_] for i in range(1, len(self.m) + 1)], idxs,
                                  [int(mp.kernel_size) for mp in self.m], d0, accumulate=True)      # one pass for the three pools
-        return self.cv1.bwd(tape, d0, dx, acc, need_dx)
+        return self.cv1.bwd(tape, d0, dx, acc, need_dx, fuse_up=fuse_up)
 
 
 class Focus(HipModule):

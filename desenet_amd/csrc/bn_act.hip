@@ -678,6 +678,27 @@ extern "C" int dsn_bn_act_bwd_reduce(const dsn_tensor* dz, const dsn_tensor* y, 
     return DSN_OK;
 }
 
+// The same sums for a channel SLICE of a block (dz, y: the slice's views; scale .. rstd: the slice's parameters), added at channel
+// ch0 of a wider accumulator ([DSN_BN_NREP][2][acc_c] doubles): the rest of the block's channels got theirs in the epilogue of
+// the input-gradient convolution that completed their dz (dsn_conv2d_dgrad_bnred).
+extern "C" int dsn_bn_act_bwd_reduce_into(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                                          const float* mean, const float* rstd, int32_t act, void* acc, int32_t acc_c, int32_t ch0,
+                                          void* stream) {
+    DSN_CHECK_ARG(tensor_ok(dz) && tensor_ok(y) && same_shape(dz, y), "bn_act_bwd_reduce_into: invalid tensors");
+    DSN_CHECK_ARG(scale && shift && mean && rstd && acc && ch0 >= 0 && acc_c >= ch0 + y->c, "bn_act_bwd_reduce_into: bad argument");
+    DSN_CHECK_ARG(y->c <= PRO_MAXC, "bn_act_bwd_reduce_into: at most %d channels", PRO_MAXC);
+    const int64_t P = npix(y);
+    hipStream_t st = (hipStream_t)stream;
+    const bool v = vec_ok(y) && vec_ok(dz);
+    const double esz = y->dtype == DSN_F32 ? 4.0 : 2.0;
+    BnParams bp{scale, shift, mean, rstd, nullptr, act, y->c};
+    BnAcc f{(double*)acc + ch0, acc_c, (double)P};      // (replica stride and the second sum's offset follow acc_c)
+    ProfScope prof(KID_BN_BWD_REDUCE, 0.0, 2.0 * P * y->c * esz, st);
+    DSN_DISPATCH_DTYPE(y->dtype, T, (launch_reduce<T, true, BwdRedF>(v, y, dz, f, st, bp)));
+    DSN_LAUNCH_CHECK("bn_act_bwd reduce (slice)");
+    return DSN_OK;
+}
+
 extern "C" int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                                     const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                                     float* dbeta, int32_t accumulate, const void* workspace, int64_t workspace_bytes,

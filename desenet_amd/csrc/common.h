@@ -223,6 +223,96 @@ template <> __device__ __forceinline__ u32x4 lazy_apply<bf16_t>(u32x4 v, const f
 }
 #endif
 
+// ---- BatchNorm backward sums in a dgrad epilogue (include/desenet_hip.h: dsn_bnred) -------------------------------------------------
+// Every thread of the vectorised tile store owns ONE channel vector (256 % vectors-per-row == 0) over several rows: it keeps the two
+// partial sums of its VEC channels in registers while it stores, then the block folds them (lanes of equal channel vector by
+// shuffles, the four waves through LDS) and adds them to the producer's fp64 accumulators -- the same accumulators, replica
+// scheme and consumer (ew_prologue mode 1) as the stand-alone reduction.
+typedef dsn_bnred BnRed;
+#if defined(__HIPCC__)
+template <typename T, int VEC, int NIT> struct BnRedLane {
+    const T* yp;
+    int64_t yld;
+    float sc[VEC], sh[VEC], mu[VEC], rs[VEC], q0[VEC], q1[VEC];
+    u32x4 yv[NIT];          // y at the NIT vectors this thread stores: fetched BEFORE the tile is staged, consumed after its stores
+    int act;
+    bool on;
+    __device__ __forceinline__ void init(const BnRed& br, int ch) {       // ch: first channel of this thread's vector
+        on = false;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) q0[k] = q1[k] = 0.f;
+        for (int s = 0; s < br.nseg; ++s) {
+            const dsn_bnred_seg& g = br.seg[s];
+            if (ch >= g.c0 && ch < g.c1) {
+                on = true;
+                const int k0 = ch - g.c0;
+                yp = (const T*)g.y + k0;
+                yld = g.yld;
+                act = g.act;
+#pragma unroll
+                for (int k = 0; k < VEC; k += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(g.scale + k0 + k), b = *reinterpret_cast<const f32x4*>(g.shift + k0 + k);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(g.mean + k0 + k), d = *reinterpret_cast<const f32x4*>(g.rstd + k0 + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sc[k + e] = a[e]; sh[k + e] = b[e]; mu[k + e] = c[e]; rs[k + e] = d[e]; }
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void prefetch(int it, int64_t row) {      // row < 0: this vector is not stored
+        if (on && row >= 0) yv[it] = *reinterpret_cast<const u32x4*>(yp + row * yld);
+    }
+    // outv: the values just stored (rounded to T -- what the apply pass will read as dz)
+    __device__ __forceinline__ void add(int it, const T (&outv)[VEC]) {
+        if (!on) return;
+        T yl[VEC];
+        *reinterpret_cast<u32x4*>(yl) = yv[it];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float y = to_f32<T>(yl[k]);
+            const float gk = to_f32<T>(outv[k]) * act_grad(y * sc[k] + sh[k], act);
+            q0[k] += gk;
+            q1[k] += gk * ((y - mu[k]) * rs[k]);
+        }
+    }
+    // red: >= 8 * VPR * VEC floats of LDS nobody else is using; n0: first GEMM column of the tile; ncol: GEMM columns;
+    // chmod > 0: GEMM column -> channel is col % chmod (depth-to-space store of the stride-2 dgrad)
+    template <int VPR> __device__ __forceinline__ void finish(const BnRed& br, float* red, int rep, int n0, int ncol, int chmod) {
+        constexpr int BNW = VPR * VEC;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = VPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                q0[k] += __shfl_xor(q0[k], o);
+                q1[k] += __shfl_xor(q1[k], o);
+            }
+        }
+        if (lane < VPR) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                red[(wave * BNW + lane * VEC + k) * 2] = q0[k];
+                red[(wave * BNW + lane * VEC + k) * 2 + 1] = q1[k];
+            }
+        }
+        __syncthreads();
+        if (tid < BNW && n0 + tid < ncol) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s0 += red[(w * BNW + tid) * 2];
+                s1 += red[(w * BNW + tid) * 2 + 1];
+            }
+            const int ch = chmod > 0 ? (n0 + tid) % chmod : n0 + tid;
+            for (int s = 0; s < br.nseg; ++s) {
+                const dsn_bnred_seg& g = br.seg[s];
+                if (ch >= g.c0 && ch < g.c1) bn_acc_add(BnAcc{(double*)g.acc, g.acc_c, 0.0}, rep, g.ch0 + ch - g.c0, s0, s1);
+            }
+        }
+    }
+};
+#endif
+
 #if defined(__HIPCC__)
 // 32-bit fill as a KERNEL.  hipMemsetAsync nodes captured into a hipGraph were observed (ROCm 7.2, gfx950) not to take effect
 // reliably on replay for small, 4-byte-aligned ranges inside a larger workspace (stale contents -> garbage indices), so the
@@ -249,11 +339,11 @@ struct BnAcc;
 // materialised activation to z.
 int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                          const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
-                         const dsn_tensor* z = nullptr);
+                         const dsn_tensor* z = nullptr, const dsn_bnred* br = nullptr);
 
 int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
-                        const dsn_tensor* z = nullptr);
+                        const dsn_tensor* z = nullptr, const dsn_bnred* br = nullptr);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

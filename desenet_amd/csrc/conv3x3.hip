@@ -77,7 +77,7 @@ template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, 
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                            const float* __restrict__ bias, const T* __restrict__ res,
                                                            T* __restrict__ dst, const BnAcc fin, const HGeom g, const LazyIn lz,
-                                                           T* __restrict__ zout, int64_t zld) {
+                                                           T* __restrict__ zout, int64_t zld, const BnRed br) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static_assert(BM == TH * TW, "the M tile is the TH x TW patch");
@@ -259,6 +259,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     __syncthreads();
 
     // ---- epilogue: act(acc + bias) staged as fp32 [BM][BN + CPAD] (row r = patch pixel (r / TW, r % TW)) ------------------------
+    constexpr int VPR = BN / VEC;
+    constexpr int NIT = (BM * VPR + 255) / 256;
+    const int vh = (g.H - y0 < TH) ? g.H - y0 : TH, vw = (g.W - x0 < TW) ? g.W - x0 : TW;     // valid part of the patch
+    BnRedLane<T, VEC, NIT> bl;                      // (dgrad that completes dz of a BatchNorm block: common.h)
+    if (br.nseg) {
+        bl.init(br, n0 + (tid % VPR) * VEC);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, rl = idx / VPR, ty = rl / TW, tx = rl - ty * TW;
+            const bool ok = idx < BM * VPR && ty < vh && tx < vw && n0 + (idx - rl * VPR) * VEC < g.Cd;
+            bl.prefetch(it, ok ? ((int64_t)n * g.H + y0 + ty) * g.W + x0 + tx : -1);
+        }
+    }
     float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -274,7 +287,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             }
     }
     __syncthreads();
-    const int vh = (g.H - y0 < TH) ? g.H - y0 : TH, vw = (g.W - x0 < TW) ? g.W - x0 : TW;     // valid part of the patch
     if (fin.acc) {
         float* red = sC + BM * LDC;
         constexpr int TYS = 256 / BN > 0 ? 256 / BN : 1;
@@ -302,8 +314,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             bn_acc_add(fin, tmi, n0 + tid, t0, t1);
         }
     }
-    constexpr int VPR = BN / VEC;
-    for (int idx = tid; idx < BM * VPR; idx += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx >= BM * VPR) break;
         const int rl = idx / VPR, cv = idx - rl * VPR;
         const int col = n0 + cv * VEC;
         const int ty = rl / TW, tx = rl - ty * TW;
@@ -332,6 +346,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(vals[e]);
         *reinterpret_cast<u32x4*>(o) = *reinterpret_cast<u32x4*>(outv);
+        if (br.nseg) bl.add(it, outv);
+    }
+    if (br.nseg) {
+        __syncthreads();
+        bl.template finish<VPR>(br, sC, tmi, n0, g.Cd, 0);
     }
 }
 
@@ -339,6 +358,7 @@ struct LzArgs {                    // deferred-BatchNorm input of a launch: segm
     const LazyIn* lz;
     void* zout;
     int64_t zld;
+    const BnRed* br;               // dgrad: BatchNorm backward sums of the block(s) whose dz this launch completes (or NULL)
 };
 
 template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, bool MULTI, bool LZ>
@@ -367,7 +387,7 @@ int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const ds
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.flip ? 1 : 0), 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs,
                    elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,
-                       (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld);
+                       (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld, la.br ? *la.br : BnRed{});
     DSN_LAUNCH_CHECK("conv3x3 (halo tile)");
     return DSN_OK;
 }
@@ -386,7 +406,7 @@ template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool LZ = false>
 __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                           const float* __restrict__ bias, const T* __restrict__ res,
                                                           T* __restrict__ dst, const BnAcc fin, const HGeom g, const LazyIn lz,
-                                                          T* __restrict__ zout, int64_t zld) {
+                                                          T* __restrict__ zout, int64_t zld, const BnRed br) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static_assert(BM % 32 == 0 && BN % 32 == 0, "stages are filled 32 rows per pass");
@@ -508,6 +528,19 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
     }
     __syncthreads();
     // ---- epilogue (as igemm.hip): act(acc + bias) staged as fp32, BatchNorm partial sums, 16-byte stores ------------------------
+    constexpr int VPR = BN / VEC;
+    constexpr int NIT = (BM * VPR + 255) / 256;
+    const int rows = (M - m0 < BM) ? (int)(M - m0) : BM;
+    BnRedLane<T, VEC, NIT> bl;                      // (dgrad that completes dz of a BatchNorm block: common.h)
+    if (br.nseg) {
+        bl.init(br, n0 + (tid % VPR) * VEC);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, rl = idx / VPR;
+            const bool ok = idx < BM * VPR && rl < rows && n0 + (idx - rl * VPR) * VEC < g.Cd;
+            bl.prefetch(it, ok ? m0 + rl : -1);
+        }
+    }
     float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -523,7 +556,6 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
             }
     }
     __syncthreads();
-    const int rows = (M - m0 < BM) ? (int)(M - m0) : BM;
     if (fin.acc) {
         float* red = sC + BM * LDC;
         constexpr int TYS = 256 / BN > 0 ? 256 / BN : 1;
@@ -549,8 +581,10 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
             bn_acc_add(fin, tm, n0 + tid, t0, t1);
         }
     }
-    constexpr int VPR = BN / VEC;
-    for (int idx = tid; idx < BM * VPR; idx += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx >= BM * VPR) break;
         const int rl = idx / VPR, cv = idx - rl * VPR;
         const int col = n0 + cv * VEC;
         if (rl >= rows || col >= g.Cd) continue;
@@ -578,6 +612,11 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(vals[e]);
         *reinterpret_cast<u32x4*>(o) = *reinterpret_cast<u32x4*>(outv);
+        if (br.nseg) bl.add(it, outv);
+    }
+    if (br.nseg) {
+        __syncthreads();
+        bl.template finish<VPR>(br, sC, tm, n0, g.Cd, 0);
     }
 }
 
@@ -601,7 +640,7 @@ int launch_1x1(const dsn_tensor* s, const void* w, const float* bias, const dsn_
     constexpr int CFG = (BM == 64 && BN == 64) ? 2 : 5;
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (is_dgrad ? 1 : 0), 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,
-                       (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld);
+                       (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld, la.br ? *la.br : BnRed{});
     DSN_LAUNCH_CHECK("conv1x1 (one-trip LDS-DMA)");
     return DSN_OK;
 }
@@ -652,7 +691,7 @@ static bool lz_ok(const dsn_tensor* s, const LazyIn* lz, const dsn_tensor* z, in
 
 int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                          const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const LazyIn* lz,
-                         const dsn_tensor* z) {
+                         const dsn_tensor* z, const BnRed* br) {
     static const int mode = [] { const char* e = getenv("DSN_HALO"); return e ? atoi(e) : 1; }();       // 0: never
     if (!mode) return 1;
     if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->dil < 1 || p->dil > 3) return 1;
@@ -675,7 +714,7 @@ int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, 
     g.nslab = s->c / kc;
     if (lz && lz->nseg <= 0) lz = nullptr;
     if (lz && (is_dgrad || !lz_ok(s, lz, z, vec, es))) return 1;
-    const LzArgs la{lz, lz ? z->ptr : nullptr, lz ? z->ldc : 0};
+    const LzArgs la{lz, lz ? z->ptr : nullptr, lz ? z->ldc : 0, (br && br->nseg > 0) ? br : nullptr};
     if (lz) g.z_bytes = (uint32_t)(((npix(z) - 1) * z->ldc + z->c) * es);
     BnAcc fin{};
     if (finp) fin = *finp;
@@ -701,7 +740,7 @@ int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, 
 // The same for 1x1 / stride-1 layers with at most four 128-byte channel slabs (conv1x1_dma_kernel).
 int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const LazyIn* lz,
-                        const dsn_tensor* z) {
+                        const dsn_tensor* z, const BnRed* br) {
     static const int mode = [] { const char* e = getenv("DSN_DMA1X1"); return e ? atoi(e) : 1; }();       // 0: never
     if (!mode) return 1;
     if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0) return 1;
@@ -720,7 +759,7 @@ int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, c
     g.nslab = s->c / kc;
     if (lz && lz->nseg <= 0) lz = nullptr;
     if (lz && (is_dgrad || !lz_ok(s, lz, z, vec, es))) return 1;
-    const LzArgs la{lz, lz ? z->ptr : nullptr, lz ? z->ldc : 0};
+    const LzArgs la{lz, lz ? z->ptr : nullptr, lz ? z->ldc : 0, (br && br->nseg > 0) ? br : nullptr};
     if (lz) g.z_bytes = (uint32_t)(((npix(z) - 1) * z->ldc + z->c) * es);
     BnAcc fin{};
     if (finp) fin = *finp;

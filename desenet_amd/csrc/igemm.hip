@@ -106,7 +106,7 @@ template <typename T, int MI, int NI, int WGM, int WGN, int LD, bool PAR, bool L
 __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : MI * NI <= 8 ? 3 : 2)) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
                                                     T* __restrict__ dst, float* __restrict__ stats, const BnAcc fin, const Geom g,
-                                                    const LazyIn lz) {
+                                                    const LazyIn lz, const BnRed br) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     static_assert(!LAZY || (LD >= 1 && !PAR), "lazy inputs ride on the 16-byte staging paths");
     static_assert(GL == 0 || (LD >= 1 && !PAR && !LAZY && GL >= 3), "LDS-DMA staging: vector paths, plain inputs, >= 3 stages");
@@ -484,6 +484,40 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
 
     // ---- epilogue: stage act(acc + bias) as fp32 [BM][BN + CPAD] ------------------------------------------------
     constexpr int LDC = BN + CPAD;
+    constexpr int VPR = BN / VEC;                   // vectors per tile row
+    constexpr int NIT = (BM * VPR + 255) / 256;     // vectors per thread in the vectorised tile store
+    // vector idx of the tile -> destination (row, first channel); false: nothing is stored there
+    auto dest = [&](int idx, int& row, int& col) -> bool {
+        const int rl = idx / VPR, cv = idx - rl * VPR;
+        col = n0 + cv * VEC;
+        row = m0 + rl;
+        if (PAR) {
+            int y, x, n;
+            if (!dst_pixel(rl, y, x, n)) return false;
+            row = (n * g.Hd + y) * g.Wd + x;
+        }
+        if (row >= g.M || col >= g.Cd) return false;
+        if (g.d2s_c > 0) {
+            const int cls = col / g.d2s_c;
+            col -= cls * g.d2s_c;
+            const int x = row % g.Wd, t = row / g.Wd;
+            const int Y = 2 * (t % g.Hd) + (cls >> 1), X = 2 * x + (cls & 1);
+            if (Y >= g.Hout || X >= g.Wout) return false;
+            row = ((t / g.Hd) * g.Hout + Y) * g.Wout + X;
+        }
+        return true;
+    };
+    BnRedLane<T, VEC, NIT> bl;                      // (dgrad that completes dz of a BatchNorm block: its backward sums ride here)
+    if (br.nseg) {                                  // (host: only with the vectorised store)
+        const int c = n0 + (tid % VPR) * VEC;
+        bl.init(br, g.d2s_c > 0 ? c % g.d2s_c : c);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int row, col;
+            const bool ok = tid + it * 256 < BM * VPR && dest(tid + it * 256, row, col);
+            bl.prefetch(it, ok ? row : -1);
+        }
+    }
     float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -537,25 +571,13 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
     const bool vst = (g.Cd % VEC == 0) && (g.dld % VEC == 0) && (((uintptr_t)dst) % 16 == 0) &&
                      (!res || ((g.rld % VEC == 0) && (((uintptr_t)res) % 16 == 0)));
     if (vst) {
-        constexpr int VPR = BN / VEC;               // vectors per tile row
-        for (int idx = tid; idx < BM * VPR; idx += 256) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx >= BM * VPR) break;
             const int rl = idx / VPR, cv = idx - rl * VPR;
-            int col = n0 + cv * VEC;
-            int row = m0 + rl;
-            if (PAR) {
-                int y, x, n;
-                if (!dst_pixel(rl, y, x, n)) continue;
-                row = (n * g.Hd + y) * g.Wd + x;
-            }
-            if (row >= g.M || col >= g.Cd) continue;
-            if (g.d2s_c > 0) {
-                const int cls = col / g.d2s_c;
-                col -= cls * g.d2s_c;
-                const int x = row % g.Wd, t = row / g.Wd;
-                const int Y = 2 * (t % g.Hd) + (cls >> 1), X = 2 * x + (cls & 1);
-                if (Y >= g.Hout || X >= g.Wout) continue;
-                row = ((t / g.Hd) * g.Hout + Y) * g.Wout + X;
-            }
+            int row, col;
+            if (!dest(idx, row, col)) continue;
             float vals[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; e += 4) {
@@ -579,6 +601,11 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
 #pragma unroll
             for (int e = 0; e < VEC; ++e) outv[e] = from_f32<T>(vals[e]);
             *reinterpret_cast<u32x4*>(o) = *reinterpret_cast<u32x4*>(outv);
+            if (br.nseg) bl.add(it, outv);
+        }
+        if (br.nseg) {
+            __syncthreads();                        // (the staged tile is no longer needed: its LDS takes the partial sums)
+            bl.template finish<VPR>(br, sC, tm, n0, g.Cd, g.d2s_c);
         }
     } else {
         for (int idx = tid; idx < BM * BN; idx += 256) {
@@ -602,7 +629,11 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
 
 template <typename T, int MI, int NI, int WGM, int WGN>
 int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, float* stats, const BnAcc& fin, Geom g,
-               bool vec, hipStream_t st, int* tiles_m_out, const LazyIn* lzp = nullptr) {
+               bool vec, hipStream_t st, int* tiles_m_out, const LazyIn* lzp = nullptr, const BnRed* brp = nullptr) {
+    const BnRed br = brp ? *brp : BnRed{};
+    if (br.nseg > 0 && !(vec && g.Cd % Mma<T>::VEC == 0 && g.dld % Mma<T>::VEC == 0 && ((uintptr_t)dst) % 16 == 0 &&
+                         (!res || (g.rld % Mma<T>::VEC == 0 && ((uintptr_t)res) % 16 == 0))))
+        DSN_FAIL(DSN_EUNSUPPORTED, "conv dgrad with BatchNorm sums: the layer cannot take the vectorised store");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64 && BN == 64) ? 2
                         : (BM == 128 && BN == 32) ? 3 : (BM == 64 && BN == 16) ? 4 : (BM == 32 && BN == 64) ? 5 : 6;
@@ -661,8 +692,8 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
         const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
         const bool want = gl_env >= 0 ? gl_env == 3 : (blocks <= 448 && g.Ktot * (int)sizeof(T) >= 512);
         if (!lazy && !par && vec && want) {
-            if (uni) hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
-            else hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
+            if (uni) hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
+            else hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
             DSN_LAUNCH_CHECK("igemm (LDS-DMA)");
             return DSN_OK;
         }
@@ -673,24 +704,24 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
                                        "(channels %d, pixel stride %lld)", g.Cs, (long long)g.sld);
         const size_t dyn = ((size_t)g.Cs * 8 + (size_t)g.Cs / 8 + 15) / 16 * 16;
         if (uni)
-            hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, true>), grid, block, dyn, st, src, w, bias, res, dst, stats, fin, g, lz);
+            hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, true>), grid, block, dyn, st, src, w, bias, res, dst, stats, fin, g, lz, br);
         else
-            hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, true>), grid, block, dyn, st, src, w, bias, res, dst, stats, fin, g, lz);
+            hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, true>), grid, block, dyn, st, src, w, bias, res, dst, stats, fin, g, lz, br);
     } else if (par)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
     else if (uni)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
     else if (vec)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 0, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 0, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
     DSN_LAUNCH_CHECK("igemm");
     return DSN_OK;
 }
 
 template <typename T>
 int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, float* stats,
-           const BnAcc& fin, Geom g, hipStream_t st, int* tiles_m_out, const LazyIn* lz = nullptr) {
+           const BnAcc& fin, Geom g, hipStream_t st, int* tiles_m_out, const LazyIn* lz = nullptr, const BnRed* br = nullptr) {
     constexpr int VEC = Mma<T>::VEC;
     const T* src = (const T*)s->ptr;
     const T* res = r ? (const T*)r->ptr : nullptr;
@@ -701,30 +732,30 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     // grid still covers the 256 CUs.
     static const int force = [] { const char* e = getenv("DSN_IGEMM_CFG"); return e ? atoi(e) : -1; }();    // tuning knob
     switch (force) {
-        case 0: return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        case 1: return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        case 2: return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        case 3: return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        case 4: return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        case 5: return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        case 6: return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
+        case 0: return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 1: return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 2: return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 3: return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 4: return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 5: return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 6: return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
         default: break;
     }
     // Tile choice, from tools/sweep_igemm.sh on the DeSeNet-s layer shapes (batch 8): these layers are latency-bound, not
     // MFMA-bound, so SMALL tiles win almost everywhere (more blocks per CU hide the load -> LDS -> MFMA round trips);
     // only the few large GEMMs (FFM 3x3: 1600 tiles x K 2304) amortise a 128x128 tile.
     const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.Cd + 63) / 64);
-    if (g.Cd <= 16) return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
+    if (g.Cd <= 16) return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
     if (g.Cd <= 32) {
         if (g.M >= 400000)      // Focus conv / stem dgrad: 128 pixels x 32 channels
-            return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);
-        return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);      // 64x32
+            return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 64x32
     }
     if (tiles64 >= 1536 && g.Ktot >= 1024 && g.Cd >= 128)
-        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);      // 128x128
+        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 128x128
     if (tiles64 < 256 || (tiles64 <= 400 && g.Ktot <= 512))      // (short-K layers on 40x40 / 20x20 maps: measured 5.0 vs 5.6 us)
-        return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);      // 32x64
-    return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz);          // 64x64
+        return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 32x64
+    return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);          // 64x64
 }
 
 int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const dsn_conv_params* p) {
@@ -860,10 +891,32 @@ extern "C" int dsn_conv2d_fwd_lazy_z(const dsn_tensor* x, const dsn_lazy_in* laz
 // (dsn_pack_desc.out_dgrad_s2).  Versus the parity-class form: every block runs the full 4-tap K loop (no 1-chunk tiles),
 // M is the dy grid (4x fewer, 4x wider tiles) and each (n, y) writes two FULL destination rows (2x+px adjacent) instead of
 // every other pixel.  16/9 of the MACs -- irrelevant, these layers are latency/traffic-bound.
-extern "C" int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
-                                   void* stream) {
+namespace {
+int bnred_check(const dsn_bnred* br, const dsn_tensor* dx) {
+    if (!br) return DSN_OK;
+    const int vec = dx->dtype == DSN_F32 ? 4 : 8;
+    DSN_CHECK_ARG(br->nseg >= 0 && br->nseg <= DSN_BNRED_MAXSEG, "conv dgrad with BatchNorm sums: %d segments", br->nseg);
+    for (int i = 0; i < br->nseg; ++i) {
+        const dsn_bnred_seg& s = br->seg[i];
+        DSN_CHECK_ARG(s.c0 >= 0 && s.c1 > s.c0 && s.c1 <= dx->c, "conv dgrad with BatchNorm sums: segment %d covers [%d, %d) of %d channels",
+                      i, s.c0, s.c1, dx->c);
+        DSN_CHECK_ARG(s.y && s.scale && s.shift && s.mean && s.rstd && s.acc && s.acc_c >= s.ch0 + (s.c1 - s.c0) && s.ch0 >= 0,
+                      "conv dgrad with BatchNorm sums: null / short operand in segment %d", i);
+        if (s.c0 % vec || s.c1 % vec || s.yld % vec || (uintptr_t)s.y % 16 || (uintptr_t)s.scale % 16 || (uintptr_t)s.shift % 16 ||
+            (uintptr_t)s.mean % 16 || (uintptr_t)s.rstd % 16)
+            DSN_FAIL(DSN_EUNSUPPORTED, "conv dgrad with BatchNorm sums: segment %d is not made of 16-byte channel vectors", i);
+        for (int j = 0; j < i; ++j)
+            DSN_CHECK_ARG(s.c0 >= br->seg[j].c1 || s.c1 <= br->seg[j].c0, "conv dgrad with BatchNorm sums: segments %d and %d overlap", j, i);
+    }
+    return DSN_OK;
+}
+}  // namespace
+
+static int conv_dgrad_s2_impl(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
+                              const dsn_bnred* br, void* stream) {
     int rc = check_common(dy, w_s2, dx, p);
     if (rc) return rc;
+    if ((rc = bnred_check(br, dx))) return rc;
     DSN_CHECK_ARG(p->kh == 3 && p->kw == 3 && p->stride == 2 && p->pad == 1 && p->dil == 1,
                   "conv dgrad_s2: 3x3 / stride 2 / pad 1 only");
     const int ho = (dx->h + 2 - 3) / 2 + 1, wo = (dx->w + 2 - 3) / 2 + 1;
@@ -880,15 +933,21 @@ extern "C" int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
     g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
     if (dy->dtype == DSN_F32)
-        return launch<float>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
-    return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+        return launch<float>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
+    return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
+}
+
+extern "C" int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
+                                   void* stream) {
+    return conv_dgrad_s2_impl(dy, w_s2, dx, p, nullptr, stream);
 }
 
 namespace {
 int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
-                    const dsn_tensor* residual, void* stream) {
+                    const dsn_tensor* residual, void* stream, const dsn_bnred* br = nullptr) {
     int rc = check_common(dy, w, dx, p);
     if (rc) return rc;
+    if ((rc = bnred_check(br, dx))) return rc;
     const int ho = (dx->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int wo = (dx->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     DSN_CHECK_ARG(ho == dy->h && wo == dy->w, "conv dgrad: dy is %dx%d, expected %dx%d", dy->h, dy->w, ho, wo);
@@ -896,9 +955,9 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
         DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == dx->dtype && residual->n == dx->n && residual->h == dx->h &&
                           residual->w == dx->w && residual->c == dx->c && p->stride == 1,
                       "conv dgrad: residual must have dx's shape (stride-1 convolutions only)");
-    rc = dsn_conv3x3_halo_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream);
+    rc = dsn_conv3x3_halo_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, nullptr, nullptr, br);
     if (rc != 1) return rc;
-    rc = dsn_conv1x1_dma_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream);
+    rc = dsn_conv1x1_dma_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, nullptr, nullptr, br);
     if (rc != 1) return rc;
     Geom g{};
     g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;
@@ -908,10 +967,24 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = residual ? residual->ldc : 0;
     if (dy->dtype == DSN_F32)
-        return launch<float>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
-    return launch<bf16_t>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr);
+        return launch<float>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
+    return launch<bf16_t>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
 }
 }  // namespace
+
+// Input gradient whose launch writes the FINAL value of dz for one or two BatchNorm blocks upstream: their backward sums are
+// formed in the epilogue (include/desenet_hip.h: dsn_bnred).  residual may be NULL.  DSN_EUNSUPPORTED when the layer cannot take
+// the vectorised store: run dsn_conv2d_dgrad[_res] and dsn_bn_act_bwd_reduce instead.
+extern "C" int dsn_conv2d_dgrad_bnred(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
+                                      const dsn_tensor* residual, const dsn_bnred* red, void* stream) {
+    DSN_CHECK_ARG(red && red->nseg > 0, "conv2d_dgrad_bnred: needs at least one segment");
+    return conv_dgrad_impl(dy, w, dx, p, residual, stream, red);
+}
+extern "C" int dsn_conv2d_dgrad_s2_bnred(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
+                                         const dsn_bnred* red, void* stream) {
+    DSN_CHECK_ARG(red && red->nseg > 0, "conv2d_dgrad_s2_bnred: needs at least one segment");
+    return conv_dgrad_s2_impl(dy, w_s2, dx, p, red, stream);
+}
 
 extern "C" int dsn_conv2d_dgrad(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, const dsn_conv_params* p,
                                 void* stream) {

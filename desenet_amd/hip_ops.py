@@ -247,18 +247,44 @@ def conv2d_fwd_bnstats(x, w_packed, y, p: dsn_conv_params, gamma, beta, running_
     return out[0], out[1], out[2], out[3]
 
 
-def conv2d_dgrad_s2(dy, w_s2, dx, p: dsn_conv_params):
-    """Input gradient of a 3x3 / stride-2 / pad-1 conv through the 2x2 + depth-to-space form (weights: WeightBank.dgrad_s2)."""
+def bnred(segments):
+    """dsn_bnred from [(c0, c1, y, scale, shift, mean, rstd, act, acc, acc_c, ch0)]: the BatchNorm blocks whose dz an input-gradient
+    launch completes (y: the block's raw conv output restricted to the segment's channels; scale .. rstd: the segment's slices of
+    the saved statistics; acc: the block's backward accumulator, ch0 = accumulator channel of the segment's first channel)."""
+    r = _lib.dsn_bnred()
+    r.nseg = len(segments)
+    for i, (c0, c1, y, scale, shift, mean, rstd, act, acc, acc_c, ch0) in enumerate(segments):
+        s = r.seg[i]
+        dy_ = desc(y, raw=True)
+        s.c0, s.c1, s.ch0, s.acc_c, s.act = c0, c1, ch0, acc_c, act
+        s.y, s.yld = dy_.ptr, dy_.ldc
+        s.scale, s.shift, s.mean, s.rstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        s.acc = acc.data_ptr()
+    return r
+
+
+def conv2d_dgrad_s2(dy, w_s2, dx, p: dsn_conv_params, red=None):
+    """Input gradient of a 3x3 / stride-2 / pad-1 conv through the 2x2 + depth-to-space form (weights: WeightBank.dgrad_s2).
+    red: dsn_bnred -- the launch completes dz of those blocks and forms their BatchNorm backward sums in its epilogue."""
     L = _lib.lib()
     a, b = desc(dy), desc(dx)
+    if red is not None:
+        _lib.check(L.dsn_conv2d_dgrad_s2_bnred(C.byref(a), w_s2.data_ptr(), C.byref(b), C.byref(p), C.byref(red), stream_ptr()),
+                   "conv2d_dgrad_s2_bnred")
+        return dx
     _lib.check(L.dsn_conv2d_dgrad_s2(C.byref(a), w_s2.data_ptr(), C.byref(b), C.byref(p), stream_ptr()), "conv2d_dgrad_s2")
     return dx
 
 
-def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params, residual=None):
-    """dx (+)= conv_transpose(dy, w) (+ residual: a shortcut's gradient, added in the epilogue)."""
+def conv2d_dgrad(dy, w_packed_dgrad, dx, p: dsn_conv_params, residual=None, red=None):
+    """dx (+)= conv_transpose(dy, w) (+ residual: a shortcut's gradient, added in the epilogue).  red: see conv2d_dgrad_s2."""
     L = _lib.lib()
     a, b = desc(dy), desc(dx)
+    if red is not None:
+        r = desc(residual) if residual is not None else None
+        _lib.check(L.dsn_conv2d_dgrad_bnred(C.byref(a), w_packed_dgrad.data_ptr(), C.byref(b), C.byref(p), _ref(r), C.byref(red),
+                                            stream_ptr()), "conv2d_dgrad_bnred")
+        return dx
     if residual is not None:
         r = desc(residual)
         _lib.check(L.dsn_conv2d_dgrad_res(C.byref(a), w_packed_dgrad.data_ptr(), C.byref(b), C.byref(p), C.byref(r),
@@ -668,8 +694,36 @@ def bn_act_fwd(y, scale, shift, act, residual, z):
     return z
 
 
-def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False, sync=None, second=None):
+def bn_act_bwd_reduce(dz, y, scale, shift, mean, rstd, act, ws):
+    """First half of bn_act_bwd: the two per-channel sums (sum g, sum g * yhat) added into the ZEROED accumulator `ws`."""
+    a, b = desc(dz), desc(y, raw=True)
+    _lib.check(_lib.lib().dsn_bn_act_bwd_reduce(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), act, ws.data_ptr(), ws.numel() * ws.element_size(), stream_ptr()),
+               "bn_act_bwd_reduce")
+    return ws
+
+
+def bn_act_bwd(dz, y, scale, shift, mean, rstd, act, dy, dgamma, dbeta, accumulate=False, sync=None, second=None, pre=None):
+    """pre = (accumulator, [(k0, k1)]): the sums of channels [k0, k1) are already in `accumulator` -- they were formed in the epilogue
+    of the input-gradient convolution that completed dz (conv2d_dgrad(red=...)); only the remaining channels are reduced here."""
     a, b, c = desc(dz), desc(y, raw=True), desc(dy)      # (y is the raw conv output by definition, deferred or not)
+    if pre is not None and sync is None:
+        L = _lib.lib()
+        ws, cov = pre
+        nbytes = ws.numel() * ws.element_size()
+        ctot, k = y.shape[1], 0
+        for k0, k1 in sorted(cov) + [(ctot, ctot)]:
+            if k0 > k:      # channels [k, k0) were not covered by a fused epilogue
+                da, db_ = desc(dz[:, k:k0]), desc(y[:, k:k0], raw=True)
+                _lib.check(L.dsn_bn_act_bwd_reduce_into(C.byref(da), C.byref(db_), scale[k:k0].data_ptr(), shift[k:k0].data_ptr(),
+                                                        mean[k:k0].data_ptr(), rstd[k:k0].data_ptr(), act, ws.data_ptr(), ctot, k,
+                                                        stream_ptr()), "bn_act_bwd_reduce_into")
+            k = max(k, k1)
+        _lib.check(L.dsn_bn_act_bwd_apply(C.byref(a), C.byref(b), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), act, C.byref(c), _p(dgamma), _p(dbeta), int(accumulate),
+                                          ws.data_ptr(), nbytes, 0.0, 1.0, _bn_split(second)[1] if second is not None else None,
+                                          stream_ptr()), "bn_act_bwd_apply")
+        return dy
     ws, nbytes = bn_acc(y.shape[1], y.device)
     if sync is not None or second is not None:   # SyncBatchNorm: global sums for dy, per-rank share of dgamma / dbeta
         L = _lib.lib()

@@ -99,6 +99,31 @@ class Tape:
         self.lazy: Dict[int, List[LazyRec]] = {}
         self.lazy_pending: List[LazyRec] = []
         self.lazy_copies: Dict[tuple, torch.Tensor] = {}
+        self.bn_out: Dict[int, list] = {}
+
+    # ---- producers of BatchNorm outputs, by memory (conv_impl: backward sums in the consumer's dgrad epilogue) -----------------
+    def bn_register(self, out, rec):
+        """`out` (a view) holds the output of the BatchNorm block recorded in `rec` (channel k of the block at channel k of the
+        view).  The entry keeps `out` alive so that its memory cannot be handed to another tensor of this pass."""
+        rng = self._range(out)
+        if rng is not None:
+            sp, _, lo, c = rng
+            self.bn_out.setdefault(sp, []).append((lo, lo + c, rec, out))
+
+    def bn_producers(self, x):
+        """[(c0, c1, rec, k0)]: channels [c0, c1) of the view x are channels k0.. of the BatchNorm block `rec`; None if none are."""
+        if not self.bn_out or not torch.is_tensor(x) or x.dim() != 4:
+            return None
+        rng = self._range(x)
+        if rng is None:
+            return None
+        sp, _, lo, c = rng
+        out = []
+        for plo, phi, rec, _ in self.bn_out.get(sp, ()):
+            a, b = max(lo, plo), min(lo + c, phi)
+            if a < b:
+                out.append((a - lo, b - lo, rec, a - plo))
+        return out or None
 
     # ---- deferred BatchNorm registry ----------------------------------------------------------------------------------------
     @staticmethod

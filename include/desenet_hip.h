@@ -80,6 +80,41 @@ typedef struct {
     dsn_lazy_seg seg[DSN_LAZY_MAXSEG];
 } dsn_lazy_in;
 
+/* ---- BatchNorm backward sums in the epilogue of the input-gradient convolution that produces dz ----------------------------
+ * The backward of z = act(bn(y)) (common.py:53) needs two per-channel sums over the whole tensor, sum g and sum g * yhat with
+ * g = dz * act'(y*scale + shift), before a single dy can be formed (dsn_bn_act_bwd_reduce).  dz itself is the output of the
+ * input-gradient convolution of the block's consumer: when that launch writes the FINAL value of dz (every other contribution --
+ * a shortcut, an earlier consumer -- is already in its epilogue's residual / accumulate operands), its epilogue can form g from
+ * the value it is about to store and the producer's y at the same pixel, and add the sums to the producer's accumulators
+ * (dsn_bn_workspace_bytes, zero on entry): the reduce launch and its read of y and dz disappear.  Up to DSN_BNRED_MAXSEG channel
+ * segments of dx (a concat of two blocks' outputs -- C3's [m(..) | cv2(x)], common.py:145):
+ *   dx channel c in [c0, c1): y element (row, c - c0) of `y` (row stride yld elements, same dtype as dx), parameter index
+ *   c - c0 of scale / shift / mean / rstd, accumulator channel ch0 + (c - c0) of acc ([DSN_BN_NREP][2][acc_c] doubles). */
+#define DSN_BNRED_MAXSEG 2
+typedef struct {
+    int32_t      c0, c1;
+    int32_t      ch0, acc_c;
+    int32_t      act, _pad;
+    const void*  y;
+    int64_t      yld;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+    void*        acc;
+} dsn_bnred_seg;
+typedef struct {
+    int32_t       nseg, _pad;
+    dsn_bnred_seg seg[DSN_BNRED_MAXSEG];
+} dsn_bnred;
+/* dsn_conv2d_dgrad[_res] / dsn_conv2d_dgrad_s2 whose launch completes dz for the blocks of `red` (residual may be NULL).
+ * DSN_EUNSUPPORTED when the layer cannot take the vectorised store (channel counts / strides that are not multiples of the
+ * 16-byte vector): run the plain entry point and dsn_bn_act_bwd_reduce. */
+int dsn_conv2d_dgrad_bnred(const dsn_tensor* dy, const void* w_packed, const dsn_tensor* dx, const dsn_conv_params* p,
+                           const dsn_tensor* residual, const dsn_bnred* red, void* stream);
+int dsn_conv2d_dgrad_s2_bnred(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
+                              const dsn_bnred* red, void* stream);
+
 int         dsn_version(void);
 const char* dsn_last_error(void);
 
@@ -250,6 +285,11 @@ int dsn_bn_act_bwd(const dsn_tensor* dz, const dsn_tensor* y, const float* scale
 int dsn_bn_act_bwd_reduce(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                           const float* mean, const float* rstd, int32_t act, void* workspace, int64_t workspace_bytes,
                           void* stream);
+/* dsn_bn_act_bwd_reduce for a channel slice of a block, added at channel ch0 of a wider accumulator ([DSN_BN_NREP][2][acc_c]
+ * doubles) -- the block's other channels received their sums from dsn_conv2d_dgrad_bnred. */
+int dsn_bn_act_bwd_reduce_into(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, int32_t act, void* acc, int32_t acc_c, int32_t ch0,
+                               void* stream);
 int dsn_bn_act_bwd_apply(const dsn_tensor* dz, const dsn_tensor* y, const float* scale, const float* shift,
                          const float* mean, const float* rstd, int32_t act, const dsn_tensor* dy, float* dgamma,
                          float* dbeta, int32_t accumulate_param_grads, const void* workspace, int64_t workspace_bytes,
