@@ -370,16 +370,18 @@ class Model(HipModule):
 
         self._lazy_plan = {m.i: bool(consumers[m.i]) and isinstance(m, (Conv, Focus, C3, SPP))
                            and all(accepts(c) for c in consumers[m.i]) for m in self.model}
-        # layers that are the ONLY consumer of their (single) input layer: their input gradient is complete when they write it, so
-        # its BatchNorm backward sums can ride in that launch (conv_impl.conv_block_bwd: fuse_up)
-        # (the input layer must itself be a convolution block: a Concat's sources have consumers of their own)
+        # layers whose backward writes the LAST contribution to the gradient of their (single) input layer -- the consumer with
+        # the lowest index: the backward pass walks the layers downwards and every other consumer has already added its share to
+        # the buffer this one accumulates into -- so that gradient is complete when they write it and its BatchNorm backward sums can
+        # ride in that launch (conv_impl.conv_block_bwd: fuse_up).  The input layer must itself be a convolution block: a
+        # Concat's sources have consumers of their own.
         layers = list(self.model)
-        self._sole_consumer = set()
+        self._final_consumer = set()
         for m in layers:
             if isinstance(m, (Conv, C3, SPP)) and isinstance(m.f, int) and m.i > 0:
                 src = m.i - 1 if m.f == -1 else m.f
-                if len(consumers[src]) == 1 and isinstance(layers[src], (Conv, Focus, C3, SPP)):
-                    self._sole_consumer.add(m.i)
+                if min(c.i for c in consumers[src]) == m.i and isinstance(layers[src], (Conv, Focus, C3, SPP)):
+                    self._final_consumer.add(m.i)
 
     @staticmethod
     def _out_channels(m, chans):
@@ -534,8 +536,8 @@ class Model(HipModule):
                                                [m.i + j if j < 0 else j for j in m.f])
             if isinstance(m.f, int):
                 have = grads.get(srcs[0])
-                if m.i in self._sole_consumer and have is None:
-                    grads[srcs[0]] = m.bwd(tape, g, None, False, fuse_up=True)
+                if m.i in self._final_consumer:
+                    grads[srcs[0]] = m.bwd(tape, g, have, have is not None, fuse_up=True)
                 else:
                     grads[srcs[0]] = m.bwd(tape, g, have, have is not None)
             else:

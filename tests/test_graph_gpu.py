@@ -176,6 +176,7 @@ def test_graph_keeps_its_workspaces_when_eager_work_outgrows_them():
     re-allocated), then replay: the graph still owns the buffers it was captured with and gives the eager result."""
     from desenet_amd import hip_ops as ops
     from desenet_amd.graph import GraphedTrainStep
+    ops._wgrad_arena.clear()            # (an earlier test's large model must not have sized the arena already)
     b0 = _batch(41)
     me = _model()
     flat, opt, cl, sl = _setup(me)
