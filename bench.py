@@ -357,6 +357,8 @@ def main():
     log(f"timed region: {elapsed:.3f} s")
     if rank == 0:
         roof, table = roofline_from_profile(prof, prof_steps, dtype)
+        if roof is not None and not (train and a.model == "s" and batch == 8 and a.img == 640):
+            roof["traffic"] = None      # profiles/traffic.json holds the PMC passes of config 3's shapes only
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} threads ...")

@@ -68,6 +68,10 @@ class dsn_bnred(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("_pad", C.c_int32), ("seg", dsn_bnred_seg * BNRED_MAXSEG)]
 
 
+class dsn_copy_seg(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("copy_bytes", C.c_int64), ("total_bytes", C.c_int64)]
+
+
 class dsn_bn_final(C.Structure):
     _fields_ = [("acc", C.c_void_p), ("acc_c", C.c_int32), ("ch0", C.c_int32), ("n", C.c_int32), ("_pad", C.c_int32),
                 ("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
@@ -162,6 +166,7 @@ PROTOTYPES = {
     "dsn_bn_finalize_multi": (i32, [vp, i32, vp]),
     "dsn_lazy_materialize": (i32, [TP, vp, TP, vp, TP, vp]),
     "dsn_fill32": (i32, [vp, C.c_uint32, i64, vp]),
+    "dsn_copy_multi": (i32, [vp, i32, vp]),
     "dsn_add_i64": (i32, [vp, i64, i64, vp]),
     "dsn_profile_enable": (i32, [i32]),
     "dsn_profile_collect": (i32, [vp, i32]),

@@ -229,6 +229,12 @@ template <> __device__ __forceinline__ u32x4 lazy_apply<bf16_t>(u32x4 v, const f
 // shuffles, the four waves through LDS) and adds them to the producer's fp64 accumulators -- the same accumulators, replica
 // scheme and consumer (ew_prologue mode 1) as the stand-alone reduction.
 typedef dsn_bnred BnRed;
+// channels of y a launch with backward sums reads per output pixel (algorithmic bytes of the launch)
+static inline double bnred_channels(const BnRed* br) {
+    double c = 0.0;
+    if (br) for (int i = 0; i < br->nseg; ++i) c += br->seg[i].c1 - br->seg[i].c0;
+    return c;
+}
 #if defined(__HIPCC__)
 template <typename T, int VEC, int NIT> struct BnRedLane {
     const T* yp;

@@ -382,7 +382,8 @@ int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const ds
         attr = true;
     }
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
-    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0))) + 9.0 * g.Cs * g.Cd;
+    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) +
+                         9.0 * g.Cs * g.Cd;
     constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : 2;
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.flip ? 1 : 0), 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs,
                    elems * sizeof(T), st);
@@ -636,7 +637,7 @@ int launch_1x1(const dsn_tensor* s, const void* w, const float* bias, const dsn_
         attr = true;
     }
     const int blocks = (int)((M + BM - 1) / BM) * g.tiles_n;
-    const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0))) + (double)g.Cs * g.Cd;
+    const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) + (double)g.Cs * g.Cd;
     constexpr int CFG = (BM == 64 && BN == 64) ? 2 : 5;
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (is_dgrad ? 1 : 0), 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,

@@ -420,6 +420,71 @@ static __global__ void add_i64_kernel(int64_t* __restrict__ p, int64_t n, int64_
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) p[i] += v;
 }
+// dsn_copy_multi: up to DSN_COPY_MAXSEG flat copies in ONE launch, each zero-filled from copy_bytes to total_bytes -- the staging of
+// a training batch into the static buffers a captured step reads (image batch, label rows padded to the buffer's capacity, masks:
+// train.py:329 `imgs.to(device)`, :352-354 targets) instead of three copies and a fill.
+namespace {
+struct CopyPlan {
+    int32_t n;
+    int32_t first[DSN_COPY_MAXSEG + 1];     // first block of each segment
+    dsn_copy_seg s[DSN_COPY_MAXSEG];
+    int32_t wide[DSN_COPY_MAXSEG];          // 1: 16-byte units, 0: 4-byte units
+};
+constexpr int COPY_PER_THREAD = 4;
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyPlan pl) {
+    int j = 0;
+    while (j + 1 < pl.n && (int)blockIdx.x >= pl.first[j + 1]) ++j;
+    const dsn_copy_seg sg = pl.s[j];
+    const int64_t base = ((int64_t)blockIdx.x - pl.first[j]) * 256 * COPY_PER_THREAD + threadIdx.x;
+    if (pl.wide[j]) {
+        const int64_t nc = sg.copy_bytes / 16, nt = sg.total_bytes / 16;
+        u32x4 v[COPY_PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < COPY_PER_THREAD; ++u) {
+            const int64_t i = base + u * 256;
+            v[u] = i < nc ? ((const u32x4*)sg.src)[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < COPY_PER_THREAD; ++u) {
+            const int64_t i = base + u * 256;
+            if (i < nt) ((u32x4*)sg.dst)[i] = v[u];
+        }
+    } else {
+        const int64_t nc = sg.copy_bytes / 4, nt = sg.total_bytes / 4;
+#pragma unroll
+        for (int u = 0; u < COPY_PER_THREAD; ++u) {
+            const int64_t i = base + u * 256;
+            if (i < nt) ((uint32_t*)sg.dst)[i] = i < nc ? ((const uint32_t*)sg.src)[i] : 0u;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dsn_copy_multi(const dsn_copy_seg* segs, int32_t n, void* stream) {
+    DSN_CHECK_ARG(segs && n > 0 && n <= DSN_COPY_MAXSEG, "copy_multi: 1..%d segments", DSN_COPY_MAXSEG);
+    CopyPlan pl{};
+    pl.n = n;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const dsn_copy_seg& g = segs[i];
+        DSN_CHECK_ARG(g.dst && g.copy_bytes >= 0 && g.total_bytes >= g.copy_bytes && (g.src || g.copy_bytes == 0),
+                      "copy_multi: bad segment %d", i);
+        DSN_CHECK_ARG(g.copy_bytes % 4 == 0 && g.total_bytes % 4 == 0 && (uintptr_t)g.dst % 4 == 0 && (uintptr_t)g.src % 4 == 0,
+                      "copy_multi: segment %d is not made of aligned 32-bit words", i);
+        pl.s[i] = g;
+        pl.wide[i] = (g.copy_bytes % 16 == 0 && g.total_bytes % 16 == 0 && (uintptr_t)g.dst % 16 == 0 && (uintptr_t)g.src % 16 == 0) ? 1 : 0;
+        const int64_t units = g.total_bytes / (pl.wide[i] ? 16 : 4);
+        pl.first[i] = (int32_t)blocks;
+        blocks += (units + 256 * COPY_PER_THREAD - 1) / (256 * COPY_PER_THREAD);
+        DSN_CHECK_ARG(blocks < (1ll << 30), "copy_multi: too large");
+    }
+    pl.first[n] = (int32_t)blocks;
+    if (blocks == 0) return DSN_OK;
+    hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pl);
+    DSN_LAUNCH_CHECK("copy_multi");
+    return DSN_OK;
+}
+
 extern "C" int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream) {
     DSN_CHECK_ARG(p && n >= 0, "add_i64: bad args");
     if (n == 0) return DSN_OK;

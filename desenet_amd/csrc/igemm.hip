@@ -671,7 +671,8 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     // algorithmic work of this launch: every source/destination element and every weight touched once
     const double K = (double)g.Ktot;
     const double src_elems = (double)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws * g.Cs;
-    const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd;
+    const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd +
+                         (double)g.M * (g.d2s_c > 0 ? 4.0 : 1.0) * bnred_channels(brp);
     ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
                    elems * sizeof(T), st);
     static const bool no_uni = getenv("DSN_IGEMM_NOUNI") != nullptr;                                          // tuning knob

@@ -25,6 +25,7 @@ from typing import Callable, Optional
 import torch
 import torch.distributed as dist
 
+from . import hip_ops as ops
 from .runtime import Tape
 
 
@@ -235,27 +236,45 @@ class GraphedTrainStep:
             torch.autograd.graph.increment_version([p for p in self.model.parameters()])
 
     # ---- per-step API -----------------------------------------------------------------------------------------------------------
-    def _set_labels(self, det_targets, seg_targets):
-        if det_targets is not None:
-            n = int(det_targets.shape[0])
-            if n > self.det_t.shape[0]:
-                raise ValueError(f"{n} label rows exceed this step's capacity ({self.det_t.shape[0]}); build it with a larger max_targets")
-            self.det_t.zero_()
-            if n:
-                self.det_t[:n].copy_(det_targets.to(self.det_t.dtype), non_blocking=True)
-        if seg_targets is not None:
-            self.seg_t.copy_(seg_targets, non_blocking=True)
-
-    def __call__(self, x: torch.Tensor = None, det_targets: torch.Tensor = None, seg_targets: torch.Tensor = None):
-        """One micro-batch: copies the batch into the static buffers, replays forward/backward, and -- on the last micro-batch
-        of an accumulation window -- all-reduces and steps the optimizer.  Returns the (device) loss of this micro-batch."""
+    def _stage(self, x, det_targets, seg_targets):
+        """The batch -> the static buffers the graphs read, in ONE launch (dsn_copy_multi: image, label rows zero-padded to the
+        buffer's capacity, masks) when everything is already on the device in the buffers' dtypes; per-tensor copies otherwise."""
+        pairs, slow = [], []
         if x is not None and x.data_ptr() != self.x.data_ptr():
-            self.x.copy_(x, non_blocking=True)
+            pairs.append((self.x, x))
         if det_targets is not None or seg_targets is not None:
             if self.det_t is None:
                 raise RuntimeError("this step was built without static label buffers (legacy form): pass det_targets / "
                                    "seg_targets to the constructor")
-            self._set_labels(det_targets, seg_targets)
+            if det_targets is not None:
+                n = int(det_targets.shape[0])
+                if n > self.det_t.shape[0]:
+                    raise ValueError(f"{n} label rows exceed this step's capacity ({self.det_t.shape[0]}); build it with a larger max_targets")
+                pairs.append((self.det_t, det_targets if n else None))
+            if seg_targets is not None:
+                pairs.append((self.seg_t, seg_targets))
+        for dst, src in pairs:
+            if src is not None and (src.device != dst.device or src.dtype != dst.dtype or not src.is_contiguous()
+                                    or src.numel() > dst.numel() or (src.data_ptr() | dst.data_ptr()) % 4
+                                    or (src.numel() * src.element_size()) % 4):
+                slow.append((dst, src))
+        fast = [p for p in pairs if not any(p[0] is d for d, _ in slow)]
+        if fast:
+            ops.copy_multi(fast)
+        for dst, src in slow:
+            if dst is self.det_t:
+                dst.zero_()
+                dst[:src.shape[0]].copy_(src.to(dst.dtype), non_blocking=True)
+            else:
+                dst.copy_(src, non_blocking=True)
+
+    def _set_labels(self, det_targets, seg_targets):
+        self._stage(None, det_targets, seg_targets)
+
+    def __call__(self, x: torch.Tensor = None, det_targets: torch.Tensor = None, seg_targets: torch.Tensor = None):
+        """One micro-batch: copies the batch into the static buffers, replays forward/backward, and -- on the last micro-batch
+        of an accumulation window -- all-reduces and steps the optimizer.  Returns the (device) loss of this micro-batch."""
+        self._stage(x, det_targets, seg_targets)
         first = self.micro == 0
         last = self.micro == self.accumulate - 1
         if self.g_opt is None:                   # single rank, no accumulation: one replay is the whole step

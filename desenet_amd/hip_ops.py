@@ -1038,6 +1038,19 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def copy_multi(pairs):
+    """[(dst, src | None)] flat copies in one launch: dst[:src.numel()] = src, the rest of dst zero (dst, src: contiguous tensors of
+    one dtype on the device; src None = clear dst).  At most 4 pairs."""
+    segs = (_lib.dsn_copy_seg * len(pairs))()
+    for i, (dst, src) in enumerate(pairs):
+        if not dst.is_contiguous() or (src is not None and (not src.is_contiguous() or src.dtype != dst.dtype or src.device != dst.device)):
+            raise ValueError("copy_multi: contiguous tensors of one dtype on one device")
+        nb = src.numel() * src.element_size() if src is not None else 0
+        segs[i] = _lib.dsn_copy_seg(dst.data_ptr(), src.data_ptr() if src is not None and nb else None, nb,
+                                    dst.numel() * dst.element_size())
+    _lib.check(_lib.lib().dsn_copy_multi(segs, len(pairs), stream_ptr()), "copy_multi")
+
+
 def add_i64_(t: torch.Tensor, value: int) -> torch.Tensor:
     _require_gpu(t)
     assert t.dtype == torch.int64 and t.is_contiguous()

@@ -454,6 +454,17 @@ int dsn_cast(const float* src, void* dst, int32_t dtype, int64_t n, void* stream
 /* p[0 .. n_words) = value (32-bit words; p 4-byte aligned): `optimizer.zero_grad()` on the flat gradient buffer
  * (scripts/train.py:378) and the per-step accumulator clears, as a kernel (no memset graph nodes). */
 int dsn_fill32(void* p, uint32_t value, int64_t n_words, void* stream);
+/* Up to DSN_COPY_MAXSEG flat device-to-device copies in one launch; bytes [copy_bytes, total_bytes) of each destination are
+ * zero-filled.  Stages a training batch (scripts/train.py:329 imgs, :352-354 targets / masks) into the static buffers a
+ * captured step reads.  Sizes and pointers: multiples of 4 bytes (16-byte vectors are used where everything is 16-aligned). */
+#define DSN_COPY_MAXSEG 4
+typedef struct {
+    void*       dst;
+    const void* src;
+    int64_t     copy_bytes;
+    int64_t     total_bytes;
+} dsn_copy_seg;
+int dsn_copy_multi(const dsn_copy_seg* segs_host, int32_t n, void* stream);
 /* p[i] += value for n int64 elements: BatchNorm's `num_batches_tracked += 1` for every layer in one launch. */
 int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream);
 
