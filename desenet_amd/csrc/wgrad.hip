@@ -291,6 +291,156 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
 }
 
 
+// ---- 128 x 128 tile (bf16, 16-byte paths): the per-tap kernel for layers whose weight matrix is at least that large -------------
+// The 64 x 64 tile runs 4 MFMAs per wave between two barriers and reads 8 transposed fragments halves for them -- it is bound by
+// LDS and barriers, not by MFMA (7-12 % of the bf16 rate on config 5's layers), and a Co x Ci = 256 x 256 layer reads each operand
+// four times.  Here a wave owns 64(co) x 64(ci): 16 MFMAs per 32-pixel chunk for 16 fragment reads, each operand is read half as
+// often, and a block is 4x fewer work items for the same layer.  Rows are [pixel][128 channels] = 256 bytes: every row starts at
+// bank 0, so the 32-byte column group is XOR-ed with swz128(row) -- a bijection of the 8 rows a transposing read touches per
+// 32-lane half (rows 8*fg + q: bits 0, 1, 3) onto the 8 groups, with bit 0 of the row in the TOP bit so that the two rows of a
+// 16-lane store pass land in different halves of the bank row.
+constexpr int TB2 = 128;
+__device__ __forceinline__ int swz128(int row) { return ((row & 1) << 2) | ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+template <int PK>
+__device__ __forceinline__ void wgrad_body128(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ out,
+                                              const WGeom& g, int bid) {
+    constexpr int ROW = TB2, RG = PK / 32, NV = 2;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][PK * ROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][PK * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int taps = g.KH * g.KW;
+    const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
+    const int tco = bid % g.tiles_co; bid /= g.tiles_co;
+    const int tap = bid % taps;
+    const int split = bid / taps;
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+    const int co0 = tco * TB2, ci0 = tci * TB2;
+    const int p_begin = split * g.ppb;
+    const int p_end = (p_begin + g.ppb < g.P) ? p_begin + g.ppb : g.P;
+    const int nchunks = (p_end - p_begin + PK - 1) / PK;
+    const int srow = tid >> 3, sv = tid & 7;        // staged pixel row, first of the thread's two 16-byte vectors (sv, sv + 8)
+    u32x4 ra[RG][NV], rb[RG][NV];
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.dy_bytes, 0x00020000);
+    const bool lin = g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo;
+    int cp[RG], cox[RG], coy[RG], cn[RG];
+    uint32_t aoff[RG], boff[RG];
+    const int tap_dy = ky * g.dil - g.pad, tap_dx = kx * g.dil - g.pad;
+    const uint32_t astep = (uint32_t)(PK * (int)g.yld) * 2, bstep = (uint32_t)(PK * (int)g.xld) * 2;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+        cp[rg] = p_begin + srow + 32 * rg;
+        const int pc = cp[rg] < g.P ? cp[rg] : g.P - 1;
+        cox[rg] = pc % g.Wo;
+        const int t = pc / g.Wo;
+        coy[rg] = t % g.Ho;
+        cn[rg] = t / g.Ho;
+        aoff[rg] = (uint32_t)(cp[rg] * (int)g.yld + co0) * 2;
+        boff[rg] = (uint32_t)((cp[rg] + tap_dy * g.Wi + tap_dx) * (int)g.xld + ci0) * 2;     // used when lin
+    }
+    auto load_chunk = [&]() {            // (the cursor advances: called once per chunk, in order)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            const int p = cp[rg];
+            const bool pok = p < p_end;
+            const int iy = coy[rg] * g.stride + tap_dy, ix = cox[rg] * g.stride + tap_dx;
+            const bool xok = pok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const uint32_t abase = aoff[rg];
+            const uint32_t bbase = lin ? boff[rg] : (uint32_t)(((cn[rg] * g.Hi + iy) * g.Wi + ix) * (int)g.xld + ci0) * 2;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int vc = (sv + 8 * i) * 8;
+                ra[rg][i] = __builtin_amdgcn_raw_buffer_load_b128(yr, (pok && co0 + vc < g.Co) ? abase + vc * 2 : OOB, 0, 0);
+                rb[rg][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (xok && ci0 + vc < g.CiLoad) ? bbase + vc * 2 : OOB, 0, 0);
+            }
+            aoff[rg] += astep;
+            boff[rg] += bstep;
+            cp[rg] = p + PK;
+            cox[rg] += PK;
+            while (cox[rg] >= g.Wo) {
+                cox[rg] -= g.Wo;
+                if (++coy[rg] >= g.Ho) { coy[rg] = 0; ++cn[rg]; }
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = sv + 8 * i;                                   // vector of the row: 32-byte group v >> 1, half v & 1
+                const int col = ((((v >> 1) ^ swz128(srow)) << 1) | (v & 1)) << 3;
+                *reinterpret_cast<u32x4*>(&sA[buf][(srow + 32 * rg) * ROW + col]) = ra[rg][i];
+                *reinterpret_cast<u32x4*>(&sB[buf][(srow + 32 * rg) * ROW + col]) = rb[rg][i];
+            }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const int q = fr >> 2, pp = fr & 3;
+        const int fz = swz128(8 * fg + q);
+#pragma unroll
+        for (int ks = 0; ks < PK / 32; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* base = &sA[buf][(32 * ks + 8 * fg + q) * ROW + (((wm * 4 + i) ^ fz) << 4) + 4 * pp];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+                a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t* base = &sB[buf][(32 * ks + 8 * fg + q) * ROW + (((wn * 4 + j) ^ fz) << 4) + 4 * pp];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+                b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nchunks;
+        if (more) load_chunk();
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* o = out + (g.S > 1 ? (int64_t)split * g.Co * taps * g.Cip : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + (wm * 4 + i) * 16 + fg * 4 + e;
+                const int ci = ci0 + (wn * 4 + j) * 16 + fr;
+                if (co < g.Co && ci < g.Ci) {
+                    float* d = (g.S == 1 && g.oihw) ? o + ((int64_t)co * g.Ci + ci) * taps + tap
+                                                    : o + ((int64_t)co * taps + tap) * g.Cip + ci;
+                    float v = acc[i][j][e];
+                    if (g.S == 1 && g.accumulate) v += *d;
+                    *d = v;
+                }
+            }
+}
+
 // ---- all-taps variant (bf16, 3x3): one block owns a 64(co) x 64(ci) tile of ALL nine taps over its pixel range ------------
 // The per-tap kernel above re-reads dy once per tap (9x: 472 MB instead of 52 MB for the Focus conv -- it ran at the HBM
 // rate of the re-reads).  Here dy is staged once per chunk and shared by the nine taps, the nine shifted x gathers hit the
@@ -520,6 +670,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
                                                     float* __restrict__ out, const WGeom g) {
     wgrad_body<T, VECLOAD, PK>(x, dy, out, g, blockIdx.x);
 }
+template <int PK>
+__global__ __launch_bounds__(256, 2) void wgrad128_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          float* __restrict__ out, const WGeom g) {
+    wgrad_body128<PK>(x, dy, out, g, blockIdx.x);
+}
 template <int NT>
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                  float* __restrict__ out, const WGeom g) {
@@ -538,10 +693,10 @@ struct WJob {
     float* out;            // slabs (S > 1) or dw
     float* dw;
     WGeom g;
-    int32_t kind;          // 0: per-tap blocks, 1: all-taps blocks
+    int32_t kind;          // 0: per-tap blocks (64 x 64 tiles), 1: all-taps blocks, 3: per-tap blocks with 128 x 128 tiles
     int32_t dtype;
-    int32_t blocks[3];     // blocks of this job in the per-tap / all-taps / reduce launch
-    int32_t start[3];      // first block of this job in each launch
+    int32_t blocks[4];     // blocks of this job in the per-tap / all-taps / reduce / 128-tile launch
+    int32_t start[4];      // first block of this job in each launch
     int64_t n_out;
     double flops, bytes;
     LazyIn lx;             // deferred BatchNorm + act segments of x (nseg == 0: plain)
@@ -576,6 +731,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_alltaps_grouped_kernel(const WJo
     wgrad_alltaps_body<9, LAZY>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
                           xcd_local(blockIdx.x - jobs[l].start[1], jobs[l].blocks[1]), &jobs[l].lx);
 }
+template <int PK>
+__global__ __launch_bounds__(256, 2) void wgrad128_grouped_kernel(const WJob* __restrict__ jobs, int n) {
+    const int l = find_job(jobs, n, blockIdx.x, 3);
+    const WGeom g = jobs[l].g;
+    wgrad_body128<PK>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
+                      xcd_local(blockIdx.x - jobs[l].start[3], jobs[l].blocks[3]));
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     __shared__ float part[16][65];
     const int l = find_job(jobs, n, blockIdx.x, 2);
@@ -601,14 +763,27 @@ inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
     return vl && fits;
 }
 
-inline int choose_split(const WGeom& g, bool alltaps = false) {
+// 128 x 128 tiles: bf16, whole 128-channel blocks on both sides, enough pixels that the 4x fewer tiles still fill the chip through
+// the split (DSN_WGRAD_T128 = 0: never, 1: whenever the shape allows, default: P >= DSN_WGRAD_T128_MINPX pixels)
+inline bool use_tile128(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p, bool alltaps) {
+    static const int mode = [] { const char* e = getenv("DSN_WGRAD_T128"); return e ? atoi(e) : -1; }();
+    // (measured, MI355X: config 5 24.57 ms without the 128-wide tiles, 23.83 with them from 16384 pixels up, 23.69 on every eligible
+    //  layer; config 3 4.728 / 4.79 / 4.712 ms -- a partial move leaves two under-filled grouped launches, so it is all or nothing)
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_T128_MINPX"); return e ? atoi(e) : 0; }();
+    if (mode == 0 || alltaps || x->dtype != DSN_BF16) return false;
+    if (dy->c % TB2 != 0 || x->c % TB2 != 0) return false;
+    return mode == 1 || npix(dy) >= minpx;
+}
+
+inline int choose_split(const WGeom& g, bool alltaps = false, bool t128 = false) {
     const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
     static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 320; }();
     static const int scap = [] { const char* e = getenv("DSN_WGRAD_SCAP"); return e ? atoi(e) : 256; }();
     static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 4096; }();
     // (re-measured with the grouped launches, MI355X: blocks 288..352 x minpx 4096..5120 is a plateau -- 0.54 ms gather + 0.06 ms
     //  slab reduce; 256 / 1024 was 0.56 + 0.14: four times the slab traffic for parallelism the shared grids no longer need)
-    const int tgt = alltaps ? target / 2 : target, cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
+    static const int target128 = [] { const char* e = getenv("DSN_WGRAD_BLOCKS128"); return e ? atoi(e) : 64; }();     // (sweep: 64..128 best on config 5, flat on config 3)
+    const int tgt = alltaps ? target / 2 : (t128 ? target128 : target), cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
     int64_t s = (tgt + base - 1) / base;
     const int64_t smax = (g.P + minpx - 1) / minpx;
     if (s > smax) s = smax;
@@ -623,10 +798,12 @@ extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const d
     if (!x || !dy || !p) return 0;
     WGeom g{};
     g.P = (int32_t)npix(dy);
-    g.tiles_co = (dy->c + TB - 1) / TB;
-    g.tiles_ci = (x->c + TB - 1) / TB;
+    const bool at = use_alltaps(x, dy, p);
+    const int tb = use_tile128(x, dy, p, at) ? TB2 : TB;
+    g.tiles_co = (dy->c + tb - 1) / tb;
+    g.tiles_ci = (x->c + tb - 1) / tb;
     g.KH = p->kh; g.KW = p->kw;
-    const int S = choose_split(g, use_alltaps(x, dy, p));
+    const int S = choose_split(g, at, tb == TB2);
     const int64_t row = ci_pad > x->c ? ci_pad : x->c;
     return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * row * sizeof(float) : 0;
 }
@@ -648,10 +825,21 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.Co = dy->c; g.Ci = x->c; g.Cip = ci_pad;
     g.KH = p->kh; g.KW = p->kw; g.stride = p->stride; g.pad = p->pad; g.dil = p->dil;
     g.yld = dy->ldc; g.xld = x->ldc;
-    g.tiles_co = (g.Co + TB - 1) / TB; g.tiles_ci = (g.Ci + TB - 1) / TB;
     const bool alltaps = use_alltaps(x, dy, p);
-    g.S = choose_split(g, alltaps);
-    static const int gpk = [] { const char* e = getenv("DSN_WGRAD_GPK"); return (e && atoi(e) == 64) ? 64 : 32; }();
+    bool t128 = use_tile128(x, dy, p, alltaps);
+    {   // (the 128-tile kernel exists for the 16-byte paths only: the same conditions as *vec_out below)
+        const int es0 = 2;
+        t128 = t128 && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) && ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0) &&
+               ((npix(x) - 1) * x->ldc + x->c) * es0 < (1ll << 31) && ((npix(dy) - 1) * dy->ldc + dy->c) * es0 < (1ll << 31) &&
+               (!oihw || ci_pad >= x->c);
+    }
+    const int tb = t128 ? TB2 : TB;
+    g.tiles_co = (g.Co + tb - 1) / tb; g.tiles_ci = (g.Ci + tb - 1) / tb;
+    g.S = choose_split(g, alltaps, t128);
+    static const int gpk = [] {
+        const char *e = getenv("DSN_WGRAD_GPK"), *f = getenv("DSN_WGRAD_T128_PK");
+        return ((e && atoi(e) == 64) || (f && atoi(f) == 64)) ? 64 : 32;
+    }();
     const int PK = gpk;       // pixel ranges are multiples of the largest chunk any kernel variant may use
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
@@ -681,7 +869,7 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.dy_bytes = (uint32_t)(yb < (1ll << 31) ? yb : 0);
     *job = WJob{};
     job->x = x->ptr; job->dy = dy->ptr; job->out = out; job->dw = dw; job->g = g;
-    job->kind = alltaps ? 1 : 0;
+    job->kind = alltaps ? 1 : (t128 ? 3 : 0);
     job->dtype = x->dtype;
     job->blocks[job->kind] = g.tiles_ci * g.tiles_co * (alltaps ? 1 : g.KH * g.KW) * g.S;
     job->blocks[2] = g.S > 1 ? (int32_t)((n_out + 63) / 64) : 0;
@@ -725,7 +913,9 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     dim3 grid(job.blocks[job.kind]), block(256);
     {
         ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), job.flops, job.bytes, st);
-        if (job.kind == 1) {
+        if (job.kind == 3) {
+            hipLaunchKernelGGL(wgrad128_kernel<32>, grid, block, 0, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
+        } else if (job.kind == 1) {
             alltaps_attr_once();
             hipLaunchKernelGGL(wgrad_alltaps_bf16_kernel<9>, grid, block, ALLTAPS_LDS, st, (const bf16_t*)x->ptr,
                                (const bf16_t*)dy->ptr, out, g);
@@ -791,24 +981,26 @@ extern "C" int dsn_conv2d_wgrad_plan_lazy(const dsn_tensor* x, const dsn_lazy_in
                       "conv wgrad plan: lazy segment %d must carry scale / shift arrays over channels inside x", i);
         if (s.c0 % 8 || s.c1 % 8) DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: lazy segment bounds must be multiples of 8");
     }
+    if (((WJob*)job_out)->kind == 3)
+        DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: the 128 x 128-tile kernel does not apply deferred transforms (materialise x)");
     ((WJob*)job_out)->lx = *lx;
     return DSN_OK;
 }
 
 // jobs_host: n planned jobs, contiguous.  Assigns every job its first block in each of the three launches (in place) and
-// returns the three grid sizes + totals in launch_out[8] = {grid per-tap, grid all-taps, grid reduce, dtype, flops, bytes,
-// reduce bytes, 0} (doubles).  Upload the array AFTER this call.
+// returns the grid sizes + totals in launch_out[10] = {grid per-tap, grid all-taps, grid reduce, dtype, flops, bytes,
+// reduce bytes, any deferred x, grid 128-tile, 0} (doubles).  Upload the array AFTER this call.
 extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* launch_out) {
     DSN_CHECK_ARG(jobs_host && n > 0 && launch_out, "conv wgrad plan_finish: bad arguments");
     WJob* jobs = (WJob*)jobs_host;
     // longest blocks first: a block's life is its pixel range, and the hardware dispatches blocks in index order -- heavy
     // jobs at the end of the grid would leave a tail of a few long blocks on an otherwise drained chip
     std::stable_sort(jobs, jobs + n, [](const WJob& a, const WJob& b) { return a.g.ppb > b.g.ppb; });
-    int64_t start[3] = {0, 0, 0};
+    int64_t start[4] = {0, 0, 0, 0};
     double flops = 0, bytes = 0, rbytes = 0;
     for (int i = 0; i < n; ++i) {
         DSN_CHECK_ARG(jobs[i].dtype == jobs[0].dtype, "conv wgrad plan_finish: mixed dtypes in one queue");
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             jobs[i].start[k] = (int32_t)start[k];
             start[k] += jobs[i].blocks[k];
         }
@@ -816,13 +1008,15 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
         bytes += jobs[i].bytes;
         if (jobs[i].g.S > 1) rbytes += (double)(jobs[i].g.S + 1) * jobs[i].n_out * 4;
     }
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
         DSN_CHECK_ARG(start[k] < (1ll << 31), "conv wgrad plan_finish: too many blocks");
     launch_out[0] = (double)start[0]; launch_out[1] = (double)start[1]; launch_out[2] = (double)start[2];
     launch_out[3] = (double)jobs[0].dtype; launch_out[4] = flops; launch_out[5] = bytes; launch_out[6] = rbytes;
     int any_lazy = 0;
     for (int i = 0; i < n; ++i) any_lazy |= jobs[i].lx.nseg > 0;
     launch_out[7] = (double)any_lazy;       // some x operand carries deferred-BatchNorm segments: the LAZY instantiations run
+    launch_out[8] = (double)start[3];       // grid of the 128 x 128-tile launch
+    launch_out[9] = 0.0;
     return DSN_OK;
 }
 
@@ -847,6 +1041,13 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
                 hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 64>), dim3(g0), dim3(256), 0, st, jobs, n);
             else
                 hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 32>), dim3(g0), dim3(256), 0, st, jobs, n);
+        }
+        const int g3 = (int)launch[8];
+        if (g3 > 0) {
+            DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: 128-tile jobs are bf16 only");
+            static const int pk128 = [] { const char* e = getenv("DSN_WGRAD_T128_PK"); return (e && atoi(e) == 64) ? 64 : 32; }();
+            if (pk128 == 64) hipLaunchKernelGGL(wgrad128_grouped_kernel<64>, dim3(g3), dim3(256), 0, st, jobs, n);
+            else hipLaunchKernelGGL(wgrad128_grouped_kernel<32>, dim3(g3), dim3(256), 0, st, jobs, n);
         }
         if (g1 > 0) {
             DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: all-taps jobs are bf16 only");

@@ -445,7 +445,7 @@ class WgradQueue:
         keep = self.keep
         if self.n:
             L = _lib.lib()
-            launch = (C.c_double * 8)()
+            launch = (C.c_double * 10)()
             _lib.check(L.dsn_conv2d_wgrad_plan_finish(self.host.data_ptr(), self.n, launch), "conv2d_wgrad_plan_finish")
             nb = self.n * self.job_bytes
             dev = torch.empty(nb, dtype=torch.uint8, device=self.device)

@@ -167,7 +167,7 @@ int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32
  *   dsn_conv2d_wgrad_plan: same arguments as dsn_conv2d_wgrad + job_out (HOST, dsn_wgrad_job_bytes() bytes).  x, dy, dw and
  *     workspace must stay valid and untouched until the run has executed.  DSN_EUNSUPPORTED: use dsn_conv2d_wgrad.
  *   dsn_conv2d_wgrad_plan_finish: jobs_host = n planned jobs, contiguous; assigns block ranges in place and fills
- *     launch_out[8].  Copy jobs_host to the device AFTER this call.
+ *     launch_out[10] (doubles).  Copy jobs_host to the device AFTER this call.
  *   dsn_conv2d_wgrad_run: jobs_dev = device copy of the finished plan. */
 int64_t dsn_wgrad_job_bytes(void);
 int dsn_conv2d_wgrad_plan(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,

@@ -62,6 +62,11 @@ CONV_CASES = [
     (2, 64, 16, 16, 64, 3, 1, 3, 3),     # dilation 3 (14 x 14 halo)
     (1, 256, 8, 16, 128, 3, 1, 1, 1),    # four bf16 slabs: halo prefetch of the next slab
     (3, 128, 8, 8, 32, 3, 1, 2, 2),      # one patch per image, narrow output
+    # wgrad.hip 128 x 128 tiles (bf16, whole 128-channel blocks, >= 16384 output pixels, below the all-taps threshold)
+    (4, 128, 64, 64, 256, 1, 1, 0, 1),
+    (4, 256, 66, 64, 128, 3, 1, 1, 1),   # ragged last pixel range
+    (4, 128, 130, 128, 128, 3, 2, 1, 1), # stride 2: the input cursor is re-derived per chunk
+    (4, 128, 64, 64, 128, 3, 1, 2, 2),   # dilation
 ]
 
 
@@ -144,11 +149,11 @@ def test_wgrad_large_reduction_and_padding(ops, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_queue_matches_single_layer(ops, dtype):
     """dsn_conv2d_wgrad_plan / _plan_finish / _run: several layers' weight gradients in three grouped launches give the same
-    numbers as one dsn_conv2d_wgrad per layer -- per-tap and (bf16, >= 32k pixels) all-taps blocks, split-K slabs and direct
+    numbers as one dsn_conv2d_wgrad per layer -- per-tap (64 and, bf16, 128-wide tiles) and (bf16, >= 32k pixels) all-taps blocks, split-K slabs and direct
     writes, accumulation into an existing gradient, and a layer the queue must refuse (odd channel count)."""
     layers = [  # n, ci, h, w, co, k, s
         (2, 16, 24, 24, 32, 3, 1), (8, 32, 72, 72, 32, 3, 1), (2, 64, 20, 20, 128, 1, 1), (1, 256, 8, 8, 256, 3, 1),
-        (2, 32, 40, 40, 64, 3, 2), (2, 64, 10, 10, 33, 1, 1),
+        (2, 32, 40, 40, 64, 3, 2), (2, 64, 10, 10, 33, 1, 1), (4, 128, 64, 64, 256, 1, 1), (4, 256, 72, 64, 128, 3, 1),
     ]
     queue = ops.WgradQueue(torch.device("cuda", torch.cuda.current_device()))
     pending = []
