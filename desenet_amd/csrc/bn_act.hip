@@ -340,7 +340,7 @@ __global__ __launch_bounds__(THREADS) void lazy_ew_kernel(const T* __restrict__ 
 }
 
 // saved statistics + running averages of up to FINAL_MAX BatchNorm modules per launch (end of the forward pass)
-constexpr int FINAL_MAX = 28;
+constexpr int FINAL_MAX = 40;      // (kernel arguments: 8 + 41 * 4 + 40 * 96 bytes < 4 KB)
 struct FinalTable {
     int32_t n, pad;
     int32_t first[FINAL_MAX + 1];     // first block of each entry (256 channels per block)

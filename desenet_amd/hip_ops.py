@@ -191,7 +191,7 @@ def lazy_materialize(x, lz, z, residual=None, lres=None):
 
 
 def bn_finalize_multi(recs):
-    """Saved statistics + running averages of every pending BatchNorm (runtime.LazyRec) in one launch per 28 modules."""
+    """Saved statistics + running averages of every pending BatchNorm (runtime.LazyRec) in one launch per 40 modules."""
     n = len(recs)
     arr = (_lib.dsn_bn_final * n)()
     for i, r in enumerate(recs):

@@ -227,7 +227,7 @@ class Tape:
         self.lazy_copies[(rng, True)] = z
 
     def finalize_forward(self):
-        """End of the forward pass: ONE launch (per 28 modules) writes every pending BatchNorm's saved statistics and updates its
+        """End of the forward pass: ONE launch (per 40 modules) writes every pending BatchNorm's saved statistics and updates its
         running averages (torch_utils.py:164-165)."""
         if self.lazy_pending:
             _ops().bn_finalize_multi(self.lazy_pending)

@@ -476,7 +476,7 @@ int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream);
  *   entry point.
  * dsn_bn_finalize_multi: for n BatchNorm modules whose sums are complete, write scale = g*rstd, shift = b - mean*scale, mean, rstd
  *   (saved for the backward pass) and update the running statistics (torch_utils.py:164-165 momentum 0.03, unbiased variance) --
- *   ONE launch per 32 modules at the end of the forward pass instead of one per layer.  entries: HOST array. */
+ *   ONE launch per 40 modules at the end of the forward pass instead of one per layer.  entries: HOST array. */
 typedef struct {
     const void*  acc;            /* [DSN_BN_NREP][2][acc_c] doubles */
     int32_t      acc_c, ch0;     /* accumulator channel count, first channel of this module */

@@ -30,7 +30,7 @@ def ids(sym):
     if "wgrad_reduce" in sym:
         return ["wgrad_reduce"]
     if "wgrad" in sym:
-        return ["wgrad_bf16" if "DF16b" in sym or "alltaps" in sym else "wgrad_f32"]
+        return ["wgrad_bf16" if "DF16b" in sym or "alltaps" in sym or "wgrad128" in sym else "wgrad_f32"]
     if "reduce2_kernel" in sym:
         return ["bn_act_bwd_reduce" if "BwdRedF" in sym else "bn_stats_reduce"]
     if "ew2_kernel" in sym:
@@ -41,13 +41,23 @@ def ids(sym):
 
 
 def load(path, counter):
-    agg = collections.defaultdict(lambda: [0, 0.0])
+    """{id: [launches, counter sum]}.  The grouped weight-gradient launches (per-tap 64- and 128-wide tiles, all-taps) are ONE unit of
+    work per step for the library's profiler (`wgrad_bf16`, launches_per_step = 1): their per-symbol averages are ADDED."""
+    per_sym = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        for k in ids(r["Kernel_Name"]):
-            agg[k][0] += 1
-            agg[k][1] += float(r["Counter_Value"])
+        per_sym[r["Kernel_Name"]][0] += 1
+        per_sym[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for sym, (n, v) in per_sym.items():
+        for k in ids(sym):
+            if k.startswith("wgrad_") and k != "wgrad_reduce":
+                agg[k][0] = 1
+                agg[k][1] += v / n
+            else:
+                agg[k][0] += n
+                agg[k][1] += v
     return agg
 
 
