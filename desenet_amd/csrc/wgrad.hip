@@ -23,6 +23,7 @@ struct WGeom {
     int32_t CiLoad;       // channels x actually holds (>= Ci: zero-padded tail may be loaded, never stored)
     int32_t oihw;         // final output layout: 0 = packed [Co][tap][Cip], 1 = OIHW [Co][Ci][tap]
     uint32_t x_bytes, dy_bytes;   // buffer-descriptor ranges of the vector-load paths (both tensors < 2 GiB there)
+    int32_t npx, npy;             // halo-tile kernel: 4 x 8-pixel patches per image row / column; P and ppb then count PATCHES
 };
 
 constexpr int TB = 64;    // tile edge (co and ci)
@@ -441,6 +442,11 @@ __device__ __forceinline__ void wgrad_body128(const bf16_t* __restrict__ x, cons
             }
 }
 
+// (Measured and dropped: the same tile staged with `buffer_load ... lds` into a three-stage ring, two chunks ahead, counted waits --
+//  bit-identical, and 0.3-0.5 % SLOWER on both configurations.  These kernels are not bound by the latency of their own loads: with
+//  ~770 resident blocks each pulling 16 KB per ~1 us chunk they sit at the aggregate L2 bandwidth, which only fewer re-reads --
+//  larger tiles -- relieve.)
+
 // ---- all-taps variant (bf16, 3x3): one block owns a 64(co) x 64(ci) tile of ALL nine taps over its pixel range ------------
 // The per-tap kernel above re-reads dy once per tap (9x: 472 MB instead of 52 MB for the Focus conv -- it ran at the HBM
 // rate of the re-reads).  Here dy is staged once per chunk and shared by the nine taps, the nine shifted x gathers hit the
@@ -597,6 +603,151 @@ __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x,
                 }
 }
 
+// ---- halo-tile all-taps variant (bf16, same-size 3x3 / stride 1 / pad = dilation = 1..3) ------------------------------------------
+// The all-taps kernel above stages NINE shifted copies of the x tile per 32-pixel chunk (10 16-byte loads per thread, 80 KB of LDS:
+// two blocks per CU).  Here a chunk is a 4 x 8 PATCH of output pixels and x is staged once with its halo ((4 + 2d) x (8 + 2d)
+// pixels): tap (ky, kx) of patch pixel (r, c) is halo pixel (r + ky d, c + kx d), and because every lane of a transposing read
+// supplies the address of its own row, the nine taps are nine address offsets into the same tile.  3 loads per thread per chunk at
+// d = 1 (6 at d = 3), 48 KB of LDS.  Halo rows are laid out with a pitch of 16 LDS rows (at most 14 used) so that the 8 rows a
+// 32-lane half reads -- (fg + ky d) * 16 + kx d + q for two values of fg and q = 0..3 -- differ in (row parity, swzh(row)):
+// conflict-free for every tap.
+constexpr int HPITCH = 16, HROWS = 10, HLOADS = 5;      // d <= 3: 10 x 14 halo pixels x 8 vectors <= 5 x 256
+__device__ __forceinline__ int swzh(int row) { return ((row >> 1) & 1) | (((row >> 4) & 1) << 1); }
+
+__device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ out,
+                                                const WGeom& g, int bid) {
+    constexpr int ROW = TB, NT = 9;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][32 * ROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][HROWS * HPITCH * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
+    const int tco = bid % g.tiles_co;
+    const int split = bid / g.tiles_co;
+    const int co0 = tco * TB, ci0 = tci * TB;
+    const int p_begin = split * g.ppb;                                  // (patches)
+    const int p_end = (p_begin + g.ppb < g.P) ? p_begin + g.ppb : g.P;
+    const int nchunks = p_end - p_begin;
+    const int D = g.dil, HWd = 8 + 2 * D, NHP = (4 + 2 * D) * HWd;      // halo width, halo pixels
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.dy_bytes, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    // staging plan: dy vector (pixel k = tid >> 3 of the patch, channels 8 * (tid & 7) ..), x vectors idx = tid + 256 i of the halo
+    // (idx >> 3 = halo pixel, idx & 7 = vector)
+    const int v8 = (tid & 7) * 8;
+    const int ak = tid >> 3, ar = ak >> 3, ac = ak & 7;
+    int hr[HLOADS], hc[HLOADS], hrow[HLOADS];
+    bool hon[HLOADS];
+#pragma unroll
+    for (int i = 0; i < HLOADS; ++i) {
+        const int hp = (tid + 256 * i) >> 3;
+        hon[i] = hp < NHP;
+        hr[i] = hp / HWd;
+        hc[i] = hp - hr[i] * HWd;
+        hrow[i] = hr[i] * HPITCH + hc[i];
+    }
+    const bool aok = co0 + v8 < g.Co, bok = ci0 + v8 < g.CiLoad;
+    // patch cursor
+    int pn, py, px;
+    {
+        const int per = g.npx * g.npy;
+        pn = p_begin / per;
+        const int t = p_begin - pn * per;
+        py = t / g.npx;
+        px = t - py * g.npx;
+    }
+    u32x4 ra, rb[HLOADS];
+    auto load_chunk = [&]() {
+        const int y0 = py * 4, x0 = px * 8;
+        const int oy = y0 + ar, ox = x0 + ac;
+        const bool pok = aok && oy < g.Ho && ox < g.Wo;
+        ra = __builtin_amdgcn_raw_buffer_load_b128(yr, pok ? (uint32_t)(((pn * g.Ho + oy) * g.Wo + ox) * (int)g.yld + co0 + v8) * 2u : OOB, 0, 0);
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            if (i >= 2 && !hon[i]) continue;             // (d = 1 needs two of the five)
+            const int iy = y0 - D + hr[i], ix = x0 - D + hc[i];
+            const bool ok = hon[i] && bok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (uint32_t)(((pn * g.Hi + iy) * g.Wi + ix) * (int)g.xld + ci0 + v8) * 2u : OOB, 0, 0);
+        }
+        if (++px >= g.npx) {
+            px = 0;
+            if (++py >= g.npy) { py = 0; ++pn; }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        *reinterpret_cast<u32x4*>(&sA[buf][ak * ROW + (v8 ^ (swz(ak) << 4))]) = ra;
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i)
+            if (hon[i]) *reinterpret_cast<u32x4*>(&sB[buf][hrow[i] * ROW + (v8 ^ (swzh(hrow[i]) << 4))]) = rb[i];
+    };
+    f32x4 acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto tr_frag = [&](const bf16_t* base) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto compute = [&](int buf) {
+        const int q = fr >> 2, pp = fr & 3;
+        const int fz = swz(8 * fg + q);
+        bf16x8 a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = tr_frag(&sA[buf][(8 * fg + q) * ROW + (((wm * 2 + i) ^ fz) << 4) + 4 * pp]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const int R = (fg + ky * D) * HPITCH + q + kx * D;  // halo pixel of patch pixel (fg, q) [and (fg, q + 4): + 4 rows] at this tap
+            const int hz = swzh(R);
+            bf16x8 b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = tr_frag(&sB[buf][R * ROW + (((wn * 2 + j) ^ hz) << 4) + 4 * pp]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+        }
+    };
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nchunks;
+        if (more) load_chunk();
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* o = out + (g.S > 1 ? (int64_t)split * g.Co * NT * g.Cip : 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + (wm * 2 + i) * 16 + fg * 4 + e;
+                    const int ci = ci0 + (wn * 2 + j) * 16 + fr;
+                    if (co < g.Co && ci < g.Ci) {
+                        float* d = (g.S == 1 && g.oihw) ? o + ((int64_t)co * g.Ci + ci) * NT + t
+                                                        : o + ((int64_t)co * NT + t) * g.Cip + ci;
+                        float v = acc[t][i][j][e];
+                        if (g.S == 1 && g.accumulate) v += *d;
+                        *d = v;
+                    }
+                }
+}
+
 // dw (+)= sum_s slab[s].  A 256-thread block owns 64 consecutive packed elements: 16 lanes x float4 cover them, and the 16
 // lane-groups each add every 16th slab with four 16-byte loads in flight (the old one-float-per-lane loop was pure load
 // latency: 64 dependent 256-byte reads per wave).  The 16 partial sums are combined in a fixed order -> deterministic.
@@ -675,6 +826,11 @@ __global__ __launch_bounds__(256, 2) void wgrad128_kernel(const bf16_t* __restri
                                                           float* __restrict__ out, const WGeom g) {
     wgrad_body128<PK>(x, dy, out, g, blockIdx.x);
 }
+
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                            float* __restrict__ out, const WGeom g) {
+    wgrad_halo_body(x, dy, out, g, blockIdx.x);
+}
 template <int NT>
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                  float* __restrict__ out, const WGeom g) {
@@ -693,10 +849,10 @@ struct WJob {
     float* out;            // slabs (S > 1) or dw
     float* dw;
     WGeom g;
-    int32_t kind;          // 0: per-tap blocks (64 x 64 tiles), 1: all-taps blocks, 3: per-tap blocks with 128 x 128 tiles
+    int32_t kind;          // 0: per-tap blocks (64 x 64 tiles), 1: all-taps blocks, 3: per-tap blocks with 128 x 128 tiles, 4: halo-tile all-taps
     int32_t dtype;
-    int32_t blocks[4];     // blocks of this job in the per-tap / all-taps / reduce / 128-tile launch
-    int32_t start[4];      // first block of this job in each launch
+    int32_t blocks[5];     // blocks of this job in the per-tap / all-taps / reduce / 128-tile / halo-tile launch
+    int32_t start[5];      // first block of this job in each launch
     int64_t n_out;
     double flops, bytes;
     LazyIn lx;             // deferred BatchNorm + act segments of x (nseg == 0: plain)
@@ -738,6 +894,12 @@ __global__ __launch_bounds__(256, 2) void wgrad128_grouped_kernel(const WJob* __
     wgrad_body128<PK>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
                       xcd_local(blockIdx.x - jobs[l].start[3], jobs[l].blocks[3]));
 }
+__global__ __launch_bounds__(256, 2) void wgrad_halo_grouped_kernel(const WJob* __restrict__ jobs, int n) {
+    const int l = find_job(jobs, n, blockIdx.x, 4);
+    const WGeom g = jobs[l].g;
+    wgrad_halo_body((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
+                    xcd_local(blockIdx.x - jobs[l].start[4], jobs[l].blocks[4]));
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     __shared__ float part[16][65];
     const int l = find_job(jobs, n, blockIdx.x, 2);
@@ -757,6 +919,25 @@ inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
     // measured (tools/sweep_wgrad.sh): sharing dy across the taps wins on the large maps (P >= 32k pixels: Focus, the stride-2
     // stem, 160x160 bottlenecks, FFM); on the small maps the per-tap blocks' 9x higher block count matters more
     if (mode < 0 && npix(dy) < 32768) return false;
+    const bool vl = (dy->c % 8 == 0) && (x->c % 8 == 0) && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) &&
+                    ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
+    const bool fits = (npix(x) * x->ldc < (1ll << 30)) && (npix(dy) * dy->ldc < (1ll << 30));
+    return vl && fits;
+}
+
+// halo-tile all-taps kernel: same-size 3x3 / stride 1 / pad = dilation = 1..3
+inline bool use_halo(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p) {
+    // Measured (MI355X): a block of this kernel is 20-25 % faster than an all-taps block on every 3x3 shape of both configurations
+    // (tools/bench_wgrad_kinds.py: 155-165 -> 118-130 us for a 4096-pixel range), but as a FIFTH grouped launch it splits the
+    // all-taps launch in two under-filled ones (the stride-2 stems stay behind): config 3 4.70 -> 4.82 ms per step (4.72 with a
+    // finer split, DSN_WGRAD_MINPX=1024), config 5 23.20 -> 23.02 ms.  Off by default (DSN_WGRAD_HALO=2: from
+    // DSN_WGRAD_HALO_MINPX pixels up; 1: every eligible layer) until the stride-2 layers can take it as well.
+    static const int mode = [] { const char* e = getenv("DSN_WGRAD_HALO"); return e ? atoi(e) : 0; }();
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_HALO_MINPX"); return e ? atoi(e) : 32768; }();
+    if (mode == 0 || x->dtype != DSN_BF16) return false;
+    if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->dil < 1 || p->dil > 3 || p->pad != p->dil || x->h != dy->h || x->w != dy->w)
+        return false;
+    if (mode == 2 && npix(dy) < minpx) return false;
     const bool vl = (dy->c % 8 == 0) && (x->c % 8 == 0) && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) &&
                     ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);
     const bool fits = (npix(x) * x->ldc < (1ll << 30)) && (npix(dy) * dy->ldc < (1ll << 30));
@@ -798,12 +979,18 @@ extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const d
     if (!x || !dy || !p) return 0;
     WGeom g{};
     g.P = (int32_t)npix(dy);
-    const bool at = use_alltaps(x, dy, p);
+    const bool hl = use_halo(x, dy, p);
+    const bool at = hl || use_alltaps(x, dy, p);
     const int tb = use_tile128(x, dy, p, at) ? TB2 : TB;
     g.tiles_co = (dy->c + tb - 1) / tb;
     g.tiles_ci = (x->c + tb - 1) / tb;
     g.KH = p->kh; g.KW = p->kw;
-    const int S = choose_split(g, at, tb == TB2);
+    int S = choose_split(g, at, tb == TB2);
+    if (hl) {       // (the split is re-derived on whole patches: same arithmetic as make_job)
+        const int64_t np = (int64_t)x->n * ((dy->h + 3) / 4) * ((dy->w + 7) / 8);
+        const int64_t ppb = (np + S - 1) / S;
+        S = (int)((np + ppb - 1) / ppb);
+    }
     const int64_t row = ci_pad > x->c ? ci_pad : x->c;
     return S > 1 ? (int64_t)S * dy->c * p->kh * p->kw * row * sizeof(float) : 0;
 }
@@ -825,8 +1012,9 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.Co = dy->c; g.Ci = x->c; g.Cip = ci_pad;
     g.KH = p->kh; g.KW = p->kw; g.stride = p->stride; g.pad = p->pad; g.dil = p->dil;
     g.yld = dy->ldc; g.xld = x->ldc;
-    const bool alltaps = use_alltaps(x, dy, p);
-    bool t128 = use_tile128(x, dy, p, alltaps);
+    const bool halo = use_halo(x, dy, p) && (!oihw || ci_pad >= 0);
+    const bool alltaps = !halo && use_alltaps(x, dy, p);
+    bool t128 = use_tile128(x, dy, p, alltaps || halo);
     {   // (the 128-tile kernel exists for the 16-byte paths only: the same conditions as *vec_out below)
         const int es0 = 2;
         t128 = t128 && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) && ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0) &&
@@ -835,7 +1023,7 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     }
     const int tb = t128 ? TB2 : TB;
     g.tiles_co = (g.Co + tb - 1) / tb; g.tiles_ci = (g.Ci + tb - 1) / tb;
-    g.S = choose_split(g, alltaps, t128);
+    g.S = choose_split(g, alltaps || halo, t128);
     static const int gpk = [] {
         const char *e = getenv("DSN_WGRAD_GPK"), *f = getenv("DSN_WGRAD_T128_PK");
         return ((e && atoi(e) == 64) || (f && atoi(f) == 64)) ? 64 : 32;
@@ -843,6 +1031,13 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     const int PK = gpk;       // pixel ranges are multiples of the largest chunk any kernel variant may use
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
+    if (halo) {     // the unit of work is a 4 x 8 patch: P and ppb count patches from here on (flops / bytes below use npix)
+        g.npx = (g.Wo + 7) / 8; g.npy = (g.Ho + 3) / 4;
+        const int S0 = choose_split(g, true, false);
+        g.P = dy->n * g.npy * g.npx;
+        g.ppb = (g.P + S0 - 1) / S0;
+        g.S = (g.P + g.ppb - 1) / g.ppb;
+    }
     g.accumulate = p->accumulate;
     g.oihw = oihw ? 1 : 0;
     g.CiLoad = x->c;
@@ -869,13 +1064,13 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.dy_bytes = (uint32_t)(yb < (1ll << 31) ? yb : 0);
     *job = WJob{};
     job->x = x->ptr; job->dy = dy->ptr; job->out = out; job->dw = dw; job->g = g;
-    job->kind = alltaps ? 1 : (t128 ? 3 : 0);
+    job->kind = halo ? 4 : alltaps ? 1 : (t128 ? 3 : 0);
     job->dtype = x->dtype;
-    job->blocks[job->kind] = g.tiles_ci * g.tiles_co * (alltaps ? 1 : g.KH * g.KW) * g.S;
+    job->blocks[job->kind] = g.tiles_ci * g.tiles_co * ((alltaps || halo) ? 1 : g.KH * g.KW) * g.S;
     job->blocks[2] = g.S > 1 ? (int32_t)((n_out + 63) / 64) : 0;
     job->n_out = n_out;
-    job->flops = 2.0 * g.P * g.Co * g.Ci * g.KH * g.KW;
-    job->bytes = ((double)npix(x) * g.Ci + (double)g.P * g.Co) * es + (double)n_out * 4;
+    job->flops = 2.0 * (double)npix(dy) * g.Co * g.Ci * g.KH * g.KW;
+    job->bytes = ((double)npix(x) * g.Ci + (double)npix(dy) * g.Co) * es + (double)n_out * 4;
     return DSN_OK;
 }
 
@@ -913,7 +1108,9 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     dim3 grid(job.blocks[job.kind]), block(256);
     {
         ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), job.flops, job.bytes, st);
-        if (job.kind == 3) {
+        if (job.kind == 4) {
+            hipLaunchKernelGGL(wgrad_halo_kernel, grid, block, 0, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
+        } else if (job.kind == 3) {
             hipLaunchKernelGGL(wgrad128_kernel<32>, grid, block, 0, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
         } else if (job.kind == 1) {
             alltaps_attr_once();
@@ -981,26 +1178,26 @@ extern "C" int dsn_conv2d_wgrad_plan_lazy(const dsn_tensor* x, const dsn_lazy_in
                       "conv wgrad plan: lazy segment %d must carry scale / shift arrays over channels inside x", i);
         if (s.c0 % 8 || s.c1 % 8) DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: lazy segment bounds must be multiples of 8");
     }
-    if (((WJob*)job_out)->kind == 3)
-        DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: the 128 x 128-tile kernel does not apply deferred transforms (materialise x)");
+    if (((WJob*)job_out)->kind >= 3)
+        DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: the 128 x 128-tile / halo-tile kernels do not apply deferred transforms (materialise x)");
     ((WJob*)job_out)->lx = *lx;
     return DSN_OK;
 }
 
 // jobs_host: n planned jobs, contiguous.  Assigns every job its first block in each of the three launches (in place) and
 // returns the grid sizes + totals in launch_out[10] = {grid per-tap, grid all-taps, grid reduce, dtype, flops, bytes,
-// reduce bytes, any deferred x, grid 128-tile, 0} (doubles).  Upload the array AFTER this call.
+// reduce bytes, any deferred x, grid 128-tile, grid halo-tile} (doubles).  Upload the array AFTER this call.
 extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* launch_out) {
     DSN_CHECK_ARG(jobs_host && n > 0 && launch_out, "conv wgrad plan_finish: bad arguments");
     WJob* jobs = (WJob*)jobs_host;
     // longest blocks first: a block's life is its pixel range, and the hardware dispatches blocks in index order -- heavy
     // jobs at the end of the grid would leave a tail of a few long blocks on an otherwise drained chip
     std::stable_sort(jobs, jobs + n, [](const WJob& a, const WJob& b) { return a.g.ppb > b.g.ppb; });
-    int64_t start[4] = {0, 0, 0, 0};
+    int64_t start[5] = {0, 0, 0, 0, 0};
     double flops = 0, bytes = 0, rbytes = 0;
     for (int i = 0; i < n; ++i) {
         DSN_CHECK_ARG(jobs[i].dtype == jobs[0].dtype, "conv wgrad plan_finish: mixed dtypes in one queue");
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 5; ++k) {
             jobs[i].start[k] = (int32_t)start[k];
             start[k] += jobs[i].blocks[k];
         }
@@ -1008,7 +1205,7 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
         bytes += jobs[i].bytes;
         if (jobs[i].g.S > 1) rbytes += (double)(jobs[i].g.S + 1) * jobs[i].n_out * 4;
     }
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 5; ++k)
         DSN_CHECK_ARG(start[k] < (1ll << 31), "conv wgrad plan_finish: too many blocks");
     launch_out[0] = (double)start[0]; launch_out[1] = (double)start[1]; launch_out[2] = (double)start[2];
     launch_out[3] = (double)jobs[0].dtype; launch_out[4] = flops; launch_out[5] = bytes; launch_out[6] = rbytes;
@@ -1016,16 +1213,20 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
     for (int i = 0; i < n; ++i) any_lazy |= jobs[i].lx.nseg > 0;
     launch_out[7] = (double)any_lazy;       // some x operand carries deferred-BatchNorm segments: the LAZY instantiations run
     launch_out[8] = (double)start[3];       // grid of the 128 x 128-tile launch
-    launch_out[9] = 0.0;
+    launch_out[9] = (double)start[4];       // grid of the halo-tile all-taps launch
     return DSN_OK;
 }
 
 // jobs_dev: the device copy of the finished plan.  Three launches: per-tap blocks, all-taps blocks, slab reductions.
+// (The gather launches -- per-tap 64- / 128-wide tiles, halo-tile, all-taps -- are independent of each other; forking them onto side
+//  streams so that their tails overlap was measured: 4.81 -> 6.57 ms per config-3 step, 23.1 -> 25.6 ms on config 5.  Concurrent
+//  queues do not interleave blocks the way one grid does on this part; they stay on one stream.)
 extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const double* launch, void* stream) {
     DSN_CHECK_ARG(jobs_dev && n > 0 && launch, "conv wgrad run: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const WJob* jobs = (const WJob*)jobs_dev;
     const int g0 = (int)launch[0], g1 = (int)launch[1], g2 = (int)launch[2], dtype = (int)launch[3];
+    const int g3 = (int)launch[8], g4 = (int)launch[9];
     const bool lazy = launch[7] != 0.0;
     {
         ProfScope prof(KID_WGRAD + (dtype == DSN_BF16 ? 1 : 0), launch[4], launch[5], st);
@@ -1042,12 +1243,15 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
             else
                 hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 32>), dim3(g0), dim3(256), 0, st, jobs, n);
         }
-        const int g3 = (int)launch[8];
         if (g3 > 0) {
             DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: 128-tile jobs are bf16 only");
             static const int pk128 = [] { const char* e = getenv("DSN_WGRAD_T128_PK"); return (e && atoi(e) == 64) ? 64 : 32; }();
             if (pk128 == 64) hipLaunchKernelGGL(wgrad128_grouped_kernel<64>, dim3(g3), dim3(256), 0, st, jobs, n);
             else hipLaunchKernelGGL(wgrad128_grouped_kernel<32>, dim3(g3), dim3(256), 0, st, jobs, n);
+        }
+        if (g4 > 0) {
+            DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: halo-tile jobs are bf16 only");
+            hipLaunchKernelGGL(wgrad_halo_grouped_kernel, dim3(g4), dim3(256), 0, st, jobs, n);
         }
         if (g1 > 0) {
             DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: all-taps jobs are bf16 only");

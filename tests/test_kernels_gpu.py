@@ -67,6 +67,11 @@ CONV_CASES = [
     (4, 256, 66, 64, 128, 3, 1, 1, 1),   # ragged last pixel range
     (4, 128, 130, 128, 128, 3, 2, 1, 1), # stride 2: the input cursor is re-derived per chunk
     (4, 128, 64, 64, 128, 3, 1, 2, 2),   # dilation
+    # wgrad.hip halo-tile all-taps kernel (bf16, same-size 3x3, >= 32768 output pixels): 4 x 8 patches, ragged at both borders
+    (8, 64, 70, 67, 96, 3, 1, 1, 1),
+    (2, 16, 130, 131, 32, 3, 1, 1, 1),
+    (2, 64, 130, 131, 64, 3, 1, 2, 2),   # dilation 2: 8 x 12 halo
+    (2, 32, 140, 128, 32, 3, 1, 3, 3),   # dilation 3: 10 x 14 halo (RFB2)
 ]
 
 
@@ -569,3 +574,46 @@ def test_pyramid_multi_launches_equal_the_single_ones(ops, dtype):
                                    [ops.new_act(n, oc, k, k, dtype, "cuda") for k in ks])
     for a, b in zip(ds, dm):
         assert torch.equal(a, b)
+
+
+def test_wgrad_halo_tile_kernel_in_its_own_process():
+    """The halo-tile all-taps weight-gradient kernel is off by default (DSN_WGRAD_HALO, read once per process): run it in a child
+    process against the default kernels' result for same-size 3x3 layers at dilation 1, 2, 3 with ragged 4 x 8 patches, through
+    the single-layer entry point and through the grouped launches."""
+    import os, subprocess, sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, ".")
+import desenet_amd
+from desenet_amd import hip_ops as ops
+dt = torch.bfloat16
+desenet_amd.set_compute_dtype(dt)
+out = {}
+queue = ops.WgradQueue(torch.device("cuda", torch.cuda.current_device())) if sys.argv[1] == "queue" else None
+for i, (n, ci, h, w, co, d) in enumerate([(8, 64, 70, 67, 96, 1), (2, 16, 130, 131, 32, 1), (2, 64, 130, 131, 64, 2), (2, 32, 140, 128, 32, 3)]):
+    g = torch.Generator(device="cuda").manual_seed(i)
+    x = ops.as_act((torch.randn((n, ci, h, w), device="cuda", generator=g)).to(dt))
+    dy = ops.as_act((torch.randn((n, co, h, w), device="cuda", generator=g)).to(dt))
+    dw = torch.zeros(co, ci, 3, 3, device="cuda")
+    ops.conv2d_wgrad(x, dy, dw, ci, ops.conv_params(3, 1, d, d, accumulate=True), oihw=True, queue=queue)
+    out[i] = dw
+if queue is not None:
+    queue.flush()
+torch.cuda.synchronize()
+torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[2])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("ref", {"DSN_WGRAD_HALO": "0"}), ("halo", {"DSN_WGRAD_HALO": "1"}), ("haloq", {"DSN_WGRAD_HALO": "1"})):
+            path = os.path.join(td, tag + ".pt")
+            subprocess.run([sys.executable, "-c", code, "queue" if tag == "haloq" else "single", path], cwd=root, check=True,
+                           env=dict(os.environ, **env), timeout=300)
+            res[tag] = torch.load(path)
+        for k, ref in res["ref"].items():
+            scale = float(ref.abs().max())
+            assert scale > 0
+            for tag in ("halo", "haloq"):
+                err = float((res[tag][k] - ref).abs().max())
+                assert err <= 2e-4 * scale, (tag, k, err / scale)      # fp32 accumulation in a different order
