@@ -235,8 +235,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             // outstanding vector-memory operations a wave may leave behind the ones it needs (issue order of iteration (s, 0):
             // W(f + 2), [MULTI: halo(s + 1)], [LZ: IH stores of z]; W(f + 2) alone in the other iterations)
             constexpr int EX = (MULTI ? IH : 0) + (LZ ? IH : 0);
-            if (EX > 0 && (t == 1 || t == 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BR + EX) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BR) : "memory");
+            // lgkmcnt(0): the compiler may sink the MFMAs of the previous tap -- and with them the wait for their fragment reads --
+            // BELOW this barrier (registers only: the "memory" clobbers do not hold them), which would leave ds_reads of ring stage
+            // `lbuf` merely issued when another wave's LDS-DMA starts overwriting it after the barrier.  Observed: sporadic wrong
+            // patches on >= 800-block bf16 launches (tests/test_kernels_gpu.py: the 8 x 70 x 67 case).
+            if (EX > 0 && (t == 1 || t == 2)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + EX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (LZ && t == 0) {                  // the slab's patch has landed (and the table is complete): transform it once

@@ -38,3 +38,40 @@ def test_large_halo_tile_forward_and_dgrad_vs_aten():
     env = dict(os.environ, DSN_HALO="2")
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "halo large OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_lds_dma_conv_kernels_at_production_grid_sizes(dtype):
+    """The LDS-DMA kernels (halo-tile 3x3, one-trip 1x1, the implicit GEMM's ring) recycle LDS stages behind raw s_barriers: a
+    fragment read that is merely ISSUED when the barrier falls can be overtaken by the next DMA into its stage.  That only shows
+    on grids of several resident-block generations (>= ~800 blocks: sporadic wrong 8 x 8 patches on config 3's 64 -> 64 @ 80 x 80
+    layer before the lgkmcnt(0) in front of the barriers), which the small unit-test shapes never reach -- so the layer shapes of
+    config 3 run here at batch 8, three launches each, forward and input gradient, against ATen on the CPU."""
+    import torch
+    import torch.nn.functional as F
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    desenet_amd.set_compute_dtype(dt)
+    try:
+        tol = 2e-2 if dt == torch.bfloat16 else 1e-3
+        g = torch.Generator().manual_seed(5)
+        q = lambda t: t.to(dt).float()
+        for (n, ci, h, w, co, k) in [(8, 64, 80, 80, 64, 3), (8, 64, 80, 80, 128, 3), (8, 128, 80, 80, 64, 3), (8, 64, 70, 67, 96, 3),
+                                     (8, 128, 80, 80, 128, 1), (8, 64, 160, 160, 64, 1), (8, 256, 40, 40, 256, 3)]:
+            x = torch.randn((n, ci, h, w), generator=g)
+            wt = torch.randn((co, ci, k, k), generator=g) * 0.1
+            ref = F.conv2d(q(x), q(wt), None, 1, k // 2)
+            gy = torch.randn(tuple(ref.shape), generator=g)
+            ref_dx = F.conv_transpose2d(q(gy), q(wt), None, 1, k // 2)
+            xd, gd = ops.as_act(x.cuda().to(dt)), ops.as_act(gy.cuda().to(dt))
+            wf, wd = ops.pack_weight_fwd(wt.cuda(), dt), ops.pack_weight_dgrad(wt.cuda(), dt)
+            p = ops.conv_params(k, 1, k // 2, 1)
+            for rep in range(3):
+                y = ops.conv2d_fwd(xd, wf, None, None, ops.new_act(n, co, h, w, dt, "cuda"), p)
+                dx = ops.conv2d_dgrad(gd, wd, ops.new_act(n, ci, h, w, dt, "cuda"), p)
+                e1 = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
+                e2 = float((dx.float().cpu() - ref_dx).abs().max() / ref_dx.abs().max())
+                assert e1 < tol and e2 < tol, ((n, ci, h, w, co, k), rep, e1, e2)
+    finally:
+        desenet_amd.set_compute_dtype(torch.float32)
