@@ -474,7 +474,7 @@ def test_teacher_forced_layers_bf16_at_640(net, training):
     dsn, m = net
     cfg = load_cfg()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    x = synth_images(1, 640, 5)
+    x = synth_images(8, 640, 5)       # the headline batch: kernels see their production grid sizes (several block generations per CU)
     with torch.no_grad():
         out, seg, saved = R.forward(cfg, copy.deepcopy(sd), x, training=training, keep=range(26))
     saved = dict(saved)
