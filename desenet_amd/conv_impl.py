@@ -344,13 +344,16 @@ def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
 _BNRED = int(_os.environ.get("DSN_BNRED", "2"))
 
 
-def _bnred_plan(tape, x_in, dx, residual):
+def _bnred_plan(tape, x_in, dx, residual, rng=None):
     """The input-gradient launch about to write dx completes dz for the BatchNorm block(s) whose output the view x_in is (the
     caller vouches for that: fuse_up): (dsn_bnred, marks) so that their backward sums ride in its epilogue, or (None, ()) when the
     blocks / layouts cannot take it (more than two blocks, SyncBatchNorm, channel ranges that are not whole 16-byte vectors)."""
     if not _BNRED or tape is None or x_in is None:
         return None, ()
     hits = tape.bn_producers(x_in)
+    if hits and isinstance(rng, tuple):  # only channels [lo, hi) of dx are complete (RFB2: ConvLinear's input is [x0 | x1 | x2 | x3]
+        lo, hi = rng                     # and x0, x1 still receive the gradient of their other consumer)
+        hits = [h for h in hits if h[0] >= lo and h[1] <= hi]
     if not hits or len(hits) > 2:       # DSN_BNRED_MAXSEG
         return None, ()
     vec = 4 if dx.dtype == torch.float32 else 8
@@ -456,7 +459,7 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
     fuse_up: the caller vouches that the dx this call writes (with `residual` and, if acc, what dx already holds) is the COMPLETE
     gradient of the block's input -- no other contribution follows.  Where that input is the output of BatchNorm block(s) of this
     tape, their backward sums are then formed in the dgrad epilogue (dsn_conv2d_dgrad_bnred) and their own backward skips its
-    reduction launch.
+    reduction launch.  A (lo, hi) tuple instead of True restricts the claim to those channels of the block's input.
     A dz whose rows are padded with ZEROS up to a multiple of the vector width (ops.new_act(ldc_align=...), padding cleared by
     its producer -- Detect.bwd does this for its 33-channel heads) takes the 16-byte paths: the weight gradient ignores the
     padding lanes, the input gradient runs over the padded K axis with zero-padded weights."""
@@ -518,10 +521,10 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
             # stride-2 3x3: one 2x2 stride-1 conv over dy + depth-to-space store (weights packed by the model's WeightBank)
             # (measured A/B on DeSeNet-s, 3 x 100 steps each: 4.830 ms without any fused sums, 4.725 with the stride-1 launches only,
             #  4.707 with the two stride-2 stems as well -- DSN_BNRED=0 / 1 / 2)
-            red, marks = _bnred_plan(tape, rec.get("x_in"), dx, None) if (fuse_up and residual is None and _BNRED >= 2) else (None, ())
+            red, marks = _bnred_plan(tape, rec.get("x_in"), dx, None, fuse_up) if (fuse_up and residual is None and _BNRED >= 2) else (None, ())
             ops.conv2d_dgrad_s2(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc), red=red)
         else:
-            red, marks = _bnred_plan(tape, rec.get("x_in"), dx, residual) if fuse_up else (None, ())
+            red, marks = _bnred_plan(tape, rec.get("x_in"), dx, residual, fuse_up) if fuse_up else (None, ())
             ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc), residual=residual,
                              red=red)
             residual = None

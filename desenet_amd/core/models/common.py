@@ -320,8 +320,12 @@ class _ConvBnAct(nn.Sequential):
     def fwd(self, x, tape=None, out=None, lazy_out=False):
         return conv_block_fwd(_as_input(x), self[0], self[1], ACT_SILU, self.training, tape, out, lazy_out=lazy_out)
 
-    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
-        return conv_block_bwd(tape, dy, dx, acc, need_dx)
+    def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
+        return conv_block_bwd(tape, dy, dx, acc, need_dx, fuse_up=fuse_up)
+
+
+import os as _os
+_RFB_FUSE = int(_os.environ.get("DSN_BNRED_RFB", "1"))
 
 
 class RFB2(HipModule):
@@ -365,18 +369,21 @@ class RFB2(HipModule):
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         i = self.branch1[0].in_channels
         merged = tape.pop() == "rfb-merged"
+        # BatchNorm backward sums ride in the launch that completes a gradient (conv_impl.conv_block_bwd: fuse_up): ConvLinear's
+        # for x2 and x3 (its only consumer), branch2's and branch1's accumulating dgrads for x1 and x0, branch0[1]'s for t
+        fu, fr = (True, (2 * i, 4 * i)) if _RFB_FUSE else (False, False)
         if merged:
             n, _, h, w = dy.shape
             d5 = ops.new_act(n, 5 * i, h, w, dy.dtype, dy.device)     # [d x0 | d x1 | d x2 | d x3 | d t]
-            dcat = self.ConvLinear.bwd(tape, dy, d5[:, :4 * i], False)
+            dcat = self.ConvLinear.bwd(tape, dy, d5[:, :4 * i], False, fuse_up=fr)
         else:
-            dcat = self.ConvLinear.bwd(tape, dy)
-        d1 = self.branch2.bwd(tape, dcat[:, 2 * i:3 * i], dcat[:, i:2 * i], True)     # dx1 += ...
-        d0 = self.branch1.bwd(tape, d1, dcat[:, :i], True)                            # dx0 += ...
+            dcat = self.ConvLinear.bwd(tape, dy, fuse_up=fr)
+        d1 = self.branch2.bwd(tape, dcat[:, 2 * i:3 * i], dcat[:, i:2 * i], True, fuse_up=fu)     # dx1 += ...
+        d0 = self.branch1.bwd(tape, d1, dcat[:, :i], True, fuse_up=fu)                            # dx0 += ...
         if merged:
-            self.branch0[1].bwd(tape, d0, d5[:, 4 * i:], False)
+            self.branch0[1].bwd(tape, d0, d5[:, 4 * i:], False, fuse_up=fu)
             return pair_block_bwd(tape, d5[:, 3 * i:], dx, acc, need_dx)
-        dt = self.branch0[1].bwd(tape, d0)
+        dt = self.branch0[1].bwd(tape, d0, fuse_up=fu)
         dx = self.branch0[0].bwd(tape, dt, dx, acc, need_dx)
         return self.branch3[0].bwd(tape, dcat[:, 3 * i:], dx, True, need_dx)
 
