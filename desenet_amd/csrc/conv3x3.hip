@@ -13,7 +13,8 @@
 //     (ty + ky*d, tx + kx*d): no global address arithmetic, no A traffic inside the tap loop;
 //   * the weights of (slab, tap) stream through a 3-stage LDS-DMA ring (they are shared by every block: L2 hits);
 //   * one raw s_barrier per tap, counted s_waitcnt vmcnt, no ordinary global load inside the loop (cdna_hip_programming.md 5).
-// LDS rows are 128 B = 8 slots of 16 B, slot s of row p at s ^ ((p >> 1) & 7); LDS-DMA writes lane-linearly, so the swizzle is
+// LDS rows are 128 B = 8 slots of 16 B, slot s of weight row r at s ^ ((r >> 1) & 7) and of halo pixel (hy, hx) at s ^ hswz(hy, hx);
+// LDS-DMA writes lane-linearly, so the swizzle is
 // applied on the SOURCE side (the lane that owns physical slot v fetches logical slot v ^ swz(p)).
 // Data gradient = the same kernel over dy with the taps mirrored (tap k reads halo offset (2 - k) * d) and the weights in the
 // [Ci][KH][KW][Co] layout.  Epilogue as igemm.hip: bias, activation, residual, accumulate, BatchNorm partial sums, 16-byte stores.
@@ -59,6 +60,13 @@ template <> struct HMma<bf16_t> {
 constexpr int ROWB = 128;
 constexpr int CPAD = 4;
 constexpr int NBR = 3;               // stages of the weight ring
+
+// Halo-patch swizzle: the 16 lanes of one fragment-read pass address 8 consecutive halo pixels of TWO patch rows (8 x 8 patch) or 16
+// of one row (8 x 16).  A halo row is an even number of pixels, so the half of the 256-byte bank row a pixel lands in is its COLUMN
+// parity; XOR-ing the slot with (column >> 1) ^ (row parity << 2) gives the 16 lanes 16 different (half, slot) positions for every
+// tap offset.  (The first version used the linear pixel index, (p >> 1) & 7: with a 10-pixel halo row the second patch row wraps
+// onto the first one's values -- SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 1.5 on this kernel against 0.06 in the implicit GEMM.)
+__device__ __forceinline__ int hswz(int hy, int hx) { return ((hx >> 1) & 7) ^ ((hy & 1) << 2); }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
         const int hy = p / g.HW, hx = p - hy * g.HW;
         const int gy = y0 - g.d + hy, gx = x0 - g.d + hx;
         const bool ok = p < g.NP && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-        const int ls = (lane & 7) ^ ((p >> 1) & 7);                         // logical slot this lane fetches
+        const int ls = (lane & 7) ^ hswz(hy, hx);                           // logical slot this lane fetches
         hoff[j] = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + ls * VEC) * (uint32_t)sizeof(T) : OOB;
         if constexpr (LZ) {
             const bool interior = ok && tn == 0 && hy >= g.d && hy < g.d + TH && hx >= g.d && hx < g.d + TW;
@@ -182,11 +190,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     };
 
     // ---- fragment addressing ------------------------------------------------------------------------------------------------
-    int hp0[MI];                                   // halo pixel of A row (wm*MI + i)*16 + fr at tap offset (0, 0)
+    int hp0[MI], hy0[MI], hx0[MI];                 // halo pixel (and its row / column) of A row (wm*MI + i)*16 + fr at tap offset (0, 0)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int r = (wm * MI + i) * 16 + fr;
-        hp0[i] = (r / TW) * g.HW + (r % TW);
+        hy0[i] = r / TW;
+        hx0[i] = r % TW;
+        hp0[i] = hy0[i] * g.HW + hx0[i];
     }
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -194,7 +204,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](const unsigned char* hb, int toff, int bbuf) {
+    auto compute = [&](const unsigned char* hb, int oy, int ox, int bbuf) {
+        const int toff = oy * g.HW + ox;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32x4 fa[MI], fb[NI];
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int p = hp0[i] + toff;
-                fa[i] = *reinterpret_cast<const u32x4*>(hb + p * ROWB + ((slot ^ ((p >> 1) & 7)) << 4));
+                fa[i] = *reinterpret_cast<const u32x4*>(hb + p * ROWB + ((slot ^ hswz(hy0[i] + oy, hx0[i] + ox)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             if (LZ && t == 0) store_z(s);
             const int ky = t / 3, kx = t - ky * 3;
             const int oy = (g.flip ? 2 - ky : ky) * g.d, ox = (g.flip ? 2 - kx : kx) * g.d;
-            compute(hb, oy * g.HW + ox, wbuf);
+            compute(hb, oy, ox, wbuf);
             wbuf = wbuf + 1 == NBR ? 0 : wbuf + 1;
             lbuf = lbuf + 1 == NBR ? 0 : lbuf + 1;
         }
