@@ -263,3 +263,58 @@ def test_two_rank_graph_step_equals_sum_of_rank_gradients(split):
             continue                        # BatchNorm running statistics are per rank (no --sync-bn), as in the reference
         assert torch.equal(r[0][k], r[1][k]), k
         assert rel_err(r[0][k], v.cpu()) < 5e-2, k
+
+
+def test_training_trajectory_equals_the_conservative_kernels(tmp_path):
+    """Config 3 at its real size (batch 8, 640 x 640, bf16, graph replay): 12 optimizer steps with the default kernel selection --
+    LDS-DMA convolutions (halo-tile 3x3, one-trip 1x1, ring), BatchNorm sums in dgrad epilogues, 128-wide weight-gradient tiles --
+    against the same steps with every one of them switched off (implicit GEMM, stand-alone reductions, 64-wide tiles).  Both are
+    bf16 pipelines of the same arithmetic in a different summation order, so the loss curves must agree to a few 1e-3; a kernel
+    that misbehaves only at production grid sizes (the ring-barrier race of round 2) shows here as a diverging curve."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, sys, torch
+sys.path.insert(0, ".")
+import bench, desenet_amd
+from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN, scale_hyp
+from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+from desenet_amd.graph import GraphedTrainStep
+from desenet_amd.optim import FusedSGD
+from desenet_amd.parallel import FlatGradients, sgd_param_groups
+from desenet_amd.synth import synth_images, synth_targets
+dev = torch.device("cuda", 0)
+desenet_amd.set_compute_dtype(torch.bfloat16)
+m = bench.build_model(dev).train()
+m.hyp = scale_hyp(6, 640)
+flat = FlatGradients(m.parameters())
+opt = FusedSGD(sgd_param_groups(m), lr=0.01, momentum=0.937, nesterov=True)
+cl, sl = ComputeLoss(m), SegmentationLosses()
+x = (synth_images(8, 640, 3) * 255).round().to(torch.uint8).to(dev)
+det_t, seg_t = synth_targets(8, 640, 3)
+det_t, seg_t = det_t.to(dev), seg_t.to(dev)
+def lg(det, seg, dl, sg):
+    out, d_det = cl.forward_backward(det, dl, gain=DETGAIN)
+    sout, d_seg = sl.forward_backward(seg, sg)
+    return (out, sout), d_det, d_seg
+step = GraphedTrainStep(m, lg, flat, opt, x, det_targets=det_t, seg_targets=seg_t, max_targets=256)
+losses = []
+for i in range(12):
+    out, sout = step(x, det_t, seg_t)
+    losses.append(float(out[0] + sout[0] * SEGGAIN))
+print("LOSSES " + json.dumps(losses))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    safe = {"DSN_HALO": "0", "DSN_DMA1X1": "0", "DSN_IGEMM_GL": "0", "DSN_BNRED": "0", "DSN_WGRAD_T128": "0"}
+    curves = {}
+    for tag, env in (("default", {}), ("conservative", safe)):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("LOSSES ")]
+        assert r.returncode == 0 and line, (tag, r.stdout[-500:], r.stderr[-1500:])
+        curves[tag] = json.loads(line[0][7:])
+    a, b = curves["default"], curves["conservative"]
+    assert all(x == x for x in a + b) and a[-1] < a[0]
+    worst = max(abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a, b))
+    assert worst < 2e-2, (worst, a, b)
