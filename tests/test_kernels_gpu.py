@@ -617,3 +617,24 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[2])
             for tag in ("halo", "haloq"):
                 err = float((res[tag][k] - ref).abs().max())
                 assert err <= 2e-4 * scale, (tag, k, err / scale)      # fp32 accumulation in a different order
+
+
+def test_copy_multi_stages_several_buffers_in_one_launch(ops):
+    """dsn_copy_multi: flat copies with zero-filled tails -- 16-byte and 4-byte paths, an empty source, a destination view."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 255, (8, 3, 64, 64), dtype=torch.uint8, generator=g).cuda()
+    rows = torch.rand((5, 6), generator=g).cuda()                       # 120 bytes: the 4-byte path
+    mask = torch.randint(0, 2, (8, 64, 64), dtype=torch.int64, generator=g).cuda()
+    d_img = torch.full_like(img, 7)
+    d_rows = torch.full((32, 6), 9.0, device="cuda")
+    d_mask = torch.full_like(mask, 5)
+    d_clear = torch.full((33,), 4.0, device="cuda")
+    ops.copy_multi([(d_img, img), (d_rows, rows), (d_mask, mask), (d_clear, None)])
+    torch.cuda.synchronize()
+    assert torch.equal(d_img, img) and torch.equal(d_mask, mask)
+    assert torch.equal(d_rows[:5], rows) and float(d_rows[5:].abs().max()) == 0
+    assert float(d_clear.abs().max()) == 0
+    with pytest.raises(ValueError):
+        ops.copy_multi([(d_rows, rows.double())])
+    with pytest.raises(RuntimeError):
+        ops.copy_multi([(d_rows[:2], rows)])                            # source larger than the destination
