@@ -614,11 +614,20 @@ __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x,
 constexpr int HPITCH = 16, HROWS = 10, HLOADS = 5;      // d <= 3: 10 x 14 halo pixels x 8 vectors <= 5 x 256
 __device__ __forceinline__ int swzh(int row) { return ((row >> 1) & 1) | (((row >> 4) & 1) << 1); }
 
+// S = 2 (3x3 / stride 2 / pad 1, the stem and downsampling layers): the patch's taps reach (2 * 3 + 3) x (2 * 7 + 3) = 9 x 17 input
+// pixels.  They are stored with a pitch of 18 rows plus ONE extra row for every second pair of halo rows, so that the rows a
+// 32-lane half reads -- hr = 2 fg + ky, hc = 2 q + kx: four same-parity rows per fg -- fall on opposite halves of the bank row for
+// the two values of fg, and (row >> 1) & 3 spreads the four of one fg over the four 32-byte groups.
+template <int S> __device__ __forceinline__ int halo_row(int hr, int hc) {
+    return S == 1 ? hr * HPITCH + hc : hr * 18 + hc + ((hr >> 1) & 1);
+}
+template <int S> __device__ __forceinline__ int halo_swz(int row) { return S == 1 ? swzh(row) : (row >> 1) & 3; }
+
+constexpr int HALO_A = 32 * TB, HALO_B = (HROWS * HPITCH + 8) * TB;      // elements per stage of the dy tile / the halo tile (stride 2: 8 * 18 + 16 + 1 rows)
+template <int S>
 __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ out,
-                                                const WGeom& g, int bid) {
-    constexpr int ROW = TB, NT = 9;
-    __shared__ __attribute__((aligned(16))) bf16_t sA[2][32 * ROW];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[2][HROWS * HPITCH * ROW];
+                                                const WGeom& g, int bid, bf16_t (*sA)[HALO_A], bf16_t (*sB)[HALO_B]) {
+    constexpr int ROW = TB, NT = 9;        // (the LDS stages belong to the kernel: both strides share one allocation)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
@@ -629,7 +638,7 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
     const int p_begin = split * g.ppb;                                  // (patches)
     const int p_end = (p_begin + g.ppb < g.P) ? p_begin + g.ppb : g.P;
     const int nchunks = p_end - p_begin;
-    const int D = g.dil, HWd = 8 + 2 * D, NHP = (4 + 2 * D) * HWd;      // halo width, halo pixels
+    const int D = g.dil, HWd = S == 1 ? 8 + 2 * D : 17, NHP = (S == 1 ? 4 + 2 * D : 9) * HWd;      // halo width, halo pixels
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.dy_bytes, 0x00020000);
     constexpr uint32_t OOB = 0xFFFFFFF0u;
@@ -645,7 +654,7 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
         hon[i] = hp < NHP;
         hr[i] = hp / HWd;
         hc[i] = hp - hr[i] * HWd;
-        hrow[i] = hr[i] * HPITCH + hc[i];
+        hrow[i] = halo_row<S>(hr[i], hc[i]);
     }
     const bool aok = co0 + v8 < g.Co, bok = ci0 + v8 < g.CiLoad;
     // patch cursor
@@ -666,7 +675,7 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             if (i >= 2 && !hon[i]) continue;             // (d = 1 needs two of the five)
-            const int iy = y0 - D + hr[i], ix = x0 - D + hc[i];
+            const int iy = y0 * S - D + hr[i], ix = x0 * S - D + hc[i];
             const bool ok = hon[i] && bok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (uint32_t)(((pn * g.Hi + iy) * g.Wi + ix) * (int)g.xld + ci0 + v8) * 2u : OOB, 0, 0);
         }
@@ -679,7 +688,7 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
         *reinterpret_cast<u32x4*>(&sA[buf][ak * ROW + (v8 ^ (swz(ak) << 4))]) = ra;
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i)
-            if (hon[i]) *reinterpret_cast<u32x4*>(&sB[buf][hrow[i] * ROW + (v8 ^ (swzh(hrow[i]) << 4))]) = rb[i];
+            if (hon[i]) *reinterpret_cast<u32x4*>(&sB[buf][hrow[i] * ROW + (v8 ^ (halo_swz<S>(hrow[i]) << 4))]) = rb[i];
     };
     f32x4 acc[NT][2][2];
 #pragma unroll
@@ -688,9 +697,9 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto tr_frag = [&](const bf16_t* base) -> bf16x8 {
+    auto tr_frag = [&](const bf16_t* base, int hi_rows) -> bf16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + hi_rows * ROW));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto compute = [&](int buf) {
@@ -698,15 +707,16 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
         const int fz = swz(8 * fg + q);
         bf16x8 a[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = tr_frag(&sA[buf][(8 * fg + q) * ROW + (((wm * 2 + i) ^ fz) << 4) + 4 * pp]);
+        for (int i = 0; i < 2; ++i) a[i] = tr_frag(&sA[buf][(8 * fg + q) * ROW + (((wm * 2 + i) ^ fz) << 4) + 4 * pp], 4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int ky = t / 3, kx = t - ky * 3;
-            const int R = (fg + ky * D) * HPITCH + q + kx * D;  // halo pixel of patch pixel (fg, q) [and (fg, q + 4): + 4 rows] at this tap
-            const int hz = swzh(R);
+            // halo pixel of patch pixel (fg, q) at this tap [and of (fg, q + 4): 4 S rows further, same halo row, same swizzle]
+            const int R = halo_row<S>(fg * S + ky * D, q * S + kx * D);
+            const int hz = halo_swz<S>(R);
             bf16x8 b[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = tr_frag(&sB[buf][R * ROW + (((wn * 2 + j) ^ hz) << 4) + 4 * pp]);
+            for (int j = 0; j < 2; ++j) b[j] = tr_frag(&sB[buf][R * ROW + (((wn * 2 + j) ^ hz) << 4) + 4 * pp], 4 * S);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -829,7 +839,10 @@ __global__ __launch_bounds__(256, 2) void wgrad128_kernel(const bf16_t* __restri
 
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                             float* __restrict__ out, const WGeom g) {
-    wgrad_halo_body(x, dy, out, g, blockIdx.x);
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][HALO_A];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][HALO_B];
+    if (g.stride == 2) wgrad_halo_body<2>(x, dy, out, g, blockIdx.x, sA, sB);
+    else wgrad_halo_body<1>(x, dy, out, g, blockIdx.x, sA, sB);
 }
 template <int NT>
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -897,8 +910,11 @@ __global__ __launch_bounds__(256, 2) void wgrad128_grouped_kernel(const WJob* __
 __global__ __launch_bounds__(256, 2) void wgrad_halo_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     const int l = find_job(jobs, n, blockIdx.x, 4);
     const WGeom g = jobs[l].g;
-    wgrad_halo_body((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
-                    xcd_local(blockIdx.x - jobs[l].start[4], jobs[l].blocks[4]));
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][HALO_A];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][HALO_B];
+    const int b = xcd_local(blockIdx.x - jobs[l].start[4], jobs[l].blocks[4]);
+    if (g.stride == 2) wgrad_halo_body<2>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, b, sA, sB);
+    else wgrad_halo_body<1>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, b, sA, sB);
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     __shared__ float part[16][65];
@@ -925,18 +941,19 @@ inline bool use_alltaps(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
     return vl && fits;
 }
 
-// halo-tile all-taps kernel: same-size 3x3 / stride 1 / pad = dilation = 1..3
+// halo-tile all-taps kernel: same-size 3x3 / stride 1 / pad = dilation = 1..3, and 3x3 / stride 2 / pad 1
 inline bool use_halo(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p) {
     // Measured (MI355X): a block of this kernel is 20-25 % faster than an all-taps block on every 3x3 shape of both configurations
-    // (tools/bench_wgrad_kinds.py: 155-165 -> 118-130 us for a 4096-pixel range), but as a FIFTH grouped launch it splits the
-    // all-taps launch in two under-filled ones (the stride-2 stems stay behind): config 3 4.70 -> 4.82 ms per step (4.72 with a
-    // finer split, DSN_WGRAD_MINPX=1024), config 5 23.20 -> 23.02 ms.  Off by default (DSN_WGRAD_HALO=2: from
-    // DSN_WGRAD_HALO_MINPX pixels up; 1: every eligible layer) until the stride-2 layers can take it as well.
-    static const int mode = [] { const char* e = getenv("DSN_WGRAD_HALO"); return e ? atoi(e) : 0; }();
+    // (tools/bench_wgrad_kinds.py: 155-165 -> 118-130 us for a 4096-pixel range).  While it could not take the stride-2 layers it
+    // only SPLIT the all-taps launch in two under-filled ones (config 3 4.70 -> 4.82 ms); with them it replaces that launch for
+    // every DeSeNet shape: config 3 4.690 -> 4.678 ms, config 5 23.31 -> 23.06 ms from the all-taps threshold up (mode 2, default);
+    // on every eligible layer (mode 1) the small maps lose their 9x block count: 4.727 ms.  DSN_WGRAD_HALO = 0 / 1 / 2.
+    static const int mode = [] { const char* e = getenv("DSN_WGRAD_HALO"); return e ? atoi(e) : 2; }();
     static const int minpx = [] { const char* e = getenv("DSN_WGRAD_HALO_MINPX"); return e ? atoi(e) : 32768; }();
     if (mode == 0 || x->dtype != DSN_BF16) return false;
-    if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->dil < 1 || p->dil > 3 || p->pad != p->dil || x->h != dy->h || x->w != dy->w)
-        return false;
+    const bool s1 = p->stride == 1 && p->dil >= 1 && p->dil <= 3 && p->pad == p->dil && x->h == dy->h && x->w == dy->w;
+    const bool s2 = p->stride == 2 && p->dil == 1 && p->pad == 1;
+    if (p->kh != 3 || p->kw != 3 || !(s1 || s2)) return false;
     if (mode == 2 && npix(dy) < minpx) return false;
     const bool vl = (dy->c % 8 == 0) && (x->c % 8 == 0) && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) &&
                     ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0);

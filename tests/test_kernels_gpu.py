@@ -578,8 +578,8 @@ def test_pyramid_multi_launches_equal_the_single_ones(ops, dtype):
 
 def test_wgrad_halo_tile_kernel_in_its_own_process():
     """The halo-tile all-taps weight-gradient kernel is off by default (DSN_WGRAD_HALO, read once per process): run it in a child
-    process against the default kernels' result for same-size 3x3 layers at dilation 1, 2, 3 with ragged 4 x 8 patches, through
-    the single-layer entry point and through the grouped launches."""
+    process against the default kernels' result for same-size 3x3 layers at dilation 1, 2, 3 and for stride-2 layers, with ragged
+    4 x 8 patches, through the single-layer entry point and through the grouped launches."""
     import os, subprocess, sys
     code = r'''
 import sys, torch
@@ -590,12 +590,14 @@ dt = torch.bfloat16
 desenet_amd.set_compute_dtype(dt)
 out = {}
 queue = ops.WgradQueue(torch.device("cuda", torch.cuda.current_device())) if sys.argv[1] == "queue" else None
-for i, (n, ci, h, w, co, d) in enumerate([(8, 64, 70, 67, 96, 1), (2, 16, 130, 131, 32, 1), (2, 64, 130, 131, 64, 2), (2, 32, 140, 128, 32, 3)]):
+for i, (n, ci, h, w, co, st, d) in enumerate([(8, 64, 70, 67, 96, 1, 1), (2, 16, 130, 131, 32, 1, 1), (2, 64, 130, 131, 64, 1, 2),
+                                             (2, 32, 140, 128, 32, 1, 3), (4, 32, 190, 187, 64, 2, 1), (8, 64, 160, 160, 128, 2, 1)]):
     g = torch.Generator(device="cuda").manual_seed(i)
+    ho, wo = ops.conv_out_hw(h, w, 3, st, d, d)
     x = ops.as_act((torch.randn((n, ci, h, w), device="cuda", generator=g)).to(dt))
-    dy = ops.as_act((torch.randn((n, co, h, w), device="cuda", generator=g)).to(dt))
+    dy = ops.as_act((torch.randn((n, co, ho, wo), device="cuda", generator=g)).to(dt))
     dw = torch.zeros(co, ci, 3, 3, device="cuda")
-    ops.conv2d_wgrad(x, dy, dw, ci, ops.conv_params(3, 1, d, d, accumulate=True), oihw=True, queue=queue)
+    ops.conv2d_wgrad(x, dy, dw, ci, ops.conv_params(3, st, d, d, accumulate=True), oihw=True, queue=queue)
     out[i] = dw
 if queue is not None:
     queue.flush()
