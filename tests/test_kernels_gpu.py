@@ -577,8 +577,9 @@ def test_pyramid_multi_launches_equal_the_single_ones(ops, dtype):
 
 
 def test_wgrad_halo_tile_kernel_in_its_own_process():
-    """The halo-tile all-taps weight-gradient kernel is off by default (DSN_WGRAD_HALO, read once per process): run it in a child
-    process against the default kernels' result for same-size 3x3 layers at dilation 1, 2, 3 and for stride-2 layers, with ragged
+    """The halo-tile all-taps weight-gradient kernel takes 3x3 layers from 32768 output pixels up by default (DSN_WGRAD_HALO=2, read
+    once per process): force it onto EVERY eligible layer in a child process (=1) and compare with the result of the all-taps /
+    per-tap kernels (=0) for same-size 3x3 layers at dilation 1, 2, 3 and for stride-2 layers, with ragged
     4 x 8 patches, through the single-layer entry point and through the grouped launches."""
     import os, subprocess, sys
     code = r'''
