@@ -30,7 +30,7 @@ def ids(sym):
     if "wgrad_reduce" in sym:
         return ["wgrad_reduce"]
     if "wgrad" in sym:
-        return ["wgrad_bf16" if "DF16b" in sym or "alltaps" in sym or "wgrad128" in sym else "wgrad_f32"]
+        return ["wgrad_bf16" if "DF16b" in sym or "alltaps" in sym or "wgrad128" in sym or "wgrad_halo" in sym else "wgrad_f32"]
     if "reduce2_kernel" in sym:
         return ["bn_act_bwd_reduce" if "BwdRedF" in sym else "bn_stats_reduce"]
     if "ew2_kernel" in sym:
