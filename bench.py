@@ -137,7 +137,18 @@ def cpu_baseline_infer(img, batch=2, budget_s=12.0):
                       f"torch {torch.__version__} CPU, {threads} threads"}
 
 
+def _traffic_table():
+    """profiles/traffic.json: HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
+    corrections of MI355X_MICROARCH.md, HBM), collected by tools/pmc_traffic.sh on config 3's shapes and keyed by kernel label."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tfile))
+    except Exception:
+        return {}
+
+
 def roofline_from_profile(prof, steps, dtype):
+    """prof: {label: launches/ms/flops/bytes} (hip_ops.profile_collect); label = rocprofv3 symbol family/dtype/tile/direction."""
     if not prof:
         return None, {}
     table = {}
@@ -162,14 +173,46 @@ def roofline_from_profile(prof, steps, dtype):
     roof.update({"avg_launch_us": avg_ms * 1e3, "launches_per_step": r["launches"] / steps,
                  "algorithmic_GBs": r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9,
                  "algorithmic_TFLOPs": (r["flops"] / r["launches"] / (avg_ms * 1e-3) / 1e12) if r["flops"] else None,
-                 "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "traffic": None})
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        try:
-            roof["traffic"] = json.load(open(tfile)).get(name)
-        except Exception:
-            pass
+                 "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "traffic": _traffic_table().get(name),
+                 "timing": "HIP events around the same launches on eager steps right after the timed hipGraph replays "
+                           "(10-15 % above their duration under replay: profiles/*_kernel_stats.csv hold the rocprofv3 view)"})
     return roof, table
+
+
+def roofline_by_layer(layers, steps, train):
+    """The two quantities BASELINE.json's north_star names, per layer, from the same HIP-event records:
+      train: the C3 / Bottleneck 3x3 convolutions (k3, stride 1, Ci == Co: common.py:107) forward and dgrad against the dense bf16
+             MFMA peak;
+      infer: every fused Conv+BN+SiLU launch (BN folded, activation in the epilogue: common.py:55-56) against the HBM roof."""
+    if not layers:
+        return None
+    rows, tot = [], {}
+    for (label, layer), r in sorted(layers.items()):
+        if not layer or r["ms"] <= 0:
+            continue
+        sym, dt, tile, direction = (label.split("/") + ["", "", "", ""])[:4]
+        peak_tf = PEAK["mfma_bf16_TFs"] if dt == "bf16" else PEAK["mfma_f32_TFs"]
+        geom, chans = layer.split(" ")[0], layer.split(" ")[1]
+        ci, co = (int(v) for v in chans.split("->"))
+        sec = r["ms"] * 1e-3
+        row = {"kernel": label, "layer": layer, "launches_per_step": r["launches"] / steps,
+               "avg_us": r["ms"] / r["launches"] * 1e3, "TFLOPs": r["flops"] / sec / 1e12, "GBs": r["bytes"] / sec / 1e9,
+               "mfma_frac": r["flops"] / sec / 1e12 / peak_tf, "hbm_frac": r["bytes"] / sec / 1e9 / PEAK["hbm_GBs"]}
+        if train:
+            if not (geom.startswith("k3s1") and ci == co):
+                continue
+            key = "c3_3x3_" + direction
+        else:
+            key = "conv_bn_silu_fused_k" + geom[1]
+        rows.append(row)
+        t = tot.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "peak_tf": peak_tf})
+        t["ms"] += r["ms"]; t["flops"] += r["flops"]; t["bytes"] += r["bytes"]
+    summary = {k: {"TFLOPs": t["flops"] / (t["ms"] * 1e-3) / 1e12, "mfma_frac": t["flops"] / (t["ms"] * 1e-3) / 1e12 / t["peak_tf"],
+                   "GBs": t["bytes"] / (t["ms"] * 1e-3) / 1e9, "hbm_frac": t["bytes"] / (t["ms"] * 1e-3) / 1e9 / PEAK["hbm_GBs"],
+                   "ms_per_step": t["ms"] / steps} for k, t in tot.items() if t["ms"] > 0}
+    return {"what": ("C3/Bottleneck 3x3 convolutions vs the dense bf16 MFMA peak (2.5 PFLOP/s)" if train else
+                     "fused Conv+BN+SiLU (eval) launches vs the HBM roof (8 TB/s); algorithmic bytes = input + output + weights once"),
+            "summary": summary, "layers": rows}
 
 
 def also_sections():
@@ -178,6 +221,7 @@ def also_sections():
     config 5's per-GPU shape (DeSeNet-m, 1280x1280, batch 4, bf16 training step)."""
     import subprocess
     runs = {"config2_infer_fp32_b16": ["--mode", "infer", "--steps", "30", "--warmup", "8"],
+            "config2_infer_bf16_b16": ["--mode", "infer", "--dtype", "bf16", "--steps", "30", "--warmup", "8"],
             "config5_m1280_bf16_b4": ["--model", "m", "--img", "1280", "--batch", "4", "--steps", "12", "--warmup", "4"]}
     out = {}
     for name, extra in runs.items():
@@ -192,21 +236,44 @@ def also_sections():
             j = json.loads(line[-1])
             out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
                          "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "workload": j["config"]["workload"],
-                         "roofline": j["roofline"], "kernels": j.get("kernels"), "wall_s": time.perf_counter() - t0}
+                         "roofline": j["roofline"], "roofline_by_layer": j.get("roofline_by_layer"),
+                         "kernels": j.get("kernels"), "wall_s": time.perf_counter() - t0}
         except Exception as e:      # never lose the headline line to a failing side section
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         log(f"also[{name}]: {out[name].get('value', out[name].get('error'))}")
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, as fresh child processes of
+    `python -m torch.distributed.run` (one rank per GPU), BEFORE this process has made any GPU call, relay rank 0's JSON line
+    and exit with the launcher's status (scripts/train.py:555-561 is started the same way)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("no launcher around --gpus", a.gpus, "-> starting", " ".join(cmd[1:8]), "...")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    raise SystemExit(r.returncode if r.returncode or lines else 1)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or plain `python bench.py --gpus N`)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path (no CPU fallback)")
     # (rehearsal on a one-GPU box: DSN_BENCH_BACKEND=gloo lets N ranks share the card; the driver's runs use RCCL, one GPU each)
@@ -258,8 +325,8 @@ def main():
         def loss_and_grads(det_pred, seg_pred, det_labels, seg_labels):
             # same losses, gradients straight from the kernels (graph-capturable); labels come from the step's static buffers
             out, d_det = compute_loss.forward_backward(det_pred, det_labels, gain=DETGAIN)
-            sout, d_seg = compute_seg_loss.forward_backward(seg_pred, seg_labels)
-            return (out, sout), d_det, (d_seg if SEGGAIN == 1 else d_seg * SEGGAIN)
+            sout, d_seg = compute_seg_loss.forward_backward(seg_pred, seg_labels, gain=SEGGAIN)
+            return (out, sout), d_det, d_seg
 
         micro = [0]
 
@@ -335,7 +402,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    prof = {}
+    prof, prof_layers = {}, {}
     prof_steps = a.steps
     if not a.no_profile:
         if graphed_run:
@@ -347,7 +414,7 @@ def main():
             for _ in range(prof_steps):
                 eager_step()
             torch.cuda.synchronize()
-        prof = ops.profile_collect()
+        prof, prof_layers = ops.profile_collect(by_layer=True)
         ops.profile_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -359,6 +426,7 @@ def main():
         roof, table = roofline_from_profile(prof, prof_steps, dtype)
         if roof is not None and not (train and a.model == "s" and batch == 8 and a.img == 640):
             roof["traffic"] = None      # profiles/traffic.json holds the PMC passes of config 3's shapes only
+        by_layer = roofline_by_layer(prof_layers, prof_steps, train)
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} threads ...")
@@ -378,7 +446,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
             "data": "synthetic (seeded uniform images, seeded boxes/masks, hash-filled weights)",
             "config": {"workload": workload, "batch_per_gpu": batch, "img": a.img, "parallelism": f"dp{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": table,
+            "roofline": roof, "roofline_by_layer": by_layer, "cpu_baseline": cpu, "kernels": table,
         }
         if world == 1 and train and a.model == "s" and not a.no_also and not a.also_only:
             out["also"] = also_sections()

@@ -172,6 +172,7 @@ PROTOTYPES = {
     "dsn_profile_collect": (i32, [vp, i32]),
     "dsn_profile_kernel_count": (i32, []),
     "dsn_profile_kernel_name": (C.c_char_p, [i32]),
+    "dsn_profile_dump": (i64, [vp, i64]),
 }
 
 _lib = None
@@ -193,7 +194,12 @@ def lib():
     return _lib
 
 
+class Unsupported(RuntimeError):
+    """DSN_EUNSUPPORTED (-2): the entry point does not take this shape / layout (nothing was launched).  include/desenet_hip.h
+    names the plain entry point a caller falls back to."""
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().dsn_last_error().decode(errors="replace")
-        raise RuntimeError(f"libdesenet_hip {what} failed (status {rc}): {msg}")
+        raise (Unsupported if rc == -2 else RuntimeError)(f"libdesenet_hip {what} failed (status {rc}): {msg}")

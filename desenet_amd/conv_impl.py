@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import _lib as _lib_mod
 from . import hip_ops as ops
 from .hip_ops import ACT_NONE, ACT_SIGMOID, ACT_SILU
 
@@ -418,9 +419,24 @@ def pair_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, f
         dx = ops.new_act(*x.shape, dtype, x.device)
         acc = False
     red, marks = _bnred_plan(tape, rec.get("x_in"), dx, None) if fuse_up else (None, ())
-    ops.conv2d_dgrad(dy, hit[3], dx, ops.conv_params(1, 1, 0, 1, accumulate=acc), red=red)
-    _bnred_commit(marks)
+    _dgrad_red(dy, hit[3], dx, ops.conv_params(1, 1, 0, 1, accumulate=acc), None, red, marks)
     return dx
+
+
+def _dgrad_red(dy, w, dx, params, residual, red, marks, s2=False):
+    """Input gradient with the BatchNorm backward sums of `red` in its epilogue; a launch the fused entry point does not take
+    (DSN_EUNSUPPORTED: dy not in 16-byte channel vectors, ...) is re-issued in its plain form and the sums are left to the
+    producers' own reduction (include/desenet_hip.h: dsn_conv2d_dgrad_bnred)."""
+    fn = ops.conv2d_dgrad_s2 if s2 else ops.conv2d_dgrad
+    kw = {} if s2 else {"residual": residual}
+    if red is not None:
+        try:
+            fn(dy, w, dx, params, red=red, **kw)
+            _bnred_commit(marks)
+            return
+        except _lib_mod.Unsupported:
+            pass
+    fn(dy, w, dx, params, **kw)
 
 
 def _wgrad(tape, x, dy, g, ci, params, queue):
@@ -522,13 +538,11 @@ def conv_block_bwd(tape, dz, dx=None, acc: bool = False, need_dx: bool = True, r
             # (measured A/B on DeSeNet-s, 3 x 100 steps each: 4.830 ms without any fused sums, 4.725 with the stride-1 launches only,
             #  4.707 with the two stride-2 stems as well -- DSN_BNRED=0 / 1 / 2)
             red, marks = _bnred_plan(tape, rec.get("x_in"), dx, None, fuse_up) if (fuse_up and residual is None and _BNRED >= 2) else (None, ())
-            ops.conv2d_dgrad_s2(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc), red=red)
+            _dgrad_red(dy, s2[1], dx, ops.conv_params(k, s, p, d, accumulate=acc), None, red, marks, s2=True)
         else:
             red, marks = _bnred_plan(tape, rec.get("x_in"), dx, residual, fuse_up) if fuse_up else (None, ())
-            ops.conv2d_dgrad(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc), residual=residual,
-                             red=red)
+            _dgrad_red(dy, packed_dgrad(conv, dtype), dx, ops.conv_params(k, s, p, d, accumulate=acc), residual, red, marks)
             residual = None
-        _bnred_commit(marks)
     if residual is not None:                       # (paths without a fused epilogue add: not taken by Bottleneck's 1x1)
         ops.copy(residual, dx, accumulate=True)
     return dx

@@ -93,12 +93,27 @@ class SegmentationLosses(nn.CrossEntropyLoss):
     def forward(self, pred, target):
         return _SegCEFn.apply(pred, target, self.ignore_index)
 
-    def forward_backward(self, pred, target):
-        """(out [2] = {mean CE, 1/valid}, d loss / d pred) without autograd.  `pred` may be the seg head's LOW-resolution logits
-        (SegMaskPSP under desenet_amd.graph.GraphedTrainStep(fuse_seg_loss=True): tagged `_dsn_seg_upsample = (H, W)`): the x8
-        bilinear up-sampling of yolo.py:183 is then fused with the cross entropy (dsn_seg_ce_up) and the returned gradient is the
-        low-resolution one the head's backward expects."""
+    def forward_backward(self, pred, target, gain=1.0):
+        """(out [2] = {mean CE, 1/valid}, gain * d loss / d pred) without autograd.  `pred` may be the seg head's LOW-resolution
+        logits (SegMaskPSP under desenet_amd.graph.GraphedTrainStep(fuse_seg_loss=True): tagged `_dsn_seg_upsample = (H, W)`): the
+        x8 bilinear up-sampling of yolo.py:183 is then fused with the cross entropy (dsn_seg_ce_up) and the returned gradient is
+        the low-resolution one the head's backward expects.  Shapes the fused kernel does not take run the same arithmetic
+        un-fused (up-sample, full-resolution cross entropy, up-sampling backward) and return the same kind of gradient."""
         up = getattr(pred, "_dsn_seg_upsample", None)
         if up is not None:
-            return ops.seg_ce_up(pred, target, up, self.ignore_index)
-        return ops.seg_ce(pred, target, self.ignore_index, want_grad=True)
+            try:
+                return ops.seg_ce_up(pred, target, up, self.ignore_index, gain=gain)
+            except ops.LazyUnsupported:
+                n, c, h, w = pred.shape
+                seg = torch.empty((n, c, int(up[0]), int(up[1])), dtype=torch.float32, device=pred.device)
+                ops.bilinear_ac(pred, seg, out_nchw=True)
+                out, dseg = ops.seg_ce(seg, target, self.ignore_index, want_grad=True)
+                if gain != 1.0:
+                    dseg = dseg * gain
+                vec = 4 if pred.dtype == torch.float32 else 8
+                dl = ops.bilinear_ac_bwd(dseg, ops.new_act(n, c, h, w, pred.dtype, pred.device, zero=True, ldc_align=vec),
+                                         dy_nchw=True)
+                dl._dsn_zero_padded = True
+                return out, dl
+        out, dl = ops.seg_ce(pred, target, self.ignore_index, want_grad=True)
+        return out, (dl if gain == 1.0 else dl * gain)

@@ -340,12 +340,13 @@ __global__ __launch_bounds__(THREADS) void lazy_ew_kernel(const T* __restrict__ 
 }
 
 // saved statistics + running averages of up to FINAL_MAX BatchNorm modules per launch (end of the forward pass)
-constexpr int FINAL_MAX = 40;      // (kernel arguments: 8 + 41 * 4 + 40 * 96 bytes < 4 KB)
+constexpr int FINAL_MAX = 38;      // (kernel arguments: 8 + 39 * 2 (+ padding) + 38 * 104 bytes <= 4 KB, asserted below)
 struct FinalTable {
     int32_t n, pad;
-    int32_t first[FINAL_MAX + 1];     // first block of each entry (256 channels per block)
+    int16_t first[FINAL_MAX + 1];     // first block of each entry (256 channels per block: a few hundred blocks at most)
     dsn_bn_final e[FINAL_MAX];
 };
+static_assert(sizeof(FinalTable) <= 4096, "FinalTable travels by value: keep it inside the 4 KB kernel-argument budget");
 __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(const FinalTable t) {
     int l = 0;
     while (l + 1 < t.n && t.first[l + 1] <= (int)blockIdx.x) ++l;

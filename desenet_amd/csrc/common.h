@@ -379,5 +379,19 @@ struct ProfScope {
     int slot;
     hipStream_t st;
     ProfScope(int kid, double flops, double bytes, hipStream_t stream);
+    // labelled form: `label` = "<rocprofv3 symbol family>/<dtype>/<tile>/<fwd|dgrad>", `layer` = shape key of the launch
+    // (both copied; built by the launch site only while the profiler is on: dsn_prof_on())
+    ProfScope(const char* label, const char* layer, double flops, double bytes, hipStream_t stream);
     ~ProfScope();
+};
+bool dsn_prof_on();
+// label / layer strings of a convolution launch (sym: kernel symbol family as rocprofv3 --kernel-trace prints it)
+struct ProfConv {
+    char label[64], layer[64];
+    ProfConv(const char* sym, bool bf16, int bm, int bn, bool dgrad, int k, int stride, int dil, int cs, int cd, int n, int h, int w) {
+        label[0] = layer[0] = 0;
+        if (!dsn_prof_on()) return;
+        snprintf(label, sizeof(label), "%s/%s/%dx%d/%s", sym, bf16 ? "bf16" : "f32", bm, bn, dgrad ? "dgrad" : "fwd");
+        snprintf(layer, sizeof(layer), "k%ds%dd%d %d->%d @%dx%dx%d", k, stride, dil, cs, cd, n, h, w);
+    }
 };

@@ -401,9 +401,8 @@ int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const ds
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
     const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) +
                          9.0 * g.Cs * g.Cd;
-    constexpr int CFG = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : 2;
-    ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.flip ? 1 : 0), 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs,
-                   elems * sizeof(T), st);
+    const ProfConv pc("conv3x3_halo_kernel", sizeof(T) == 2, BM, BN, g.flip != 0, 3, 1, g.d, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,
                        (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld, la.br ? *la.br : BnRed{});
     DSN_LAUNCH_CHECK("conv3x3 (halo tile)");
@@ -655,8 +654,8 @@ int launch_1x1(const dsn_tensor* s, const void* w, const float* bias, const dsn_
     }
     const int blocks = (int)((M + BM - 1) / BM) * g.tiles_n;
     const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) + (double)g.Cs * g.Cd;
-    constexpr int CFG = (BM == 64 && BN == 64) ? 2 : 5;
-    ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (is_dgrad ? 1 : 0), 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
+    const ProfConv pc("conv1x1_dma_kernel", sizeof(T) == 2, BM, BN, is_dgrad != 0, 1, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,
                        (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld, la.br ? *la.br : BnRed{});
     DSN_LAUNCH_CHECK("conv1x1 (one-trip LDS-DMA)");

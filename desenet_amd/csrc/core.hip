@@ -1,5 +1,6 @@
 // Error state, version, weight packing, casts and strided copies.
 #include "common.h"
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -11,23 +12,42 @@ void dsn_set_error(const char* fmt, ...) {
 }
 
 // ---- live profiler -------------------------------------------------------------------------------------------------
+#include <map>
+#include <string>
 #include <vector>
+extern "C" const char* dsn_profile_kernel_name(int32_t kid);
 namespace {
-struct ProfEntry { hipEvent_t a, b; int kid; double flops, bytes; };
+struct ProfEntry { hipEvent_t a, b; int kid; double flops, bytes; char label[64], layer[64]; };
 bool g_prof_on = false;
 std::vector<ProfEntry> g_prof;
 size_t g_prof_used = 0;
-}
-ProfScope::ProfScope(int kid, double flops, double bytes, hipStream_t stream) : slot(-1), st(stream) {
-    if (!g_prof_on) return;
+int prof_slot(hipStream_t st) {
+    if (!g_prof_on) return -1;
     if (g_prof_used == g_prof.size()) {
         ProfEntry e{};
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
         g_prof.push_back(e);
     }
-    slot = (int)g_prof_used++;
-    g_prof[slot].kid = kid; g_prof[slot].flops = flops; g_prof[slot].bytes = bytes;
-    (void)hipEventRecord(g_prof[slot].a, st);
+    return (int)g_prof_used++;
+}
+}
+bool dsn_prof_on() { return g_prof_on; }
+ProfScope::ProfScope(int kid, double flops, double bytes, hipStream_t stream) : slot(prof_slot(stream)), st(stream) {
+    if (slot < 0) return;
+    ProfEntry& e = g_prof[slot];
+    e.kid = kid; e.flops = flops; e.bytes = bytes;
+    snprintf(e.label, sizeof(e.label), "%s", dsn_profile_kernel_name(kid));
+    e.layer[0] = 0;
+    (void)hipEventRecord(e.a, st);
+}
+ProfScope::ProfScope(const char* label, const char* layer, double flops, double bytes, hipStream_t stream)
+    : slot(prof_slot(stream)), st(stream) {
+    if (slot < 0) return;
+    ProfEntry& e = g_prof[slot];
+    e.kid = -1; e.flops = flops; e.bytes = bytes;
+    snprintf(e.label, sizeof(e.label), "%s", label);
+    snprintf(e.layer, sizeof(e.layer), "%s", layer ? layer : "");
+    (void)hipEventRecord(e.a, st);
 }
 ProfScope::~ProfScope() {
     if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
@@ -39,11 +59,42 @@ extern "C" int dsn_profile_enable(int32_t on) {
     return DSN_OK;
 }
 
-// Aggregates per kernel id since dsn_profile_enable(1): out[kid] = {launches, total_ms, total_flops, total_bytes}.
+// Text dump of everything recorded since dsn_profile_enable(1), aggregated per (label, layer): one line per pair,
+// "label\tlayer\tlaunches\ttotal_ms\ttotal_flops\ttotal_bytes\n".  Returns the number of bytes the full dump needs (call
+// again with a larger buffer if it exceeds `cap`; the records are kept until the dump fitted), < 0 on error.
+extern "C" int64_t dsn_profile_dump(char* out, int64_t cap) {
+    struct Agg { double n = 0, ms = 0, fl = 0, by = 0; };
+    std::map<std::pair<std::string, std::string>, Agg> agg;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_prof[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b);
+        if (e != hipSuccess) { dsn_set_error("profile_dump: %s", hipGetErrorString(e)); return -(int64_t)e; }
+        Agg& a = agg[{g_prof[i].label, g_prof[i].layer}];
+        a.n += 1.0; a.ms += ms; a.fl += g_prof[i].flops; a.by += g_prof[i].bytes;
+    }
+    std::string s;
+    char line[256];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%s\t%s\t%.0f\t%.6f\t%.6e\t%.6e\n", kv.first.first.c_str(), kv.first.second.c_str(),
+                 kv.second.n, kv.second.ms, kv.second.fl, kv.second.by);
+        s += line;
+    }
+    const int64_t need = (int64_t)s.size() + 1;
+    if (out && cap >= need) {
+        memcpy(out, s.c_str(), (size_t)need);
+        g_prof_used = 0;
+    }
+    return need;
+}
+
+// Aggregates per legacy kernel id since dsn_profile_enable(1): out[kid] = {launches, total_ms, total_flops, total_bytes}
+// (labelled records -- the convolution launches -- are not in this view: dsn_profile_dump).
 extern "C" int dsn_profile_collect(double* out /* [KID_COUNT][4] */, int32_t n_kids) {
     DSN_CHECK_ARG(out && n_kids >= KID_COUNT, "profile_collect: need room for %d kernel ids", KID_COUNT);
     for (int i = 0; i < n_kids * 4; ++i) out[i] = 0.0;
     for (size_t i = 0; i < g_prof_used; ++i) {
+        if (g_prof[i].kid < 0) continue;
         float ms = 0.f;
         hipError_t e = hipEventSynchronize(g_prof[i].b);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b);
@@ -62,17 +113,17 @@ extern "C" const char* dsn_profile_kernel_name(int32_t kid) {
     static const char* cfg[7] = {"128x128", "128x64", "64x64", "128x32", "64x16", "32x64", "64x32"};
     if (kid >= KID_IGEMM && kid < KID_WGRAD) {
         const int dt = kid / 20, c = (kid % 20) / 2, dg = kid & 1;
-        snprintf(buf, sizeof(buf), "igemm_%s_%s_%s", dt ? "bf16" : "f32", c < 7 ? cfg[c] : "?", dg ? "dgrad" : "fwd");
+        snprintf(buf, sizeof(buf), "igemm_kernel/%s/%s/%s", dt ? "bf16" : "f32", c < 7 ? cfg[c] : "?", dg ? "dgrad" : "fwd");
         return buf;
     }
     switch (kid) {
-        case KID_WGRAD: return "wgrad_f32";
-        case KID_WGRAD + 1: return "wgrad_bf16";
-        case KID_WGRAD_REDUCE: return "wgrad_reduce";
-        case KID_BN_STATS: return "bn_stats_reduce";
-        case KID_BN_ACT_FWD: return "bn_act_fwd";
-        case KID_BN_BWD_REDUCE: return "bn_act_bwd_reduce";
-        case KID_BN_BWD_APPLY: return "bn_act_bwd_apply";
+        case KID_WGRAD: return "wgrad_grouped/f32";
+        case KID_WGRAD + 1: return "wgrad_grouped/bf16";
+        case KID_WGRAD_REDUCE: return "wgrad_reduce_grouped_kernel";
+        case KID_BN_STATS: return "reduce2_kernel/StatsF";
+        case KID_BN_ACT_FWD: return "lazy_ew_kernel+ew2_kernel/FwdF";
+        case KID_BN_BWD_REDUCE: return "reduce2_kernel/BwdRedF";
+        case KID_BN_BWD_APPLY: return "ew2_kernel/BwdApplyF";
     }
     return "?";
 }

@@ -675,8 +675,11 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     const double src_elems = (double)(g.M / (g.Hd * g.Wd)) * g.Hs * g.Ws * g.Cs;
     const double elems = src_elems + (double)g.M * g.Cd * (1 + (res ? 1 : 0) + (g.accumulate ? 1 : 0)) + K * g.Cd +
                          (double)g.M * (g.d2s_c > 0 ? 4.0 : 1.0) * bnred_channels(brp);
-    ProfScope prof(KID_IGEMM + (sizeof(T) == 2 ? 20 : 0) + CFG * 2 + (g.is_dgrad ? 1 : 0), 2.0 * g.M * g.Cd * K,
-                   elems * sizeof(T), st);
+    (void)CFG;
+    // (a, q): forward stride a, dgrad source stride q; d = +-dilation; depth-to-space = the stride-2 dgrad in its 2x2 form
+    const ProfConv pc("igemm_kernel", sizeof(T) == 2, BM, BN, g.is_dgrad != 0, g.KH, g.d2s_c > 0 ? 2 : (g.is_dgrad ? g.q : g.a),
+                      g.d < 0 ? -g.d : g.d, g.Cs, g.Cd, g.M / (g.Hd * g.Wd), g.Hd, g.Wd);
+    ProfScope prof(pc.label, pc.layer, 2.0 * g.M * g.Cd * K, elems * sizeof(T), st);
     static const bool no_uni = getenv("DSN_IGEMM_NOUNI") != nullptr;                                          // tuning knob
     static const int longk = [] { const char* e = getenv("DSN_IGEMM_LONGK"); return e ? atoi(e) : 9; }();
     g.longk = longk;

@@ -103,16 +103,23 @@ class GraphedTrainStep:
                 with torch.cuda.graph(self.g_first, **cap_kw):
                     self.flat.zero()
                     self.loss, tape = self._forward_backward(stop_at=self.split)
+                # BatchNorm accumulator slots: the forward pass of each micro-batch graph clears the arena and hands slots out from
+                # its start; the second half of that micro-batch's backward must CONTINUE from where its first half stopped (not from
+                # wherever the previously captured graph left the cursor), or its slots would lie beyond what the clear covers.
+                cur_first = ops.bn_arena_cursor(dev)
                 if self.accumulate > 1:
                     self.g_next = G()
                     with torch.cuda.graph(self.g_next, **cap_kw):
                         self.loss_next, tape_n = self._forward_backward(stop_at=self.split)
+                    cur_next = ops.bn_arena_cursor(dev)
                 if self.split > 0:
                     self.g_tail = G()
+                    ops.bn_arena_cursor(dev, cur_first)
                     with torch.cuda.graph(self.g_tail, **cap_kw):
                         self._backward_rest(tape)
                     if self.accumulate > 1:
                         self.g_tail_next = G()
+                        ops.bn_arena_cursor(dev, cur_next)
                         with torch.cuda.graph(self.g_tail_next, **cap_kw):
                             self._backward_rest(tape_n)
                 del tape
@@ -254,6 +261,11 @@ class GraphedTrainStep:
             if seg_targets is not None:
                 pairs.append((self.seg_t, seg_targets))
         for dst, src in pairs:
+            # images and masks must fill their buffers exactly: a smaller final batch (the reference's loader does not drop_last)
+            # would otherwise train on zero-padded images with all-background masks; only the label ROWS may be fewer
+            if src is not None and dst is not self.det_t and tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"batch shape {tuple(src.shape)} does not match the captured step's {tuple(dst.shape)}: run a "
+                                 "partial batch through an eager step (or build a second GraphedTrainStep for it)")
             if src is not None and (src.device != dst.device or src.dtype != dst.dtype or not src.is_contiguous()
                                     or src.numel() > dst.numel() or (src.data_ptr() | dst.data_ptr()) % 4
                                     or (src.numel() * src.element_size()) % 4):

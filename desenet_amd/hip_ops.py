@@ -651,6 +651,21 @@ def bn_arena_begin(device):
     a.begin()
 
 
+def bn_arena_cursor(device, set_to=None):
+    """Read (or rewind) the step arena's hand-out position.  A backward pass captured in several graphs (graph.py, world_size > 1)
+    resumes the SECOND half of micro-batch k at the position its first half left, so that both "first" and "next" micro-batch
+    graphs use the slots their own arena clear covers."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    a = _arenas.get(device)
+    if a is None:
+        return 0
+    if set_to is not None:
+        a.cursor = int(set_to)
+    return a.cursor
+
+
 def bn_acc(c, device):
     """A ZEROED accumulator slot for c channels: from the step arena when one is active, else a fresh zero-filled tensor."""
     nbytes = _lib.lib().dsn_bn_workspace_bytes(c)
@@ -1072,18 +1087,26 @@ def profile_enable(on: bool):
     _lib.check(_lib.lib().dsn_profile_enable(int(on)), "profile_enable")
 
 
-def profile_collect():
-    """{kernel name: dict(launches, ms, flops, bytes)} for every kernel launched since profile_enable(True)."""
+def profile_collect(by_layer: bool = False):
+    """{label: dict(launches, ms, flops, bytes)} for every kernel launched since profile_enable(True); label = rocprofv3 symbol
+    family / dtype / tile / direction for the convolutions.  by_layer=True: (that dict, {(label, layer): dict(...)})."""
     L = _lib.lib()
-    n = L.dsn_profile_kernel_count()
-    buf = (C.c_double * (4 * n))()
-    _lib.check(L.dsn_profile_collect(C.cast(buf, C.c_void_p), n), "profile_collect")
-    out = {}
-    for k in range(n):
-        if buf[4 * k] > 0:
-            out[L.dsn_profile_kernel_name(k).decode()] = dict(launches=int(buf[4 * k]), ms=buf[4 * k + 1],
-                                                               flops=buf[4 * k + 2], bytes=buf[4 * k + 3])
-    return out
+    need = int(L.dsn_profile_dump(None, 0))
+    if need < 0:
+        _lib.check(-need, "profile_dump")
+    buf = C.create_string_buffer(max(need, 1))
+    rc = int(L.dsn_profile_dump(C.cast(buf, C.c_void_p), need))
+    if rc < 0:
+        _lib.check(-rc, "profile_dump")
+    out, layers = {}, {}
+    for line in buf.value.decode().splitlines():
+        label, layer, n, ms, fl, by = line.split("\t")
+        rec = dict(launches=int(float(n)), ms=float(ms), flops=float(fl), bytes=float(by))
+        layers[(label, layer)] = rec
+        a = out.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for k in rec:
+            a[k] += rec[k]
+    return (out, layers) if by_layer else out
 
 
 # ------------------------------------------------------------------------------------------------ losses

@@ -522,6 +522,12 @@ int         dsn_profile_enable(int32_t on);
 int         dsn_profile_collect(double* out /* [kernel_count][4] */, int32_t kernel_count);
 int32_t     dsn_profile_kernel_count(void);
 const char* dsn_profile_kernel_name(int32_t kid);
+/* Everything recorded since dsn_profile_enable(1), aggregated per (label, layer) as text, one line per pair:
+ * "label\tlayer\tlaunches\ttotal_ms\ttotal_flops\ttotal_bytes\n".  label = "<kernel symbol family as rocprofv3 --kernel-trace
+ * prints it>/<dtype>/<tile>/<fwd|dgrad>" for the convolution launches (the name of the legacy id otherwise), layer = shape key
+ * of the launch ("k3s1d1 64->64 @8x80x80"; empty for the non-convolution ids).  Returns the bytes the dump needs; when they
+ * exceed `cap` nothing is written and the records are kept (call again with a larger buffer).  < 0: -hipError_t. */
+int64_t     dsn_profile_dump(char* out, int64_t cap);
 
 #ifdef __cplusplus
 }

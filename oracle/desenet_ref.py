@@ -288,6 +288,29 @@ def detect(cx, xs, p, strides=(8.0, 16.0, 32.0)):  # yolo.py:255-277
     return raws if cx.training else (torch.cat(z, 1), raws)
 
 
+def apply_layer(cx, L, out):
+    """One top-level layer of the yaml graph (the body of yolo.py:352 `x = m(x)`): `out` is the routed input (a tensor, or the
+    list of tensors for Concat / SegMaskPSP / Detect)."""
+    p = f"model.{L.i}"
+    if L.kind == "Focus":
+        return focus(cx, out, p, L.args[2])
+    if L.kind == "Conv":
+        return conv_bn_act(cx, out, p, L.args[2], L.args[3] if len(L.args) > 3 else 1)
+    if L.kind == "C3":
+        return c3(cx, out, p, L.n, L.args[2] if len(L.args) > 2 else True)
+    if L.kind == "SPP":
+        return spp(cx, out, p, L.args[2])
+    if L.kind == "nn.Upsample":
+        return F.interpolate(out, scale_factor=float(L.args[1]), mode=L.args[2])
+    if L.kind == "Concat":
+        return torch.cat(out, 1)
+    if L.kind == "SegMaskPSP":
+        return seg_mask_psp(cx, out, p)
+    if L.kind == "Detect":
+        return detect(cx, list(out), p)
+    raise NotImplementedError(L.kind)
+
+
 def forward(cfg, sd, x, training=False, fused=False, keep=None):
     """yolo.py:344-356.  Returns (det_out, seg_out, saved) where det_out follows Detect's train/eval contract and
     `saved` maps layer index -> output for every index in `keep` (default: the reference's save list)."""
@@ -299,25 +322,7 @@ def forward(cfg, sd, x, training=False, fused=False, keep=None):
     for L in layers:
         if L.f != -1:
             out = y[L.f] if isinstance(L.f, int) else [out if j == -1 else y[j] for j in L.f]
-        p = f"model.{L.i}"
-        if L.kind == "Focus":
-            out = focus(cx, out, p, L.args[2])
-        elif L.kind == "Conv":
-            out = conv_bn_act(cx, out, p, L.args[2], L.args[3] if len(L.args) > 3 else 1)
-        elif L.kind == "C3":
-            out = c3(cx, out, p, L.n, L.args[2] if len(L.args) > 2 else True)
-        elif L.kind == "SPP":
-            out = spp(cx, out, p, L.args[2])
-        elif L.kind == "nn.Upsample":
-            out = F.interpolate(out, scale_factor=float(L.args[1]), mode=L.args[2])
-        elif L.kind == "Concat":
-            out = torch.cat(out, 1)
-        elif L.kind == "SegMaskPSP":
-            out = seg_mask_psp(cx, out, p)
-        elif L.kind == "Detect":
-            out = detect(cx, list(out), p)
-        else:
-            raise NotImplementedError(L.kind)
+        out = apply_layer(cx, L, out)
         y.append(out if L.i in keep or L.i in save else None)
     saved = {i: y[i] for i in keep if i < len(y) and torch.is_tensor(y[i])}
     return out, y[-2], saved

@@ -216,21 +216,25 @@ def test_graph_keeps_its_workspaces_when_eager_work_outgrows_them():
 
 
 # ---- two ranks, one GPU (gloo rendezvous, CUDA tensors): the product's multi-rank step ------------------------------------
-def _worker(rank, world, port, path, split):
+def _worker(rank, world, port, path, split, accumulate=1, backend="gloo"):
     import torch.distributed as dist
     from desenet_amd.graph import GraphedTrainStep
     from desenet_amd.parallel import broadcast_parameters
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
         m = _model()
         broadcast_parameters(m)
         flat, opt, cl, sl = _setup(m)
-        batches = [_batch(50 + 2 * s + rank, 6 - rank) for s in range(2)]
+        batches = [_batch(50 + 2 * s + rank, 6 - rank) for s in range(2 * accumulate)]
         step = GraphedTrainStep(m, _lg(cl, sl), flat, opt, batches[0][0], det_targets=batches[0][1],
-                                seg_targets=batches[0][2], max_targets=32, split_layer=split)
-        assert step.multi and (step.split > 0) == (split != 0)
+                                seg_targets=batches[0][2], max_targets=32, split_layer=split, accumulate=accumulate)
+        assert step.multi == (world > 1) and (step.split > 0) == (split != 0 and world > 1)
         for b in batches:
             step(*b)
         torch.cuda.synchronize()
@@ -239,23 +243,26 @@ def _worker(rank, world, port, path, split):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split", [None, 0])
-def test_two_rank_graph_step_equals_sum_of_rank_gradients(split):
-    """GraphedTrainStep with world_size 2 (backward captured in two halves around the first, asynchronous all-reduce when
-    split != 0): parameters after two steps equal a single process that accumulates both ranks' batches per step (SUM of rank
-    gradients, train.py:356-358) -- and both ranks hold identical parameters."""
+@pytest.mark.parametrize("split,accumulate", [(None, 1), (0, 1), (None, 2)])
+def test_two_rank_graph_step_equals_sum_of_rank_gradients(split, accumulate):
+    """GraphedTrainStep with world_size 2 over gloo (two ranks share the one GPU of the test box, so the collective itself
+    cannot be RCCL here; test_rccl_* below loads that path): backward captured in two halves around the first, asynchronous
+    all-reduce when split != 0; with accumulate 2 the "first" and "next" micro-batch graphs each have their own second half.
+    Parameters after two optimizer steps equal a single process that accumulates all ranks' (micro-)batches per step (SUM of
+    rank gradients, train.py:356-358,370-376) -- and both ranks hold identical parameters."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, port, d, split), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, d, split, accumulate), nprocs=2, join=True)
         r = [torch.load(os.path.join(d, f"r{i}.pt")) for i in range(2)]
     me = _model()
     flat, opt, cl, sl = _setup(me)
     for s in range(2):
         flat.zero()
-        for rank in range(2):
-            _eager_micro(me, cl, sl, _batch(50 + 2 * s + rank, 6 - rank))
+        for micro in range(accumulate):
+            for rank in range(2):
+                _eager_micro(me, cl, sl, _batch(50 + 2 * (s * accumulate + micro) + rank, 6 - rank))
         opt.step()
     sd = me.state_dict()
     for k, v in sd.items():
@@ -263,6 +270,49 @@ def test_two_rank_graph_step_equals_sum_of_rank_gradients(split):
             continue                        # BatchNorm running statistics are per rank (no --sync-bn), as in the reference
         assert torch.equal(r[0][k], r[1][k]), k
         assert rel_err(r[0][k], v.cpu()) < 5e-2, k
+
+
+def test_rccl_world_size_one_step_and_all_reduce():
+    """The RCCL code path of the product on the one GPU the box has: init_process_group("nccl", device_id=...) with world size 1,
+    an asynchronous all-reduce of the flat gradient buffer (what graph.py issues between the two backward graphs), a graph-captured
+    training step built while the process group is live, destroy.  (Two ranks cannot share a GPU under RCCL: the multi-rank
+    arithmetic is covered over gloo above, the 1 -> 8 curve is the driver's.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rccl_worker, args=(port, d), nprocs=1, join=True)
+        got = torch.load(os.path.join(d, "ok.pt"))
+    assert got["ok"] and got["backend"] == "nccl"
+
+
+def _rccl_worker(rank, port, path):
+    import torch.distributed as dist
+    from desenet_amd.graph import GraphedTrainStep
+    from desenet_amd.parallel import FlatGradients, broadcast_parameters
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = _model()
+        broadcast_parameters(m)                       # (no-op at world size 1)
+        flat, opt, cl, sl = _setup(m)
+        flat.flat.fill_(1.5)
+        ref = flat.flat.clone()
+        work = dist.all_reduce(flat.flat, op=dist.ReduceOp.SUM, async_op=True)      # RCCL kernel on RCCL's stream
+        work.wait()
+        dist.all_reduce(flat.flat[: flat.flat.numel() // 2], op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        same = torch.equal(flat.flat, ref)
+        b = _batch(70, 4)
+        step = GraphedTrainStep(m, _lg(cl, sl), flat, opt, b[0], det_targets=b[1], seg_targets=b[2], max_targets=32)
+        w0 = next(m.parameters()).detach().clone()
+        step(*b)
+        torch.cuda.synchronize()
+        moved = not torch.equal(w0, next(m.parameters()).detach())
+        torch.save({"ok": bool(same and moved), "backend": dist.get_backend()}, os.path.join(path, "ok.pt"))
+    finally:
+        dist.destroy_process_group()
 
 
 def test_training_trajectory_equals_the_conservative_kernels(tmp_path):

@@ -505,3 +505,82 @@ def test_teacher_forced_layers_bf16_at_640(net, training):
         dsn.set_compute_dtype(torch.float32)
     bad = {i: e for i, e in worst.items() if e > 4e-2}
     assert not bad, (bad, worst)
+
+
+def test_teacher_forced_layer_backward_bf16_at_640(net):
+    """bf16 BACKWARD where the headline runs (config 3: 8 x 640 x 640), against the ORACLE and per top-level layer, so that a
+    dgrad / wgrad / BatchNorm-backward error cannot hide behind a comparison of the HIP path with itself: layer L of the mirrored
+    model is fed the oracle's fp32 input to L and the oracle's upstream gradient d(total loss)/d(output of L) (train.py:352-367:
+    detgain * det loss + seggain * seg loss), and its bf16 input gradient(s) and parameter gradients are held to the oracle's
+    for the same isolated layer (torch.autograd.grad over oracle.desenet_ref.apply_layer in fp32 on the CPU).
+    rel err = max|a-b| / max|b| per tensor <= 6e-2; gradients whose oracle value is numerically zero (max|b| < 1e-12: the
+    BatchNorm before a 1x1-map Conv, quirk Q1) must be zero or absent."""
+    import copy
+    from oracle import desenet_ref as R
+    from oracle import loss_ref
+    dsn, m = net
+    cfg = load_cfg()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    is_p = lambda k: "running" not in k and "num_batches" not in k and "anchor" not in k
+    x = synth_images(8, 640, 5)
+    det_t, seg_t = synth_targets(8, 640, 5)
+    # ---- oracle: whole step once, upstream gradient of every layer output
+    sd = {k: v.clone().requires_grad_(is_p(k)) for k, v in sd0.items()}
+    layers, _ = R.parse_arch(cfg, 3)
+    cx = R.Ctx(sd, training=True)
+    ys, out = [], x
+    for L in layers:
+        if L.f != -1:
+            out = ys[L.f] if isinstance(L.f, int) else [out if j == -1 else ys[j] for j in L.f]
+        out = R.apply_layer(cx, L, out)
+        for t in (out if isinstance(out, (list, tuple)) else [out]):
+            t.retain_grad()
+        ys.append(out)
+    total, *_ = loss_ref.step_loss(ys[25], ys[24], det_t, seg_t, sd["model.25.anchors"], 6, 640)
+    total.backward()
+    ups = [[t.grad for t in y] if isinstance(y, (list, tuple)) else y.grad for y in ys]
+    ins_of = lambda L: (x if L.i == 0 else ys[L.i - 1] if L.f == -1 else ys[L.f] if isinstance(L.f, int)
+                        else [ys[L.i + j if j < 0 else j] for j in L.f])
+    mm = copy.deepcopy(m).train()
+    dsn.set_compute_dtype(torch.bfloat16)
+    worst, bad = {}, {}
+    try:
+        for L, HL in zip(layers, list(mm.model)):
+            if ups[L.i] is None or (isinstance(ups[L.i], list) and any(u is None for u in ups[L.i])):
+                continue
+            raw = ins_of(L)
+            lst = isinstance(raw, (list, tuple))
+            # oracle, isolated layer (fresh running statistics: BatchNorm's train-mode forward updates them in place)
+            sdl = {k: v.clone().requires_grad_(is_p(k)) for k, v in sd0.items()}
+            oin = [t.detach().clone().requires_grad_(L.i != 0) for t in (raw if lst else [raw])]
+            oout = R.apply_layer(R.Ctx(sdl, training=True), L, oin if lst else oin[0])
+            pk = [k for k in sdl if k.startswith(f"model.{L.i}.") and sdl[k].requires_grad]
+            oo = list(oout) if isinstance(oout, (list, tuple)) else [oout]
+            uu = ups[L.i] if isinstance(ups[L.i], list) else [ups[L.i]]
+            want = [t for t in oin if t.requires_grad] + [sdl[k] for k in pk]
+            og = torch.autograd.grad(oo, want, uu, allow_unused=True)
+            n_in = sum(t.requires_grad for t in oin)
+            # HIP, bf16
+            hin = [t.detach().clone().cuda().requires_grad_(L.i != 0) for t in (raw if lst else [raw])]
+            for p_ in HL.parameters():
+                p_.grad = None
+            hout = HL(hin if lst else hin[0])
+            ho = list(hout) if isinstance(hout, (list, tuple)) else [hout]
+            torch.autograd.backward(ho, [u.cuda().to(o.dtype) for u, o in zip(uu, ho)])
+            hp = dict(HL.named_parameters())
+            got = [t.grad for t in hin if t.requires_grad] + [hp[k[len(f"model.{L.i}."):]].grad for k in pk]
+            names = [f"dx{j}" for j in range(n_in)] + pk
+            for nme, g, o in zip(names, got, og):
+                if o is None or float(o.abs().max()) < 1e-12:
+                    if g is not None and float(g.abs().max()) > 1e-6:
+                        bad[(L.i, nme)] = "oracle gradient is zero / absent, HIP's is not"
+                    continue
+                assert g is not None, (L.i, nme, "no HIP gradient")
+                e = rel_err(g.float().cpu(), o)
+                worst[(L.i, nme)] = e
+                if not e <= 6e-2:
+                    bad[(L.i, nme)] = e
+    finally:
+        dsn.set_compute_dtype(torch.float32)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:8]
+    assert len(worst) > 150 and not bad, (bad, top)

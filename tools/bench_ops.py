@@ -45,12 +45,22 @@ LAYERS_M = [  # DeSeNet-m (config 5): batch 4, 1280x1280 -- the layers that carr
 ]
 
 
+_STREAM = None
+
+
 def timeit(fn, iters=30):
-    for _ in range(3):
-        fn()
+    """us per call under hipGraph replay.  Warm-up and capture run on ONE side stream: hip_ops' workspaces are per stream and
+    may not grow during a capture (the warm-up grows them to this layer's size first)."""
+    global _STREAM
+    if _STREAM is None:
+        _STREAM = torch.cuda.Stream()
+    _STREAM.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(_STREAM):
+        for _ in range(3):
+            fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=_STREAM):
         for _ in range(iters):
             fn()
     g.replay()
