@@ -351,6 +351,13 @@ int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, c
                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
                         const dsn_tensor* z = nullptr, const dsn_bnred* br = nullptr);
 
+// conv_ws.hip: weights-stationary persistent kernels, tried before the one-trip kernels above (same return convention)
+int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
+
+int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #define DSN_DISPATCH_DTYPE(dt, T, ...)                 \

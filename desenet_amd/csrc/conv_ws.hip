@@ -1,0 +1,860 @@
+// Weights-stationary, persistent convolution kernels (round 3): 1x1 / stride 1 and 3x3 / stride 1 (dilation 1..3), forward and
+// data gradient -- Conv, Bottleneck, C3, SPP, RFB2, FFM and the seg head's 1x1s (common.py:42-56,101-145,172-185,222-242,504-545;
+// yolo.py:161-181) and ATen's convolution_backward (input) behind them.
+//
+// Why: per-layer rocprofv3 / HIP-event tables (profiles/r03*) showed the one-trip kernels of conv3x3.hip bound by what every block
+// pulls through L2, not by HBM or MFMA: a 64-pixel block re-fetches its whole weight tile (64 x K x 2 B = 16..300 KB) for 8..16 KB of
+// input -- a 3x3 64 -> 64 @ 8x80x80 layer moves 59 MB of weights for 6.5 MB of activations, the same for every C3 3x3 of the net
+// (the three have equal MACs by design), and each block's life is one exposed trip to L2 + a short MFMA burst + an LDS-staged store.
+// Here a block is PERSISTENT: it loads the weights of its output-channel tile into LDS once and then walks its share of the pixel
+// tiles, with the next tile's input arriving by LDS-DMA (buffer_load ... lds) while the current one is multiplied and stored:
+//   * weights: one trip per block (<= 256 x bpc blocks) instead of one per 64 pixels;
+//   * input: double-buffered tiles, one counted s_waitcnt vmcnt per tile (stores of the previous tile stay in flight), one raw
+//     s_barrier per tile, no barrier inside a tile (the weights are resident: nothing streams but the pixels);
+//   * MFMA with the operands swapped (A = weight rows, B = pixels): the accumulator then holds 4 consecutive CHANNELS of one
+//     pixel per lane, and with the weight rows of two 16-channel tiles interleaved in LDS (row order c0 + 8*(i>>2) + 4*t + (i&3))
+//     a lane owns 8 consecutive bf16 channels = one 16-byte store straight from registers: no LDS staging tile, no second barrier;
+//   * BatchNorm partial sums (training forward) stay in registers across all tiles of the block and reach the fp64 accumulators
+//     once per block.
+// Layout contracts are those of conv3x3.hip (NHWC activations with a pixel stride, weights [Co][KH][KW][Ci] / [Ci][KH][KW][Co] for
+// the data gradient, 128-byte LDS rows with the slot XOR swizzle applied on the source side of the DMA).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct WGeom {
+    int32_t N, H, W;          // images, map (source and destination have the same size)
+    int32_t Cs, Cd;           // source / destination channels
+    int32_t d, flip;          // 3x3: dilation (= padding); 1: data gradient (mirrored taps)
+    int32_t act;
+    int64_t sld, dld;
+    uint32_t src_bytes, w_bytes, dst_bytes;
+    int32_t tiles_m, tiles_n; // pixel tiles (3x3: N * tiles_y * tiles_x patches), channel tiles
+    int32_t tiles_y, tiles_x;
+    int32_t HW, NP;           // 3x3: halo columns / pixels
+    int32_t wrow;             // elements per weight row (taps * Cs)
+};
+
+template <typename T> struct WMma;
+template <> struct WMma<float> {
+    static constexpr int VEC = 4;
+    // D[channel][pixel] += W[channel][k] * X[pixel][k]
+    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], xf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], xf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], xf[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc, 0, 0, 0);
+    }
+};
+template <> struct WMma<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ void run(f32x4& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    }
+};
+
+constexpr int ROWB = 128;
+constexpr uint32_t OOB = 0xFFFFFFF0u;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// Hand-issued LDS fragment reads.  hipcc schedules ds_reads as late as it can (registers are what it minimises), i.e. right in
+// front of the MFMA that consumes them; with one wave per SIMD that exposes the full LDS latency at every k-step.  Issued from
+// inline asm the reads keep their place -- PF steps ahead of their MFMAs -- and the wave waits with a COUNTED lgkmcnt that leaves
+// the younger steps in flight (cdna_hip_programming.md 5.7 form (iii): "=v" loads, a wait-only statement, sched_barrier(0) so
+// that no MFMA is hoisted above the wait).  addr: 32-bit LDS byte address.
+#define DS_READ_B128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+// s_waitcnt vmcnt(BASE + n * STEP) for a wave-uniform n in 0 .. 3: the DMA ring waits leave (D - 2) younger tiles and the n store
+// groups issued since the awaited tile's DMA in flight (vmcnt retires in issue order, loads, LDS-DMA and stores alike)
+template <int BASE, int STEP> __device__ __forceinline__ void wait_vm(int n) {
+    static_assert(BASE + 3 * STEP <= 63, "vmcnt is a 6-bit counter");
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + STEP) : "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 2 * STEP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 3 * STEP) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// LDS row q of a block's weight tile holds output channel wrow_channel(q): identity for fp32 (a lane's 4 accumulator rows are 4
+// consecutive channels = 16 bytes), and for bf16 the rows of two 16-channel MFMA tiles interleaved in groups of 4 so that tile
+// 2p gives a lane channels 8*fg + 0..3 and tile 2p + 1 channels 8*fg + 4..7 of the 32-channel pair p.
+template <typename T> __device__ __forceinline__ int wrow_channel(int q) {
+    if constexpr (sizeof(T) == 4) return q;
+    const int p = q >> 5, t = (q >> 4) & 1, i = q & 15;
+    return p * 32 + (i >> 2) * 8 + t * 4 + (i & 3);
+}
+
+// ---- epilogue of one (pixel tile i, channel vector v) of a lane: bias, activation, BatchNorm sums, one 16-byte store ------------
+template <typename T, int NI> struct OutVec;
+template <int NI> struct OutVec<bf16_t, NI> {
+    static constexpr int NV = NI / 2, CPV = 8;
+    // channel offset (inside the block's BN channels) of vector v of the lane's wave-column wn, lane group fg
+    __device__ static __forceinline__ int ch(int wn, int v, int fg) { return (wn * NI + 2 * v) * 16 + fg * 8; }
+    __device__ static __forceinline__ void get(const f32x4 (&acc)[NI], int v, float (&o)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = acc[2 * v][e]; o[4 + e] = acc[2 * v + 1][e]; }
+    }
+};
+template <int NI> struct OutVec<float, NI> {
+    static constexpr int NV = NI, CPV = 4;
+    __device__ static __forceinline__ int ch(int wn, int v, int fg) { return (wn * NI + v) * 16 + fg * 4; }
+    __device__ static __forceinline__ void get(const f32x4 (&acc)[NI], int v, float (&o)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[v][e];
+    }
+};
+
+template <typename T, int CPV> __device__ __forceinline__ u32x4 pack_out(const float (&o)[CPV]) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]});
+    } else {
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (bf16_t)o[k];
+        return __builtin_bit_cast(u32x4, v);
+    }
+}
+
+// Per-lane BatchNorm partial sums of the block's output (training forward: the conv is plain, the sums are of the fp32 accumulators
+// exactly as conv3x3.hip's epilogue forms them), kept across tiles; finish() folds lanes -> waves -> fp64 accumulators.
+template <int NV, int CPV, bool ON> struct StatRegs {
+    float s[ON ? NV : 1][ON ? CPV : 1], ss[ON ? NV : 1][ON ? CPV : 1];
+    __device__ __forceinline__ void zero() {
+        if constexpr (ON) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) s[v][k] = ss[v][k] = 0.f;
+        }
+    }
+    __device__ __forceinline__ void add(int v, const float (&o)[CPV], bool valid) {
+        if constexpr (ON) {
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) {
+                const float x = valid ? o[k] : 0.f;
+                s[v][k] += x;
+                ss[v][k] += x * x;
+            }
+        }
+    }
+};
+
+// ================================================================================================================================
+// 1x1 / stride 1.  Block tile BM pixels x BN channels, K = NS slabs of 128 bytes (any channel count that is a multiple of the
+// 16-byte vector: lanes past the last channel fetch nothing and leave zeros).  LDS: [weights NS x BN rows][2 stages x NS x BM rows].
+// ================================================================================================================================
+template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS, int D>
+__global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
+                                                         const float* __restrict__ bias, T* __restrict__ dst, const BnAcc fin,
+                                                         const WGeom g) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are filled 32 rows per DMA pass");
+    constexpr int VEC = WMma<T>::VEC;
+    constexpr int KC = ROWB / (int)sizeof(T);
+    constexpr int AR = BM / 32, BR = BN / 32;
+    typedef OutVec<T, NI> OV;
+    constexpr int NV = OV::NV, CPV = OV::CPV;
+    constexpr int ST = MI * NV;                      // store instructions per wave and tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                  // [NS][BN][128 B]
+    static_assert(D >= 2 && D <= 4, "ring of 2 .. 4 pixel-tile stages");
+    constexpr int LPT = NS * AR;                      // LDS-DMA instructions per wave and pixel tile
+    unsigned char* sA = smem + NS * BN * ROWB;                 // [D][NS][BM][128 B]
+    float* sRed = reinterpret_cast<float*>(sA + D * NS * BM * ROWB);     // [WGM][BN][2] (STATS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int64_t M = (int64_t)g.N * g.H * g.W;
+    const int tn = blockIdx.x % g.tiles_n, grp = blockIdx.x / g.tiles_n, ngrp = gridDim.x / g.tiles_n;
+    const int n0 = tn * BN;
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, g.dst_bytes, 0x00020000);
+
+    // ---- DMA plan: pass i of a tile covers rows 32 i + (tid >> 3); the lane that owns physical slot tid & 7 fetches logical slot ls
+    const int r0 = tid >> 3;
+    const int ls = (tid & 7) ^ ((r0 >> 1) & 7);
+    const bool kin[4] = {ls * VEC < g.Cs, KC + ls * VEC < g.Cs, 2 * KC + ls * VEC < g.Cs, 3 * KC + ls * VEC < g.Cs};
+    auto load_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int ch = n0 + wrow_channel<T>(32 * i + r0);
+            const uint32_t base = ch < g.Cd ? (uint32_t)((int64_t)ch * g.wrow + ls * VEC) * (uint32_t)sizeof(T) : OOB;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t off = (base == OOB || !kin[s]) ? OOB : base + (uint32_t)(s * ROWB);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + ((s * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto load_a = [&](int tm, int stage) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int64_t m = (int64_t)tm * BM + 32 * i + r0;
+            const uint32_t base = (tm < g.tiles_m && m < M) ? (uint32_t)(m * g.sld + ls * VEC) * (uint32_t)sizeof(T) : OOB;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t off = (base == OOB || !kin[s]) ? OOB : base + (uint32_t)(s * ROWB);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    // per-lane epilogue constants: bias of the lane's channel vectors
+    float bv[NV][CPV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = n0 + OV::ch(wn, v, fg);
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) bv[v][k] = (bias && c + k < g.Cd) ? bias[c + k] : 0.f;
+    }
+    StatRegs<NV, CPV, STATS> stat;
+    stat.zero();
+
+    // LDS byte offsets of the fragment reads (slab 0): pixel row / weight row of MFMA index fr, logical slot 4 h + fg swizzled by row
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
+    uint32_t xpre[2][MI], wpre[2][NI];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = (wm * MI + i) * 16 + fr;
+            xpre[h][i] = (uint32_t)(r * ROWB + (((4 * h + fg) ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int r = (wn * NI + j) * 16 + fr;
+            wpre[h][j] = lds0 + (uint32_t)(r * ROWB + (((4 * h + fg) ^ ((r >> 1) & 7)) << 4));
+        }
+    }
+
+    // ring: tiles grp + j ngrp, j = 0 .. D - 2 are requested up front (tiles past the block's share: all lanes out of range, so
+    // that every wave issues the same number of DMA instructions and the counted waits below stay exact)
+    load_w();
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_a(grp + j * ngrp, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPT) : "memory");        // weights + the first tile
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) asm volatile("" : "+v"(bv[v][k]));       // (bias loads retired with the wait above)
+
+    int stage = 0, it = 0;
+    for (int tm = grp; tm < g.tiles_m; tm += ngrp, ++it) {
+        // every wave has waited for its own DMA of this tile and finished reading the stage the next DMA overwrites
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_a(tm + (D - 1) * ngrp, stage == 0 ? D - 1 : stage - 1);
+
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // 2 NS k-steps (slab, 64-byte half); fragments requested PF steps ahead of their MFMAs (see DS_READ_B128)
+        constexpr int NSTEP = 2 * NS, PF = 2;
+        constexpr int RPS = MI + NI;
+        static_assert(RPS * PF <= 15, "lgkmcnt is a 4-bit counter");
+        const uint32_t a0 = lds0 + (uint32_t)(sA - smem) + (uint32_t)(stage * NS * BM * ROWB);
+        u32x4 fx[PF + 1][MI], fw[PF + 1][NI];
+        auto frags = [&](int k, int b) {
+            const int sl = k >> 1, h = k & 1;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const uint32_t a = a0 + xpre[h][i] + (uint32_t)(sl * BM * ROWB);
+                DS_READ_B128(fx[b][i], a);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const uint32_t a = wpre[h][j] + (uint32_t)(sl * BN * ROWB);
+                DS_READ_B128(fw[b][j], a);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < PF && k < NSTEP; ++k) frags(k, k);
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k + PF < NSTEP) {
+                frags(k + PF, (k + PF) % (PF + 1));
+                wait_lgkm<RPS * PF>();
+            } else if (k + 1 < NSTEP) {
+                wait_lgkm<RPS>();
+            } else {
+                wait_lgkm<0>();
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], fw[k % (PF + 1)][j], fx[k % (PF + 1)][i]);
+        }
+        // ---- epilogue straight from the accumulators: lane (fg, fr) owns pixel fr of each 16-pixel tile, channels fg * CPV ..
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int64_t m = (int64_t)tm * BM + (wm * MI + i) * 16 + fr;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = n0 + OV::ch(wn, v, fg);
+                float o[CPV];
+                OV::get(acc[i], v, o);
+                const bool ok = m < M && c < g.Cd;
+                stat.add(v, o, ok);
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
+                if (g.act == DSN_ACT_SILU) {               // (one uniform branch per vector, not per element)
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
+                } else if (g.act == DSN_ACT_SIGMOID) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                }
+                const uint32_t off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
+            }
+        }
+        // the next tile's DMA is older than (D - 2) younger tiles and the store groups issued since: min(it + 1, D - 1) of them
+        wait_vm<(D - 2) * LPT, ST>(it + 1 < D - 1 ? it + 1 : D - 1);
+        stage = stage + 1 == D ? 0 : stage + 1;
+    }
+
+    if constexpr (STATS) {
+        // lanes of one fg group hold different pixels of the same channels: fold the 16 fr lanes, then the WGM waves of a column
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    stat.s[v][k] += __shfl_xor(stat.s[v][k], o);
+                    stat.ss[v][k] += __shfl_xor(stat.ss[v][k], o);
+                }
+            }
+        __syncthreads();
+        if (fr == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) {
+                    const int cl = OV::ch(wn, v, fg) + k;
+                    sRed[(wm * BN + cl) * 2] = stat.s[v][k];
+                    sRed[(wm * BN + cl) * 2 + 1] = stat.ss[v][k];
+                }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cd) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) {
+                t0 += sRed[(w * BN + tid) * 2];
+                t1 += sRed[(w * BN + tid) * 2 + 1];
+            }
+            bn_acc_add(fin, blockIdx.x, n0 + tid, t0, t1);
+        }
+    }
+}
+
+struct WsPlan {
+    int grid;
+    size_t lds;
+};
+
+// grid of persistent blocks: as many as fit the chip at this LDS footprint, every block the same number of tiles where possible
+static WsPlan ws_plan(int tiles_m, int tiles_n, size_t lds, int max_bpc) {
+    int bpc = (int)((160 * 1024) / lds);
+    if (bpc < 1) bpc = 1;
+    if (bpc > max_bpc) bpc = max_bpc;
+    int groups = (256 * bpc) / tiles_n;
+    if (groups < 1) groups = 1;
+    if (groups > tiles_m) groups = tiles_m;
+    const int per = (tiles_m + groups - 1) / groups;
+    groups = (tiles_m + per - 1) / per;
+    return WsPlan{groups * tiles_n, lds};
+}
+
+template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS>
+int launch_1x1_ws(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, WGeom g, const BnAcc& fin,
+                  int is_dgrad, hipStream_t st) {
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    // pixel-tile stages: as deep as keeps two blocks per CU (weights + ring <= ~78 KB), 2 .. 4
+    constexpr int TILEB = NS * BM * ROWB, WB1 = NS * BN * ROWB;
+    constexpr int DFIT = (78 * 1024 - WB1) / TILEB;
+    constexpr int D = DFIT >= 4 ? 4 : (DFIT >= 3 ? 3 : 2);
+    const int64_t M = (int64_t)g.N * g.H * g.W;
+    g.tiles_m = (int)((M + BM - 1) / BM);
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    const size_t lds = (size_t)NS * (BN + D * BM) * ROWB + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
+    static const int max_bpc = [] { const char* e = getenv("DSN_WS_BPC"); return e ? atoi(e) : 4; }();
+    const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, max_bpc);
+    auto kern = conv1x1_ws_kernel<T, MI, NI, WGM, WGN, NS, STATS, D>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const double elems = (double)M * (g.Cs + (double)g.Cd) + (double)g.Cs * g.Cd;
+    const ProfConv pc("conv1x1_ws_kernel", sizeof(T) == 2, BM, BN, is_dgrad != 0, 1, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g);
+    DSN_LAUNCH_CHECK("conv1x1 (weights-stationary)");
+    return DSN_OK;
+}
+
+template <typename T, int MI, int NI, int WGM, int WGN, bool STATS>
+int launch_1x1_ws_ns(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
+                     int is_dgrad, hipStream_t st, int ns) {
+    switch (ns) {
+        case 1: return launch_1x1_ws<T, MI, NI, WGM, WGN, 1, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
+        case 2: return launch_1x1_ws<T, MI, NI, WGM, WGN, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
+        case 3: return launch_1x1_ws<T, MI, NI, WGM, WGN, 3, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
+        case 4: return launch_1x1_ws<T, MI, NI, WGM, WGN, 4, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
+        default: return 1;
+    }
+}
+
+template <typename T, bool STATS>
+int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
+                      int is_dgrad, hipStream_t st, int ns) {
+    static const int force = [] { const char* e = getenv("DSN_WS_CFG"); return e ? atoi(e) : -1; }();     // tuning knob
+    int cfg = force;
+    if (cfg < 0) cfg = g.Cd <= 32 ? 2 : (ns >= 3 ? 1 : 0);
+    switch (cfg) {
+        case 1: return launch_1x1_ws_ns<T, 1, 2, 2, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);     // 32 x 64
+        case 2: return launch_1x1_ws_ns<T, 2, 2, 4, 1, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);     // 128 x 32
+        case 3: return launch_1x1_ws_ns<T, 4, 2, 2, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);     // 128 x 64
+        default: return launch_1x1_ws_ns<T, 2, 2, 2, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);    // 64 x 64
+    }
+}
+
+
+// ================================================================================================================================
+// 3x3 / stride 1 / dilation d (padding d).  A block owns BN output channels -- ALL nine taps of their weights stay in LDS
+// ([tap][slab][BN rows][128 B]: 72 KB for 64 channels x one 64-channel slab) -- and walks a contiguous range of TH x TW output
+// patches; per (patch, slab) the (TH + 2d) x (TW + 2d) halo of the slab arrives by LDS-DMA into one of two stages while the previous
+// one is multiplied: nine taps = nine shifted reads of the halo, 18 k-steps without a barrier (conv3x3.hip streams the weights of
+// every tap through a ring behind a barrier per tap, once per 64 pixels).  Halo swizzle as conv3x3.hip's hslot().
+// ================================================================================================================================
+__device__ __forceinline__ int hslot(int slot, int hx) { return (((slot >> 1) ^ ((hx >> 1) & 3)) << 1) | (slot & 1); }
+
+template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, int NS, bool STATS, int D, bool HP>
+__global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
+                                                         const float* __restrict__ bias, T* __restrict__ dst, const BnAcc fin,
+                                                         const WGeom g) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    static_assert(BM == TH * TW, "the pixel tile is the TH x TW patch");
+    static_assert(BN % 32 == 0, "weight rows are filled 32 per DMA pass");
+    constexpr int VEC = WMma<T>::VEC;
+    constexpr int KC = ROWB / (int)sizeof(T);
+    constexpr int BR = BN / 32;
+    typedef OutVec<T, NI> OV;
+    constexpr int NV = OV::NV, CPV = OV::CPV;
+    constexpr int ST = MI * NV;
+    constexpr int HSTAGE = IH * 32 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                  // [9][NS][BN][128 B]
+    static_assert(D >= 2 && D <= 4 && (NS == 1 || NS == 2), "ring of 2 .. 4 halo stages; one or two slabs");
+    unsigned char* sH = smem + 9 * NS * BN * ROWB;             // [D][IH * 32][128 B]
+    float* sRed = reinterpret_cast<float*>(sH + D * HSTAGE);   // [WGM][BN][2] (STATS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tn = blockIdx.x % g.tiles_n, grp = blockIdx.x / g.tiles_n, ngrp = gridDim.x / g.tiles_n;
+    const int n0 = tn * BN;
+    const int per = (g.tiles_m + ngrp - 1) / ngrp;              // contiguous patch range of this block: neighbours share halo columns
+    const int t_begin = grp * per, t_end = (t_begin + per < g.tiles_m) ? t_begin + per : g.tiles_m;
+    const int tiles_img = g.tiles_y * g.tiles_x;
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, g.dst_bytes, 0x00020000);
+
+    // ---- weights: row q = 32 i + (tid >> 3) of (tap, slab); the lane that owns physical slot tid & 7 fetches logical slot lsw
+    const int r0 = tid >> 3;
+    const int lsw = (tid & 7) ^ ((r0 >> 1) & 7);
+    auto load_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int ch = n0 + wrow_channel<T>(32 * i + r0);
+            const uint32_t base = ch < g.Cd ? (uint32_t)((int64_t)ch * g.wrow + lsw * VEC) * (uint32_t)sizeof(T) : OOB;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bool kin = s * KC + lsw * VEC < g.Cs;
+                    const uint32_t off = (base == OOB || !kin) ? OOB : base + (uint32_t)((t * g.Cs + s * KC) * (int)sizeof(T));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (((t * NS + s) * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                }
+        }
+    };
+    // ---- halo: instruction j of this wave covers halo pixels 32 j + 8 wave .. + 8; lane -> pixel p, physical slot lane & 7
+    // chunk c of this block = (patch t_begin + c / NS, slab c % NS); chunks past the block's range: every lane out of range
+    auto load_halo = [&](int c, int stage) {
+        const int tile = t_begin + c / NS, slab = c % NS;
+        const bool live = tile < t_end;
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < IH; ++j) {
+            const int p = 32 * j + 8 * wave + (lane >> 3);
+            const int hy = p / g.HW, hx = p - hy * g.HW;
+            const int gy = y0 - g.d + hy, gx = x0 - g.d + hx;
+            const int ls = hslot(lane & 7, hx);
+            const bool ok = live && p < g.NP && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W && slab * KC + ls * VEC < g.Cs;
+            const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + slab * KC + ls * VEC) * (uint32_t)sizeof(T) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (32 * j + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+        }
+    };
+
+    float bv[NV][CPV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = n0 + OV::ch(wn, v, fg);
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) bv[v][k] = (bias && c + k < g.Cd) ? bias[c + k] : 0.f;
+    }
+    StatRegs<NV, CPV, STATS> stat;
+    stat.zero();
+
+    // fragment addressing: MFMA column fr of pixel tile i is patch pixel r = (wm MI + i) 16 + fr = (r / TW, r % TW)
+    int hp0[MI], hx0[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = (wm * MI + i) * 16 + fr;
+        hx0[i] = r % TW;
+        hp0[i] = (r / TW) * g.HW + hx0[i];
+    }
+
+    // LDS byte offsets of the fragment reads: xpre[column tap rx][half h][i] = halo pixel (row of r, column of r + rx d), logical
+    // slot 4 h + fg through hslot(); wpre[h][j] = weight row of MFMA row fr in tile j (tap 0, slab 0), slot swizzled by row
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
+    uint32_t xpre[3][2][MI], wpre[2][NI];
+#pragma unroll
+    for (int rx = 0; rx < 3; ++rx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                xpre[rx][h][i] = (uint32_t)((hp0[i] + rx * g.d) * ROWB + (hslot(4 * h + fg, hx0[i] + rx * g.d) << 4));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int r = (wn * NI + j) * 16 + fr;
+            wpre[h][j] = lds0 + (uint32_t)(r * ROWB + (((4 * h + fg) ^ ((r >> 1) & 7)) << 4));
+        }
+
+    load_w();
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_halo(j, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");         // weights + the first chunk
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) asm volatile("" : "+v"(bv[v][k]));
+
+    int stage = 0, c = 0;                    // c: chunk counter of this block
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            load_halo(c + D - 1, stage == 0 ? D - 1 : stage - 1);      // into the stage chunk c - 1 has just released
+            if constexpr (HP) {
+            // 18 k-steps (tap, 64-byte half); the fragments of step k + PF are requested before the MFMAs of step k
+            constexpr int NSTEP = 18, PF = 2;
+            const uint32_t hb = lds0 + (uint32_t)(sH - smem) + (uint32_t)(stage * HSTAGE);
+            u32x4 fx[PF + 1][MI], fw[PF + 1][NI];
+            auto frags = [&](int k, int b) {
+                const int t = k >> 1, h = k & 1;
+                const int ky = t / 3, kx = t - ky * 3;
+                const int ry = g.flip ? 2 - ky : ky, rx = g.flip ? 2 - kx : kx;
+                const uint32_t rowoff = (uint32_t)(ry * g.d * g.HW) * ROWB;           // wave-uniform
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const uint32_t a = hb + rowoff + xpre[rx][h][i];
+                    DS_READ_B128(fx[b][i], a);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const uint32_t a = wpre[h][j] + (uint32_t)((t * NS + s) * BN * ROWB);
+                    DS_READ_B128(fw[b][j], a);
+                }
+            };
+            auto mma = [&](int b) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], fw[b][j], fx[b][i]);
+            };
+            constexpr int RPS = MI + NI;                         // reads per step
+            static_assert(PF == 2 && RPS * PF <= 15, "two steps ahead; lgkmcnt is a 4-bit counter");
+#pragma unroll
+            for (int k = 0; k < PF; ++k) frags(k, k);
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                if (k + PF < NSTEP) {
+                    frags(k + PF, (k + PF) % (PF + 1));
+                    wait_lgkm<RPS * PF>();
+                } else if (k + 1 < NSTEP) {
+                    wait_lgkm<RPS>();                               // k == NSTEP - 2: one younger step still in flight
+                } else {
+                    wait_lgkm<0>();
+                }
+                mma(k % (PF + 1));
+            }
+            } else {
+                // compiler-scheduled fragment reads (measured faster than the hand-issued form on the 8 x 16 patch configurations)
+                const unsigned char* hbp = sH + stage * HSTAGE;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    const int oy = (g.flip ? 2 - ky : ky) * g.d, ox = (g.flip ? 2 - kx : kx) * g.d;
+                    const int toff = oy * g.HW + ox;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 gx[MI], gw[NI];
+                        const int slot = 4 * h + fg;
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            gx[i] = *reinterpret_cast<const u32x4*>(hbp + (hp0[i] + toff) * ROWB + (hslot(slot, hx0[i] + ox) << 4));
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const int r = (wn * NI + j) * 16 + fr;
+                            gw[j] = *reinterpret_cast<const u32x4*>(sW + ((t * NS + s) * BN + r) * ROWB + ((slot ^ ((r >> 1) & 7)) << 4));
+                        }
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], gw[j], gx[i]);
+                    }
+                }
+            }
+            if (s + 1 < NS) {
+                // chunk c + 1 (the next slab of this patch) is older than D - 2 younger halos and the store groups issued since its
+                // DMA went out at the start of chunk c - D + 2: chunks j in [c - D + 2, c] with j % NS == NS - 1 (and j >= 0)
+                int nst = 0;
+#pragma unroll
+                for (int b = 0; b <= D - 2; ++b) nst += (c - b >= 0 && (c - b) % NS == NS - 1) ? 1 : 0;
+                wait_vm<(D - 2) * IH, ST>(nst);
+                ++c;
+            }
+            stage = stage + 1 == D ? 0 : stage + 1;
+        }
+        // ---- epilogue: lane (fg, fr) owns patch pixel (r / TW, r % TW) of each 16-pixel tile, channels fg * CPV ..
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = (wm * MI + i) * 16 + fr;
+            const int y = y0 + r / TW, x = x0 + r % TW;
+            const int64_t m = ((int64_t)n * g.H + y) * g.W + x;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = n0 + OV::ch(wn, v, fg);
+                float o[CPV];
+                OV::get(acc[i], v, o);
+                const bool ok = y < g.H && x < g.W && c < g.Cd;
+                stat.add(v, o, ok);
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
+                if (g.act == DSN_ACT_SILU) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
+                } else if (g.act == DSN_ACT_SIGMOID) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                }
+                const uint32_t off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
+            }
+        }
+        {   // as above, after this patch's ST stores (chunk c is a last-slab chunk)
+            int nst = 0;
+#pragma unroll
+            for (int b = 0; b <= D - 2; ++b) nst += (c - b >= 0 && (c - b) % NS == NS - 1) ? 1 : 0;
+            wait_vm<(D - 2) * IH, ST>(nst);
+            ++c;
+        }
+    }
+
+    if constexpr (STATS) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    stat.s[v][k] += __shfl_xor(stat.s[v][k], o);
+                    stat.ss[v][k] += __shfl_xor(stat.ss[v][k], o);
+                }
+            }
+        __syncthreads();
+        if (fr == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) {
+                    const int cl = OV::ch(wn, v, fg) + k;
+                    sRed[(wm * BN + cl) * 2] = stat.s[v][k];
+                    sRed[(wm * BN + cl) * 2 + 1] = stat.ss[v][k];
+                }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cd) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) {
+                t0 += sRed[(w * BN + tid) * 2];
+                t1 += sRed[(w * BN + tid) * 2 + 1];
+            }
+            bn_acc_add(fin, blockIdx.x, n0 + tid, t0, t1);
+        }
+    }
+}
+
+template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, int NS, bool STATS>
+int launch_3x3_ws(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, WGeom g, const BnAcc& fin,
+                  hipStream_t st) {
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    // halo stages: as many (<= 4) as fit next to the weights in 150 KB
+    constexpr int WB = 9 * NS * BN * ROWB, HS = IH * 32 * ROWB;
+    constexpr int RED = STATS ? WGM * BN * 2 * 4 : 0, CAP = 160 * 1024;
+    constexpr int D = (WB + 4 * HS + RED <= CAP) ? 4 : (WB + 3 * HS + RED <= CAP) ? 3 : 2;
+    g.tiles_y = (g.H + TH - 1) / TH;
+    g.tiles_x = (g.W + TW - 1) / TW;
+    g.tiles_m = g.N * g.tiles_y * g.tiles_x;
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    g.HW = TW + 2 * g.d;
+    g.NP = (TH + 2 * g.d) * g.HW;
+    if (g.NP > IH * 32) return 1;
+    const size_t lds = (size_t)WB + (size_t)D * HS + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
+    if (lds > 160 * 1024) return 1;
+    const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 2);
+    constexpr bool HP = TW == 8;          // hand-issued fragment reads: measured +10 % on 8 x 8 patches, -30 % on 8 x 16 ones
+    auto kern = conv3x3_ws_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, NS, STATS, D, HP>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd) + 9.0 * g.Cs * g.Cd;
+    const ProfConv pc("conv3x3_ws_kernel", sizeof(T) == 2, BM, BN, g.flip != 0, 3, 1, g.d, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * sizeof(T), st);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g);
+    DSN_LAUNCH_CHECK("conv3x3 (weights-stationary)");
+    return DSN_OK;
+}
+
+// shape dispatch: dilation picks the halo size (IH), channels the (slabs, BN) pair whose weights fit LDS
+template <typename T, bool STATS>
+int launch_3x3_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
+                      hipStream_t st, int ns) {
+    // 8 x 8 patches: (8 + 2d)^2 halo pixels = 100 / 144 / 196 -> IH 4 / 5 / 7
+    if (ns == 1 && g.Cd > 32) {        // 64 output channels per block, one slab: 72 KB of weights
+        if (g.d == 1) return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 4, 1, STATS>(s, w, bias, d, g, fin, st);
+        if (g.d == 2) return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 5, 1, STATS>(s, w, bias, d, g, fin, st);
+        return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 7, 1, STATS>(s, w, bias, d, g, fin, st);
+    }
+    if (ns == 1) {                     // <= 32 output channels: 8 x 16 patches x 32 channels (36 KB of weights)
+        if (g.d == 1) return launch_3x3_ws<T, 8, 16, 2, 2, 4, 1, 6, 1, STATS>(s, w, bias, d, g, fin, st);
+        return 1;
+    }
+    if (ns == 2) {                     // two slabs: 32 output channels per block
+        if (g.d == 1) return launch_3x3_ws<T, 8, 16, 2, 2, 4, 1, 6, 2, STATS>(s, w, bias, d, g, fin, st);
+        return 1;
+    }
+    return 1;
+}
+
+}  // namespace
+
+// Tried by the convolution entry points of igemm.hip BEFORE the one-trip kernels of conv3x3.hip.  Returns 1 when the launch is not
+// one this kernel takes (nothing launched), 0 when it ran, < 0 / hipError on failure.
+int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br) {
+    static const int mode = [] { const char* e = getenv("DSN_WS"); return e ? atoi(e) : 1; }();       // 0: never
+    if (!mode) return 1;
+    if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0) return 1;
+    if (r || p->accumulate || (br && br->nseg > 0)) return 1;
+    if (s->h != d->h || s->w != d->w || s->n != d->n || s->dtype != d->dtype) return 1;
+    const int es = s->dtype == DSN_F32 ? 4 : 2, vec = 16 / es, kc = ROWB / es;
+    const int ns = (s->c + kc - 1) / kc;
+    if (s->c % vec != 0 || ns > 4 || d->c % vec != 0 || s->ldc % vec != 0 || d->ldc % vec != 0) return 1;
+    if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
+    const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * es, wb = (int64_t)d->c * s->c * es;
+    const int64_t db = ((npix(d) - 1) * d->ldc + d->c) * es;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || db >= (1ll << 32) - 64) return 1;
+    if (npix(d) < 2048) return 1;              // tiny maps (pyramid pooling, FFM attention): one-trip kernels
+    WGeom g{};
+    g.N = s->n; g.H = s->h; g.W = s->w; g.Cs = s->c; g.Cd = d->c;
+    g.act = p->act;
+    g.sld = s->ldc; g.dld = d->ldc;
+    g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb; g.dst_bytes = (uint32_t)db;
+    g.wrow = s->c;
+    BnAcc fin{};
+    if (finp) fin = *finp;
+    hipStream_t st = (hipStream_t)stream;
+    if (fin.acc) {
+        if (bias || p->act != DSN_ACT_NONE) return 1;
+        if (s->dtype == DSN_F32) return launch_1x1_ws_cfg<float, true>(s, w, bias, d, g, fin, is_dgrad, st, ns);
+        return launch_1x1_ws_cfg<bf16_t, true>(s, w, bias, d, g, fin, is_dgrad, st, ns);
+    }
+    if (s->dtype == DSN_F32) return launch_1x1_ws_cfg<float, false>(s, w, bias, d, g, fin, is_dgrad, st, ns);
+    return launch_1x1_ws_cfg<bf16_t, false>(s, w, bias, d, g, fin, is_dgrad, st, ns);
+}
+
+
+int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br) {
+    static const int mode = [] { const char* e = getenv("DSN_WS3"); return e ? atoi(e) : 1; }();       // 0: never
+    if (!mode) return 1;
+    if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->dil < 1 || p->dil > 3) return 1;
+    if (r || p->accumulate || (br && br->nseg > 0)) return 1;
+    if (s->h != d->h || s->w != d->w || s->n != d->n || s->dtype != d->dtype) return 1;
+    const int es = s->dtype == DSN_F32 ? 4 : 2, vec = 16 / es, kc = ROWB / es;
+    const int ns = (s->c + kc - 1) / kc;
+    if (s->c % vec != 0 || ns > 2 || d->c % vec != 0 || s->ldc % vec != 0 || d->ldc % vec != 0) return 1;
+    if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
+    const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * es, wb = (int64_t)d->c * 9 * s->c * es;
+    const int64_t db = ((npix(d) - 1) * d->ldc + d->c) * es;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || db >= (1ll << 32) - 64) return 1;
+    if (npix(d) < 2048) return 1;
+    WGeom g{};
+    g.N = s->n; g.H = s->h; g.W = s->w; g.Cs = s->c; g.Cd = d->c; g.d = p->dil; g.flip = is_dgrad ? 1 : 0;
+    g.act = p->act;
+    g.sld = s->ldc; g.dld = d->ldc;
+    g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb; g.dst_bytes = (uint32_t)db;
+    g.wrow = 9 * s->c;
+    BnAcc fin{};
+    if (finp) fin = *finp;
+    hipStream_t st = (hipStream_t)stream;
+    if (fin.acc) {
+        if (bias || p->act != DSN_ACT_NONE) return 1;
+        if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, true>(s, w, bias, d, g, fin, st, ns);
+        return launch_3x3_ws_cfg<bf16_t, true>(s, w, bias, d, g, fin, st, ns);
+    }
+    if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, false>(s, w, bias, d, g, fin, st, ns);
+    return launch_3x3_ws_cfg<bf16_t, false>(s, w, bias, d, g, fin, st, ns);
+}

@@ -185,6 +185,86 @@ __global__ __launch_bounds__(256) void maxpool_multi_kernel(const T* __restrict_
     }
 }
 
+// The three SPP pools as a CASCADE (round 3): window sizes k0, 2 k0 - 1, 3 k0 - 2 (5 / 9 / 13, common.py:172-185) are pool_k0
+// applied once, twice, three times -- with the clipped (-inf padded) windows of MaxPool2d the reachable set of the composition is
+// exactly the larger clipped window.  ATen's "first maximum in row-major window order" is the maximum of (value, flat index) pairs
+// under (value descending, index ascending), which IS associative, so the cascade carries pairs and reproduces the arg-max bit for
+// bit: 6 separable passes of k0 pair reads per element instead of 2 (5 + 9 + 13).  A block owns one image x one 16-byte channel
+// vector for ALL three outputs (the old kernel: one block per output, 256 threads, 42 us on 8 x 256 x 20 x 20).
+template <typename T, int V, int NT>
+__global__ __launch_bounds__(NT) void maxpool_cascade_kernel(const T* __restrict__ x, int64_t xld, const MaxFwd out, int H, int W,
+                                                             int C, int r) {
+    extern __shared__ float smp[];
+    const int HW = H * W, PL = HW * V;
+    float* val[2] = {smp, smp + PL};
+    int* idx[2] = {reinterpret_cast<int*>(smp + 2 * PL), reinterpret_cast<int*>(smp + 3 * PL)};
+    const int ncv = C / V;
+    const int n = blockIdx.x / ncv, cv = blockIdx.x % ncv;
+    for (int p = threadIdx.x; p < HW; p += NT) {
+        float v[V];
+        VecIO<T, V>::load(x + ((int64_t)n * HW + p) * xld + cv * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { val[0][k * HW + p] = v[k]; idx[0][k * HW + p] = p; }
+    }
+    __syncthreads();
+    // (value, index) a beats b: larger value, or equal value at a smaller flat index; a NaN always wins (as ATen's scan keeps it)
+    auto better = [](float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi) || v != v; };
+    for (int stage = 0; stage < out.n; ++stage) {
+        // row pass: buffer 0 -> 1
+        for (int it = threadIdx.x; it < PL; it += NT) {
+            const int k = it / HW, p = it - k * HW;
+            const int row = p / W, w = p - row * W;
+            const int w0 = w - r < 0 ? 0 : w - r, w1 = w + r >= W ? W - 1 : w + r;
+            const float* sv = val[0] + k * HW + row * W;
+            const int* si = idx[0] + k * HW + row * W;
+            float bv = sv[w0];
+            int bi = si[w0];
+            for (int c = w0 + 1; c <= w1; ++c) {
+                const float v = sv[c];
+                const int i = si[c];
+                if (better(v, i, bv, bi)) { bv = v; bi = i; }
+            }
+            val[1][it] = bv;
+            idx[1][it] = bi;
+        }
+        __syncthreads();
+        // column pass: buffer 1 -> 0
+        for (int it = threadIdx.x; it < PL; it += NT) {
+            const int k = it / HW, p = it - k * HW;
+            const int h = p / W, w = p - h * W;
+            const int h0 = h - r < 0 ? 0 : h - r, h1 = h + r >= H ? H - 1 : h + r;
+            const float* sv = val[1] + k * HW + w;
+            const int* si = idx[1] + k * HW + w;
+            float bv = sv[h0 * W];
+            int bi = si[h0 * W];
+            for (int rr = h0 + 1; rr <= h1; ++rr) {
+                const float v = sv[rr * W];
+                const int i = si[rr * W];
+                if (better(v, i, bv, bi)) { bv = v; bi = i; }
+            }
+            val[0][it] = bv;
+            idx[0][it] = bi;
+        }
+        __syncthreads();
+        T* y = (T*)out.y[stage];
+        for (int p = threadIdx.x; p < HW; p += NT) {
+            float res[V];
+            int q[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) { res[k] = val[0][k * HW + p]; q[k] = idx[0][k * HW + p]; }
+            const int64_t op = (int64_t)n * HW + p;
+            VecIO<T, V>::store(y + op * out.ld[stage] + cv * V, res);
+            if (out.idx[stage]) {
+#pragma unroll
+                for (int k = 0; k < V; k += 4)
+                    *reinterpret_cast<u32x4*>(out.idx[stage] + op * C + cv * V + k) =
+                        u32x4{(uint32_t)q[k], (uint32_t)q[k + 1], (uint32_t)q[k + 2], (uint32_t)q[k + 3]};
+            }
+        }
+        // (the next stage's row pass only reads buffer 0 and writes buffer 1: no barrier needed between this store loop and it)
+    }
+}
+
 // dx[n][q][c] (+)= sum over outputs p whose window contains q and whose arg-max is q
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, int64_t yld, const int32_t* __restrict__ idx,
@@ -507,6 +587,77 @@ __global__ void bilinear_bwd_vec_kernel(const T* __restrict__ dy, int64_t yld, T
     }
 }
 
+// Separable form of the same (round 3): a block owns one dx ROW (n, hi) and a range of channel vectors.  Pass 1 folds the few dy
+// rows that touch hi into an fp32 row t[wo][c] in LDS (dy rows are read as whole contiguous NHWC lines); pass 2 folds, for every dx
+// pixel of the row, the few columns that touch it.  The gather form above walks a (2 scale + 3)^2 window per dx vector with a lerp
+// evaluation per candidate (121 candidates at x4: 38.9 us for the seg head's m32 branch, 13 MB of dy); here every dy row is read
+// about twice in total and the lerp arithmetic is per row / per column.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld,
+                                                                int Hi, int Wi, int Ho, int Wo, int C, int cvb, float sh, float sw,
+                                                                int accumulate) {
+    extern __shared__ float trow[];                    // [Wo][cvb * V]
+    const int nsplit = (C / V + cvb - 1) / cvb;
+    const int part = blockIdx.x % nsplit;
+    const int row = blockIdx.x / nsplit;               // n * Hi + hi
+    const int hi = row % Hi, n = row / Hi;
+    const int cv0 = part * cvb;
+    const int ncv = (C / V - cv0) < cvb ? (C / V - cv0) : cvb;
+    int h_lo = 0, h_hi = Ho - 1;
+    if (sh > 0.f) {
+        h_lo = (int)floorf((float)(hi - 1) / sh) - 1;
+        h_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
+        h_lo = h_lo < 0 ? 0 : h_lo;
+        h_hi = h_hi > Ho - 1 ? Ho - 1 : h_hi;
+    }
+    for (int it = threadIdx.x; it < Wo * ncv; it += 256) {
+        const int wo = it / ncv, cv = it - wo * ncv;
+        float sacc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) sacc[k] = 0.f;
+        for (int ho = h_lo; ho <= h_hi; ++ho) {
+            const Lerp a = lerp_coord(ho, sh, Hi);
+            const float wh = (a.i0 == hi ? a.l0 : 0.f) + (a.i1 == hi ? a.l1 : 0.f);
+            if (wh == 0.f) continue;
+            float g[V];
+            VecIO<T, V>::load(dy + (((int64_t)n * Ho + ho) * Wo + wo) * yld + (cv0 + cv) * V, g);
+#pragma unroll
+            for (int k = 0; k < V; ++k) sacc[k] += wh * g[k];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) trow[(wo * cvb + cv) * V + k] = sacc[k];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < Wi * ncv; it += 256) {
+        const int wi = it / ncv, cv = it - wi * ncv;
+        int w_lo = 0, w_hi = Wo - 1;
+        if (sw > 0.f) {
+            w_lo = (int)floorf((float)(wi - 1) / sw) - 1;
+            w_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
+            w_lo = w_lo < 0 ? 0 : w_lo;
+            w_hi = w_hi > Wo - 1 ? Wo - 1 : w_hi;
+        }
+        float sacc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) sacc[k] = 0.f;
+        for (int wo = w_lo; wo <= w_hi; ++wo) {
+            const Lerp b = lerp_coord(wo, sw, Wi);
+            const float ww = (b.i0 == wi ? b.l0 : 0.f) + (b.i1 == wi ? b.l1 : 0.f);
+            if (ww == 0.f) continue;
+#pragma unroll
+            for (int k = 0; k < V; ++k) sacc[k] += ww * trow[(wo * cvb + cv) * V + k];
+        }
+        T* o = dx + (((int64_t)n * Hi + hi) * Wi + wi) * xld + (cv0 + cv) * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) sacc[k] += old[k];
+        }
+        VecIO<T, V>::store(o, sacc);
+    }
+}
+
 // NCHW fp32 dy (the full-resolution seg-logit gradient) -> NHWC dx, separable: a block owns one (n, c, hi) row of dx.
 // Pass 1: every thread folds its dy COLUMNS over the few dy rows that touch hi (coalesced along w) into LDS; pass 2: every
 // dx pixel of the row folds the few columns that touch it.  The gather form above reads a ~17x17 window per dx element
@@ -632,6 +783,94 @@ __global__ void adaptive_avgpool_bwd_multi_kernel(const PoolSrcs srcs, T* __rest
                     const float area = (float)((h1 - h0) * (w1 - w0));
 #pragma unroll
                     for (int k = 0; k < V; ++k) s[k] += v[k] / area;
+                }
+            }
+        }
+        T* o = dx + (((int64_t)n * H + h) * W + w) * xld + cv * V;
+        if (accumulate) {
+            float old[V];
+            VecIO<T, V>::load(o, old);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += old[k];
+        }
+        VecIO<T, V>::store(o, s);
+    }
+}
+
+// Row form of the same (round 3): a block owns one dx row (n, h).  The pooled rows that contain h (at most two per source:
+// adaptive bins overlap by one row when H is not a multiple of the grid) are block-uniform, and the bins of every column are
+// tabulated once per block in LDS -- the element loop is left with loads, multiplies by a reciprocal bin area and adds.  (The form
+// above spends ~100 integer divisions per 16-byte vector on bin arithmetic: 37 us for PyramidPooling's 8 x 128 x 80 x 80 dx.)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_rows_kernel(const PoolSrcs srcs, T* __restrict__ dx, int64_t xld, int H,
+                                                                        int W, int C, int accumulate) {
+    extern __shared__ int ctab[];                      // [4 sources][W][4]: ow0, ow1 (or -1), 1/width bits of each
+    const int h = blockIdx.x % H, n = blockIdx.x / H;
+    const int ncv = C / V;
+    for (int it = threadIdx.x; it < srcs.n * W; it += 256) {
+        const int b = it / W, w = it - b * W;
+        const int KW = srcs.KW[b];
+        const int ow0 = (w * KW) / W;
+        int cand[3] = {ow0 - 1, ow0, ow0 + 1}, got = 0;
+        int o[2] = {-1, -1};
+        float inv[2] = {0.f, 0.f};
+        for (int j = 0; j < 3; ++j) {
+            const int ow = cand[j];
+            if (ow < 0 || ow >= KW || got == 2) continue;
+            const int w0 = bin_lo(ow, W, KW), w1 = bin_hi(ow, W, KW);
+            if (w < w0 || w >= w1) continue;
+            o[got] = ow;
+            inv[got] = 1.f / (float)(w1 - w0);
+            ++got;
+        }
+        int* e = ctab + (b * W + w) * 4;
+        e[0] = o[0]; e[1] = o[1]; e[2] = __float_as_int(inv[0]); e[3] = __float_as_int(inv[1]);
+    }
+    // rows: block-uniform (scalar) arithmetic
+    int oh[4][2];
+    float ih[4][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        oh[b][0] = oh[b][1] = -1;
+        ih[b][0] = ih[b][1] = 0.f;
+        if (b >= srcs.n) continue;
+        const int KH = srcs.KH[b];
+        const int oh0 = (h * KH) / H;
+        bool first = true;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            const int c = oh0 + j;
+            if (c < 0 || c >= KH) continue;
+            const int h0 = bin_lo(c, H, KH), h1 = bin_hi(c, H, KH);
+            if (h < h0 || h >= h1) continue;
+            if (first) { oh[b][0] = c; ih[b][0] = 1.f / (float)(h1 - h0); first = false; }
+            else { oh[b][1] = c; ih[b][1] = 1.f / (float)(h1 - h0); }
+        }
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < W * ncv; it += 256) {
+        const int w = it / ncv, cv = it - w * ncv;
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b >= srcs.n) continue;
+            const T* dy = (const T*)srcs.dy[b];
+            const int* e = ctab + (b * W + w) * 4;
+            const int KW = srcs.KW[b];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (oh[b][a] < 0) continue;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ow = e[c];
+                    if (ow < 0) continue;
+                    const float f = ih[b][a] * __int_as_float(e[2 + c]);
+                    float v[V];
+                    VecIO<T, V>::load(dy + (((int64_t)n * srcs.KH[b] + oh[b][a]) * KW + ow) * srcs.ld[b] + cv * V, v);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) s[k] += v[k] * f;
                 }
             }
         }
@@ -1028,7 +1267,25 @@ extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, v
     const int HW = x->h * x->w;
     const int V = x->dtype == DSN_F32 ? 4 : 8;
     const size_t lds = (size_t)HW * V * 3 * sizeof(float);
-    if (vec && lds <= 60 * 1024) {
+    // cascade form: outputs k0, 2 k0 - 1, 3 k0 - 2 in this order (SPP's 5 / 9 / 13)
+    bool cascade = vec && (size_t)HW * V * 4 * sizeof(float) <= 64 * 1024;
+    for (int i = 0; i < n_out; ++i) cascade = cascade && ks[i] == (i + 1) * (ks[0] - 1) + 1;
+    static const bool no_cascade = getenv("DSN_MAXPOOL_CASCADE") && atoi(getenv("DSN_MAXPOOL_CASCADE")) == 0;
+    if (cascade && !no_cascade) {
+        MaxFwd out{};
+        out.n = n_out;
+        for (int i = 0; i < n_out; ++i) {
+            out.y[i] = ys[i].ptr; out.ld[i] = ys[i].ldc; out.idx[i] = idxs ? (int32_t*)idxs[i] : nullptr; out.k[i] = ks[i];
+        }
+        const dim3 grid(x->n * (x->c / V));
+        const size_t l4 = (size_t)HW * V * 4 * sizeof(float);
+        if (x->dtype == DSN_F32)
+            hipLaunchKernelGGL((maxpool_cascade_kernel<float, 4, 512>), grid, dim3(512), l4, st, (const float*)x->ptr, x->ldc, out,
+                               x->h, x->w, x->c, ks[0] / 2);
+        else
+            hipLaunchKernelGGL((maxpool_cascade_kernel<bf16_t, 8, 1024>), grid, dim3(1024), l4, st, (const bf16_t*)x->ptr, x->ldc,
+                               out, x->h, x->w, x->c, ks[0] / 2);
+    } else if (vec && lds <= 60 * 1024) {
         MaxFwd out{};
         out.n = n_out;
         for (int i = 0; i < n_out; ++i) {
@@ -1208,6 +1465,27 @@ extern "C" int dsn_bilinear_ac_bwd(const dsn_tensor* dy, int32_t dy_nchw, const 
         });
         DSN_LAUNCH_CHECK("bilinear_ac_bwd (split)");
         return DSN_OK;
+    }
+    if (!dy_nchw && vec16(dx) && vec16(dy) && dy->h >= dx->h && dy->w >= dx->w) {
+        // separable rows form: one block per dx row and per group of channel vectors (<= 48 KB of fp32 row in LDS, enough blocks
+        // to cover the chip)
+        const int V = dx->dtype == DSN_F32 ? 4 : 8;
+        const int ncv = dx->c / V;
+        int cvb = ncv;
+        while (cvb > 1 && ((int64_t)dy->w * cvb * V * 4 > 48 * 1024 || (int64_t)dx->n * dx->h * ((ncv + cvb - 1) / cvb) < 512)) cvb = (cvb + 1) / 2;
+        if ((int64_t)dy->w * cvb * V * 4 <= 48 * 1024) {
+            const int nsplit = (ncv + cvb - 1) / cvb;
+            const size_t lds = (size_t)dy->w * cvb * V * 4;
+            const dim3 grid((unsigned)(dx->n * dx->h * nsplit));
+            if (dx->dtype == DSN_F32)
+                hipLaunchKernelGGL((bilinear_bwd_rows_kernel<float, 4>), grid, dim3(256), lds, st, (const float*)dy->ptr, dy->ldc,
+                                   (float*)dx->ptr, dx->ldc, dx->h, dx->w, dy->h, dy->w, dx->c, cvb, sh, sw, accumulate);
+            else
+                hipLaunchKernelGGL((bilinear_bwd_rows_kernel<bf16_t, 8>), grid, dim3(256), lds, st, (const bf16_t*)dy->ptr, dy->ldc,
+                                   (bf16_t*)dx->ptr, dx->ldc, dx->h, dx->w, dy->h, dy->w, dx->c, cvb, sh, sw, accumulate);
+            DSN_LAUNCH_CHECK("bilinear_ac_bwd (separable rows)");
+            return DSN_OK;
+        }
     }
     if (!dy_nchw && vec16(dx) && vec16(dy)) {
         const int V = dx->dtype == DSN_F32 ? 4 : 8;
@@ -1393,6 +1671,20 @@ extern "C" int dsn_adaptive_avgpool_bwd_multi(const dsn_tensor* dys, int32_t n_s
             srcs.dy[i] = dys[i].ptr; srcs.ld[i] = dys[i].ldc; srcs.KH[i] = dys[i].h; srcs.KW[i] = dys[i].w;
         }
         const int V = dx->dtype == DSN_F32 ? 4 : 8;
+        bool rows = (int64_t)n_src * dx->w * 16 <= 48 * 1024 && dx->n * dx->h >= 64;
+        for (int i = 0; i < n_src; ++i) rows = rows && dys[i].h <= dx->h && dys[i].w <= dx->w;     // (bins: at most two per row / column)
+        if (rows) {
+            const size_t lds = (size_t)n_src * dx->w * 16;
+            const dim3 grid((unsigned)(dx->n * dx->h));
+            if (dx->dtype == DSN_F32)
+                hipLaunchKernelGGL((adaptive_avgpool_bwd_rows_kernel<float, 4>), grid, dim3(256), lds, st, srcs, (float*)dx->ptr,
+                                   dx->ldc, dx->h, dx->w, dx->c, accumulate);
+            else
+                hipLaunchKernelGGL((adaptive_avgpool_bwd_rows_kernel<bf16_t, 8>), grid, dim3(256), lds, st, srcs, (bf16_t*)dx->ptr,
+                                   dx->ldc, dx->h, dx->w, dx->c, accumulate);
+            DSN_LAUNCH_CHECK("adaptive_avgpool_bwd (rows)");
+            return DSN_OK;
+        }
         const int64_t total = npix(dx) * (dx->c / V);
         if (dx->dtype == DSN_F32)
             hipLaunchKernelGGL((adaptive_avgpool_bwd_multi_kernel<float, 4>), dim3(ew_grid(total)), dim3(256), 0, st, srcs,

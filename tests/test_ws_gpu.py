@@ -1,0 +1,177 @@
+"""conv_ws.hip -- the weights-stationary persistent convolution kernels -- against stock PyTorch-CPU fp32 convolutions of the
+same rounded inputs (fp32 1e-3 relative, bf16 2e-2: the bounds of tests/test_kernels_gpu.py), through the C ABI
+(dsn_conv2d_fwd / dsn_conv2d_dgrad / dsn_conv2d_fwd_bnacc pick the kernel; the library's labelled profiler confirms which one ran).
+Cases: several tiles per persistent block, ragged pixel and channel tiles, partial 128-byte slabs (32 / 40 / 96 channels),
+channel slices of wider buffers, bias + activation epilogues, BatchNorm partial sums."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_kernels_gpu import TOL, q, rnd, to_dev
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from desenet_amd import hip_ops
+    return hip_ops
+
+
+def _ran(ops, fn, family):
+    ops.profile_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        prof = ops.profile_collect()
+    finally:
+        ops.profile_enable(False)
+    assert any(k.startswith(family) for k in prof), (family, list(prof))
+    return out
+
+
+# n, ci, h, w, co
+CASES_1X1 = [
+    (8, 128, 80, 80, 64),      # config 3's C3 cv1: 800 pixel tiles over <= 512 blocks (several tiles per block, two slabs)
+    (2, 64, 47, 45, 64),       # ragged last pixel tile, one slab
+    (2, 32, 64, 64, 32),       # half a slab (32 bf16 channels), 128 x 32 tile
+    (2, 96, 40, 56, 40),       # one and a half slabs, ragged channel tile (40 of 64)
+    (1, 256, 48, 48, 200),     # four slabs (32 x 64 tiles), ragged last channel tile
+    (3, 40, 31, 33, 72),       # nothing aligned to a tile
+    (4, 128, 40, 40, 128),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES_1X1)
+@pytest.mark.parametrize("act", ["silu", "none"])
+def test_conv1x1_ws_forward(ops, case, dtype, act):
+    n, ci, h, w, co = case
+    if dtype == torch.float32 and ci > 128:
+        pytest.skip("more than four fp32 slabs: not a weights-stationary launch")
+    x, wt, b = rnd((n, ci, h, w), 11), rnd((co, ci, 1, 1), 12, -0.3, 0.3), rnd((co,), 13)
+    ref = F.conv2d(q(x, dtype), q(wt, dtype), b)
+    if act == "silu":
+        ref = F.silu(ref)
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, h, w, dtype, "cuda")
+    p = ops.conv_params(1, act=ops.ACT_SILU if act == "silu" else ops.ACT_NONE)
+    _ran(ops, lambda: ops.conv2d_fwd(xd, wp, b.cuda(), None, y, p), "conv1x1_ws_kernel")
+    assert_close(y.float().cpu(), ref, TOL[dtype], f"ws 1x1 fwd {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES_1X1)
+def test_conv1x1_ws_dgrad(ops, case, dtype):
+    n, ci, h, w, co = case
+    if dtype == torch.float32 and co > 128:
+        pytest.skip("more than four fp32 slabs: not a weights-stationary launch")
+    dy, wt = rnd((n, co, h, w), 21), rnd((co, ci, 1, 1), 22, -0.3, 0.3)
+    ref = F.conv_transpose2d(q(dy, dtype), q(wt, dtype))
+    dyd = to_dev(ops, dy, dtype)
+    wd = ops.pack_weight_dgrad(wt.cuda(), dtype)
+    dx = ops.new_act(n, ci, h, w, dtype, "cuda")
+    _ran(ops, lambda: ops.conv2d_dgrad(dyd, wd, dx, ops.conv_params(1)), "conv1x1_ws_kernel")
+    assert_close(dx.float().cpu(), ref, TOL[dtype], f"ws 1x1 dgrad {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1x1_ws_channel_slices(ops, dtype):
+    """Reads a channel slice of a wider buffer and writes a slice of a concat buffer (pixel strides larger than the channel counts);
+    nothing outside the destination slice is touched."""
+    n, h, w = 2, 40, 48
+    big = rnd((n, 192, h, w), 31)
+    wt = rnd((96, 64, 1, 1), 32, -0.3, 0.3)
+    xin = to_dev(ops, big, dtype)
+    ref = F.conv2d(q(big[:, 64:128], dtype), q(wt, dtype))
+    cat = ops.new_act(n, 160, h, w, dtype, "cuda", zero=True)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    _ran(ops, lambda: ops.conv2d_fwd(xin[:, 64:128], wp, None, None, cat[:, 32:128], ops.conv_params(1)), "conv1x1_ws_kernel")
+    assert_close(cat[:, 32:128].float().cpu(), ref, TOL[dtype], "slice write")
+    assert float(cat[:, :32].abs().max()) == 0 and float(cat[:, 128:].abs().max()) == 0, "wrote outside the slice"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(8, 128, 80, 80, 64), (2, 96, 40, 56, 40), (3, 64, 31, 33, 72)])
+def test_conv1x1_ws_batchnorm_sums(ops, case, dtype):
+    """Training forward: y = conv(x) and the per-channel fp64 sums of y's fp32 accumulators (dsn_conv2d_fwd_bnacc), folded by
+    dsn_bn_act_fwd_acc -- mean / rstd / output against F.batch_norm of the reference convolution."""
+    n, ci, h, w, co = case
+    x, wt = rnd((n, ci, h, w), 41), rnd((co, ci, 1, 1), 42, -0.3, 0.3)
+    g, b = rnd((co,), 43, 0.5, 1.5), rnd((co,), 44, -0.2, 0.2)
+    yref = F.conv2d(q(x, dtype), q(wt, dtype))
+    zref = F.silu(F.batch_norm(yref, None, None, g, b, True, 0.03, 1e-3))
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, h, w, dtype, "cuda")
+    z = ops.new_act(n, co, h, w, dtype, "cuda")
+    rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+    stats = _ran(ops, lambda: ops.conv2d_fwd_bnstats(xd, wp, y, ops.conv_params(1), g.cuda(), b.cuda(), rm, rv, 0.03, 1e-3,
+                                                     ops.ACT_SILU, None, z), "conv1x1_ws_kernel")
+    mean = yref.mean((0, 2, 3))
+    var = yref.var((0, 2, 3), unbiased=False)
+    assert_close(stats[2].cpu(), mean, 2e-3 if dtype == torch.float32 else 2e-2, "batch mean")
+    assert_close(stats[3].cpu(), 1.0 / torch.sqrt(var + 1e-3), 2e-3 if dtype == torch.float32 else 2e-2, "rstd")
+    assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
+    assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
+
+
+# n, ci, h, w, co, dil
+CASES_3X3 = [
+    (8, 64, 80, 80, 64, 1),      # config 3's Bottleneck 3x3 @80: 800 patches of 8 x 8 over 256 persistent blocks
+    (2, 64, 40, 48, 64, 2),      # RFB2 branch, dilation 2 (12 x 12 halo)
+    (2, 64, 40, 40, 64, 3),      # dilation 3 (14 x 14 halo)
+    (2, 64, 70, 67, 96, 1),      # ragged patches at both borders, ragged channel tile
+    (2, 32, 64, 64, 32, 1),      # half a slab, 8 x 16 patches x 32 channels
+    (4, 128, 40, 40, 128, 1),    # two slabs per patch (the halo of slab 1 is prefetched while slab 0 is multiplied)
+    (2, 96, 33, 47, 40, 1),      # one and a half slabs, ragged everything
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES_3X3)
+def test_conv3x3_ws_forward_and_dgrad(ops, case, dtype):
+    n, ci, h, w, co, d = case
+    if dtype == torch.float32 and (ci > 64 or (ci > 32 and d > 1)):
+        pytest.skip("more than two fp32 slabs (or two with dilation): not a weights-stationary launch")
+    x, wt, b = rnd((n, ci, h, w), 51), rnd((co, ci, 3, 3), 52, -0.2, 0.2), rnd((co,), 53)
+    ref = F.silu(F.conv2d(q(x, dtype), q(wt, dtype), b, 1, d, d))
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, h, w, dtype, "cuda")
+    _ran(ops, lambda: ops.conv2d_fwd(xd, wp, b.cuda(), None, y, ops.conv_params(3, 1, d, d, act=ops.ACT_SILU)), "conv3x3_ws_kernel")
+    assert_close(y.float().cpu(), ref, TOL[dtype], f"ws 3x3 fwd {case}")
+    if dtype == torch.float32 and (co > 64 or (co > 32 and d > 1)):
+        return
+    dy = rnd((n, co, h, w), 54)
+    dref = F.conv_transpose2d(q(dy, dtype), q(wt, dtype), None, 1, d, 0, 1, d)
+    dyd = to_dev(ops, dy, dtype)
+    wd = ops.pack_weight_dgrad(wt.cuda(), dtype)
+    dx = ops.new_act(n, ci, h, w, dtype, "cuda")
+    _ran(ops, lambda: ops.conv2d_dgrad(dyd, wd, dx, ops.conv_params(3, 1, d, d)), "conv3x3_ws_kernel")
+    assert_close(dx.float().cpu(), dref, TOL[dtype], f"ws 3x3 dgrad {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(8, 64, 80, 80, 64, 1), (2, 64, 70, 67, 96, 1), (4, 128, 40, 40, 128, 1)])
+def test_conv3x3_ws_batchnorm_sums(ops, case, dtype):
+    n, ci, h, w, co, d = case
+    if dtype == torch.float32 and ci > 64:
+        pytest.skip("more than two fp32 slabs")
+    x, wt = rnd((n, ci, h, w), 61), rnd((co, ci, 3, 3), 62, -0.2, 0.2)
+    g, b = rnd((co,), 63, 0.5, 1.5), rnd((co,), 64, -0.2, 0.2)
+    yref = F.conv2d(q(x, dtype), q(wt, dtype), None, 1, d, d)
+    zref = F.silu(F.batch_norm(yref, None, None, g, b, True, 0.03, 1e-3))
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, h, w, dtype, "cuda")
+    z = ops.new_act(n, co, h, w, dtype, "cuda")
+    rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+    stats = _ran(ops, lambda: ops.conv2d_fwd_bnstats(xd, wp, y, ops.conv_params(3, 1, d, d), g.cuda(), b.cuda(), rm, rv, 0.03, 1e-3,
+                                                     ops.ACT_SILU, None, z), "conv3x3_ws_kernel")
+    assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 2e-3 if dtype == torch.float32 else 2e-2, "batch mean")
+    assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
+    assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")

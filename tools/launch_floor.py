@@ -65,7 +65,35 @@ def main():
         for _ in range(n):
             ops.conv2d_fwd(a8, w8, None, None, b8, p11)
 
-    for name, body in (("library copy, 32 elements", lib_copy), ("library BN+SiLU apply, 32 elements", lib_bnact),
+    def lib_alt():                                    # the step's pattern: two DIFFERENT library kernels alternating, each reading the other's output
+        for _ in range(n // 2):
+            ops.conv2d_fwd(a8, w8, None, None, b8, p11)
+            ops.bn_act_fwd(b8, sc, sh, ops.ACT_SILU, None, a8)
+
+    # the same pattern at a real layer size (8 x 128 x 40 x 40, bf16: 3.3 MB per tensor): 1x1 conv -> BN + SiLU apply -> ...
+    A = ops.new_act(8, 128, 40, 40, torch.bfloat16, "cuda"); A.normal_()
+    B = ops.new_act(8, 128, 40, 40, torch.bfloat16, "cuda")
+    W = ops.pack_weight_fwd(torch.randn(128, 128, 1, 1, device="cuda") * 0.05, torch.bfloat16)
+    sc128 = torch.ones(128, device="cuda"); sh128 = torch.zeros(128, device="cuda")
+
+    def layer_alt():
+        for _ in range(n // 2):
+            ops.conv2d_fwd(A, W, None, None, B, p11)
+            ops.bn_act_fwd(B, sc128, sh128, ops.ACT_SILU, None, A)
+
+    def layer_conv_only():
+        for _ in range(n // 2):
+            ops.conv2d_fwd(A, W, None, None, B, p11)
+            ops.conv2d_fwd(B, W, None, None, A, p11)
+
+    def layer_bn_only():
+        for _ in range(n // 2):
+            ops.bn_act_fwd(A, sc128, sh128, ops.ACT_SILU, None, B)
+            ops.bn_act_fwd(B, sc128, sh128, ops.ACT_SILU, None, A)
+
+    for name, body in (("conv <-> BN apply alternating, 1 block", lib_alt), ("1x1 conv <-> BN apply @8x128x40x40", layer_alt),
+                       ("1x1 conv only @8x128x40x40", layer_conv_only), ("BN apply only @8x128x40x40", layer_bn_only),
+                       ("library copy, 32 elements", lib_copy), ("library BN+SiLU apply, 32 elements", lib_bnact),
                        ("library igemm conv, 1 block", lib_conv), ("tiny (64 floats)", tiny), ("medium (3.3 MB bf16 read+write)", medium),
                        ("six distinct tiny kernels", mixed), ("128 MB stream + tiny (per pair x8)", tiny_after_big),
                        ("128 MB stream alone (x8)", big_only)):
