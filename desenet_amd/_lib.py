@@ -173,6 +173,7 @@ PROTOTYPES = {
     "dsn_profile_kernel_count": (i32, []),
     "dsn_profile_kernel_name": (C.c_char_p, [i32]),
     "dsn_profile_dump": (i64, [vp, i64]),
+    "dsn_ws_mode": (i32, [i32, i32]),
 }
 
 _lib = None

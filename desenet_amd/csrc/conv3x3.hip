@@ -254,6 +254,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             // patches on >= 800-block bf16 launches (tests/test_kernels_gpu.py: the 8 x 70 x 67 case).
             if (EX > 0 && (t == 1 || t == 2)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + EX) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
+            // (the "memory" clobber already keeps every ds_read of the previous tap above the wait; sched_barrier pins the whole
+            //  issue order at this point -- cdna_hip_programming.md 5: place reads by the count, not by clean runs)
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (LZ && t == 0) {                  // the slab's patch has landed (and the table is complete): transform it once

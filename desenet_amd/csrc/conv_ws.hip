@@ -149,14 +149,120 @@ template <int NV, int CPV, bool ON> struct StatRegs {
     }
 };
 
+// ---- data-gradient extras: shortcut gradient, accumulation into dx, BatchNorm backward sums (include/desenet_hip.h: dsn_bnred) ----
+// A dgrad launch may add a residual tensor (a Bottleneck shortcut's gradient), add to what dx already holds (fan-in), and -- when it
+// writes the FINAL dz of one or two BatchNorm blocks -- form their backward sums from the value it stores and the producer's y.
+// These operands are per-lane 16-byte vectors at exactly the (pixel, channel vector) positions the lane stores; they are fetched by
+// hand-issued buffer loads ONE TILE AHEAD into a ping-pong register set (an ordinary load next to in-flight LDS-DMA makes hipcc
+// drain the whole vector-memory queue at its first use: cdna_hip_programming.md 5, trap (b)) and waited for with counted vmcnt.
+struct WsX {
+    const void* res;
+    int64_t rld;
+    uint32_t res_bytes;
+    int32_t accumulate;
+    int32_t nseg, _pad;
+    struct Seg {
+        int32_t c0, c1, ch0, acc_c, act, _pad;
+        const void* y;
+        int64_t yld;
+        uint32_t y_bytes, _pad2;
+        const float *scale, *shift, *mean, *rstd;
+        double* acc;
+    } seg[2];
+};
+
+__device__ __forceinline__ u32x4 make_rsrc4(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+// (descriptor words come from kernel arguments: wave-uniform; s_nop 4: SGPR written by a VALU/SALU just before a VMEM reads it)
+#define BUF_LOAD_B128(dst, off, rsrc) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(rsrc) : "memory")
+
+template <typename T, int MI, int NV, int CPV> struct WsXRegs { u32x4 res[MI][NV], old[MI][NV], y0[MI][NV], y1[MI][NV]; };
+
+template <typename T, int MI, int NV, int CPV> struct WsXState {
+    static constexpr int XL = 4 * MI * NV;               // buffer loads per wave and tile (always issued; absent operands: out of range)
+    u32x4 r_res, r_old, r_y0, r_y1;
+    int segv[NV];                                        // segment of the lane's vector v (-1: none)
+    int actv[NV];
+    float sc[NV][CPV], sh[NV][CPV], mu[NV][CPV], rs[NV][CPV], q0[NV][CPV], q1[NV][CPV];
+    __device__ __forceinline__ void init(const WsX& ex, const void* dst, uint32_t dst_bytes, const int (&cabs)[NV], int Cd) {
+        r_res = make_rsrc4(ex.res, ex.res ? ex.res_bytes : 0);
+        r_old = make_rsrc4(dst, ex.accumulate ? dst_bytes : 0);
+        r_y0 = make_rsrc4(ex.seg[0].y, ex.nseg > 0 ? ex.seg[0].y_bytes : 0);
+        r_y1 = make_rsrc4(ex.seg[1].y, ex.nseg > 1 ? ex.seg[1].y_bytes : 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            segv[v] = -1;
+            actv[v] = 0;
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) { sc[v][k] = sh[v][k] = mu[v][k] = rs[v][k] = 0.f; q0[v][k] = q1[v][k] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s < ex.nseg && cabs[v] >= ex.seg[s].c0 && cabs[v] < ex.seg[s].c1 && cabs[v] < Cd) {
+                    segv[v] = s;
+                    actv[v] = ex.seg[s].act;
+                    const int k0 = cabs[v] - ex.seg[s].c0;
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) {
+                        sc[v][k] = ex.seg[s].scale[k0 + k]; sh[v][k] = ex.seg[s].shift[k0 + k];
+                        mu[v][k] = ex.seg[s].mean[k0 + k]; rs[v][k] = ex.seg[s].rstd[k0 + k];
+                    }
+                }
+            }
+        }
+    }
+    // request the operands of one tile: pix[i] = destination pixel index of the lane's pixel in tile row i (or -1: not stored)
+    __device__ __forceinline__ void issue(WsXRegs<T, MI, NV, CPV>& x, const WsX& ex, const int64_t (&pix)[MI], const int (&cabs)[NV],
+                                          int64_t dld, int Cd) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const bool ok = pix[i] >= 0 && cabs[v] < Cd;
+                const uint32_t o_res = ok ? (uint32_t)(pix[i] * ex.rld + cabs[v]) * (uint32_t)sizeof(T) : OOB;
+                const uint32_t o_old = ok ? (uint32_t)(pix[i] * dld + cabs[v]) * (uint32_t)sizeof(T) : OOB;
+                const uint32_t o_y0 = (ok && segv[v] == 0) ? (uint32_t)(pix[i] * ex.seg[0].yld + (cabs[v] - ex.seg[0].c0)) * (uint32_t)sizeof(T) : OOB;
+                const uint32_t o_y1 = (ok && segv[v] == 1) ? (uint32_t)(pix[i] * ex.seg[1].yld + (cabs[v] - ex.seg[1].c0)) * (uint32_t)sizeof(T) : OOB;
+                BUF_LOAD_B128(x.res[i][v], o_res, r_res);
+                BUF_LOAD_B128(x.old[i][v], o_old, r_old);
+                BUF_LOAD_B128(x.y0[i][v], o_y0, r_y0);
+                BUF_LOAD_B128(x.y1[i][v], o_y1, r_y1);
+            }
+    }
+    // o: accumulator values of (tile row i, vector v) -> + residual + old; returns the packed stored value and adds the BN sums
+    __device__ __forceinline__ u32x4 apply(const WsXRegs<T, MI, NV, CPV>& x, int i, int v, float (&o)[CPV], bool ok) {
+        T rv[CPV], ov[CPV], yv[CPV];
+        *reinterpret_cast<u32x4*>(rv) = x.res[i][v];
+        *reinterpret_cast<u32x4*>(ov) = x.old[i][v];
+        *reinterpret_cast<u32x4*>(yv) = segv[v] == 1 ? x.y1[i][v] : x.y0[i][v];
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) o[k] += to_f32<T>(rv[k]) + to_f32<T>(ov[k]);       // (absent operands read as zeros)
+        const u32x4 packed = pack_out<T, CPV>(o);
+        if (segv[v] >= 0 && ok) {
+            T outv[CPV];
+            *reinterpret_cast<u32x4*>(outv) = packed;
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) {
+                const float y = to_f32<T>(yv[k]);
+                const float gk = to_f32<T>(outv[k]) * act_grad(y * sc[v][k] + sh[v][k], actv[v]);
+                q0[v][k] += gk;
+                q1[v][k] += gk * ((y - mu[v][k]) * rs[v][k]);
+            }
+        }
+        return packed;
+    }
+};
+
 // ================================================================================================================================
 // 1x1 / stride 1.  Block tile BM pixels x BN channels, K = NS slabs of 128 bytes (any channel count that is a multiple of the
 // 16-byte vector: lanes past the last channel fetch nothing and leave zeros).  LDS: [weights NS x BN rows][2 stages x NS x BM rows].
 // ================================================================================================================================
-template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS, int D>
+template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS, int D, bool EX>
 __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                          const float* __restrict__ bias, T* __restrict__ dst, const BnAcc fin,
-                                                         const WGeom g) {
+                                                         const WGeom g, const WsX ex) {
+    static_assert(!EX || (D == 3 && !STATS), "the extras variant (data gradient) runs a 3-stage ring without BatchNorm forward sums");
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are filled 32 rows per DMA pass");
@@ -223,6 +329,23 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
     }
     StatRegs<NV, CPV, STATS> stat;
     stat.zero();
+    typedef WsXState<T, MI, NV, CPV> XS;
+    typedef WsXRegs<T, MI, NV, CPV> XR;
+    XS xs;
+    XR xa, xb;
+    int cabs[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) cabs[v] = n0 + OV::ch(wn, v, fg);
+    if constexpr (EX) xs.init(ex, dst, g.dst_bytes, cabs, g.Cd);
+    auto issue_x = [&](int tm, XR& x) {
+        int64_t pix[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int64_t m = (int64_t)tm * BM + (wm * MI + i) * 16 + fr;
+            pix[i] = (tm < g.tiles_m && m < M) ? m : -1;
+        }
+        xs.issue(x, ex, pix, cabs, g.dld, g.Cd);
+    };
 
     // LDS byte offsets of the fragment reads (slab 0): pixel row / weight row of MFMA index fr, logical slot 4 h + fg swizzled by row
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
@@ -246,19 +369,25 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
     load_w();
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_a(grp + j * ngrp, j);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPT) : "memory");        // weights + the first tile
+    if constexpr (EX) {
+        issue_x(grp, xa);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPT + XS::XL) : "memory");    // weights + the first tile
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPT) : "memory");        // weights + the first tile
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int k = 0; k < CPV; ++k) asm volatile("" : "+v"(bv[v][k]));       // (bias loads retired with the wait above)
 
-    int stage = 0, it = 0;
-    for (int tm = grp; tm < g.tiles_m; tm += ngrp, ++it) {
+    int stage = 0;
+    auto tile_step = [&](int tm, int it, XR& cur, XR& nxt) {
         // every wave has waited for its own DMA of this tile and finished reading the stage the next DMA overwrites
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (EX) issue_x(tm + ngrp, nxt);                 // issue order per tile: extras(t + 1), DMA(t + D - 1), stores(t)
         load_a(tm + (D - 1) * ngrp, stage == 0 ? D - 1 : stage - 1);
 
         f32x4 acc[MI][NI];
@@ -303,6 +432,13 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                 for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], fw[k % (PF + 1)][j], fx[k % (PF + 1)][i]);
         }
         // ---- epilogue straight from the accumulators: lane (fg, fr) owns pixel fr of each 16-pixel tile, channels fg * CPV ..
+        if constexpr (EX) {
+            // extras(t) were requested one tile ago: younger in the queue are DMA(t + 1), stores(t - 1), extras(t + 1), DMA(t + 2)
+            // (first tile: requested in the prologue, behind it only extras(t + 1) and DMA(t + 2))
+            if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL + LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT + ST + XS::XL) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int64_t m = (int64_t)tm * BM + (wm * MI + i) * 16 + fr;
@@ -312,23 +448,84 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                 float o[CPV];
                 OV::get(acc[i], v, o);
                 const bool ok = m < M && c < g.Cd;
-                stat.add(v, o, ok);
-#pragma unroll
-                for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
-                if (g.act == DSN_ACT_SILU) {               // (one uniform branch per vector, not per element)
-#pragma unroll
-                    for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
-                } else if (g.act == DSN_ACT_SIGMOID) {
-#pragma unroll
-                    for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
-                }
                 const uint32_t off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
+                if constexpr (EX) {
+                    __builtin_amdgcn_raw_buffer_store_b128(xs.apply(cur, i, v, o, ok), drsrc, off, 0, 0);
+                } else {
+                    stat.add(v, o, ok);
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
+                    if (g.act == DSN_ACT_SILU) {               // (one uniform branch per vector, not per element)
+#pragma unroll
+                        for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
+                    } else if (g.act == DSN_ACT_SIGMOID) {
+#pragma unroll
+                        for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
+                }
             }
         }
-        // the next tile's DMA is older than (D - 2) younger tiles and the store groups issued since: min(it + 1, D - 1) of them
-        wait_vm<(D - 2) * LPT, ST>(it + 1 < D - 1 ? it + 1 : D - 1);
+        if constexpr (EX) {
+            // DMA(t + 1) is older than stores(t - 1), extras(t + 1), DMA(t + 2), stores(t)  (first tile: extras(t), extras(t + 1),
+            // DMA(t + 2), stores(t))
+            if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XS::XL + LPT + ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + XS::XL + LPT) : "memory");
+        } else {
+            // the next tile's DMA is older than (D - 2) younger tiles and the store groups issued since: min(it + 1, D - 1) of them
+            wait_vm<(D - 2) * LPT, ST>(it + 1 < D - 1 ? it + 1 : D - 1);
+        }
         stage = stage + 1 == D ? 0 : stage + 1;
+    };
+    {
+        int tm = grp, it = 0;
+        while (tm < g.tiles_m) {                 // (two tiles per trip: the extras registers ping-pong with static indices)
+            tile_step(tm, it, xa, xb);
+            tm += ngrp; ++it;
+            if (tm >= g.tiles_m) break;
+            tile_step(tm, it, xb, xa);
+            tm += ngrp; ++it;
+        }
+    }
+
+    if constexpr (EX) {
+        // BatchNorm backward sums: fold the 16 pixel lanes of a channel group, then the WGM waves of a column, then one atomic pair
+        if (ex.nseg > 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        xs.q0[v][k] += __shfl_xor(xs.q0[v][k], o);
+                        xs.q1[v][k] += __shfl_xor(xs.q1[v][k], o);
+                    }
+                }
+            __syncthreads();
+            if (fr == 0) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) {
+                        const int cl = OV::ch(wn, v, fg) + k;
+                        sRed[(wm * BN + cl) * 2] = xs.q0[v][k];
+                        sRed[(wm * BN + cl) * 2 + 1] = xs.q1[v][k];
+                    }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < g.Cd) {
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) {
+                    t0 += sRed[(w * BN + tid) * 2];
+                    t1 += sRed[(w * BN + tid) * 2 + 1];
+                }
+                const int ch = n0 + tid;
+                for (int sg = 0; sg < ex.nseg; ++sg)
+                    if (ch >= ex.seg[sg].c0 && ch < ex.seg[sg].c1)
+                        bn_acc_add(BnAcc{ex.seg[sg].acc, ex.seg[sg].acc_c, 0.0}, blockIdx.x, ex.seg[sg].ch0 + ch - ex.seg[sg].c0, t0, t1);
+            }
+        }
     }
 
     if constexpr (STATS) {
@@ -385,60 +582,62 @@ static WsPlan ws_plan(int tiles_m, int tiles_n, size_t lds, int max_bpc) {
     return WsPlan{groups * tiles_n, lds};
 }
 
-template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS>
+// MODE: 0 = forward epilogue (bias, activation), 1 = forward + BatchNorm sums, 2 = data gradient with extras (WsX)
+template <typename T, int MI, int NI, int WGM, int WGN, int NS, int MODE>
 int launch_1x1_ws(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, WGeom g, const BnAcc& fin,
-                  int is_dgrad, hipStream_t st) {
+                  int is_dgrad, hipStream_t st, const WsX& ex) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
-    // pixel-tile stages: as deep as keeps two blocks per CU (weights + ring <= ~78 KB), 2 .. 4
+    constexpr bool STATS = MODE == 1, EX = MODE == 2;
+    // pixel-tile stages: as deep as keeps two blocks per CU (weights + ring <= ~78 KB), 2 .. 4; the extras variant runs 3
     constexpr int TILEB = NS * BM * ROWB, WB1 = NS * BN * ROWB;
     constexpr int DFIT = (78 * 1024 - WB1) / TILEB;
-    constexpr int D = DFIT >= 4 ? 4 : (DFIT >= 3 ? 3 : 2);
+    constexpr int D = EX ? 3 : (DFIT >= 4 ? 4 : (DFIT >= 3 ? 3 : 2));
     const int64_t M = (int64_t)g.N * g.H * g.W;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (g.Cd + BN - 1) / BN;
-    const size_t lds = (size_t)NS * (BN + D * BM) * ROWB + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
+    const size_t lds = (size_t)NS * (BN + D * BM) * ROWB + ((STATS || EX) ? (size_t)WGM * BN * 2 * 4 : 0);
     static const int max_bpc = [] { const char* e = getenv("DSN_WS_BPC"); return e ? atoi(e) : 4; }();
     const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, max_bpc);
-    auto kern = conv1x1_ws_kernel<T, MI, NI, WGM, WGN, NS, STATS, D>;
+    auto kern = conv1x1_ws_kernel<T, MI, NI, WGM, WGN, NS, STATS, D, EX>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const double elems = (double)M * (g.Cs + (double)g.Cd) + (double)g.Cs * g.Cd;
+    double xch = (ex.res ? 1.0 : 0.0) + (ex.accumulate ? 1.0 : 0.0);
+    for (int i = 0; i < ex.nseg; ++i) xch += (double)(ex.seg[i].c1 - ex.seg[i].c0) / g.Cd;
+    const double elems = (double)M * (g.Cs + (double)g.Cd * (1.0 + xch)) + (double)g.Cs * g.Cd;
     const ProfConv pc("conv1x1_ws_kernel", sizeof(T) == 2, BM, BN, is_dgrad != 0, 1, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
     ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g, ex);
     DSN_LAUNCH_CHECK("conv1x1 (weights-stationary)");
     return DSN_OK;
 }
 
-template <typename T, int MI, int NI, int WGM, int WGN, bool STATS>
+template <typename T, int MI, int NI, int WGM, int WGN, int MODE>
 int launch_1x1_ws_ns(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
-                     int is_dgrad, hipStream_t st, int ns) {
+                     int is_dgrad, hipStream_t st, int ns, const WsX& ex) {
     switch (ns) {
-        case 1: return launch_1x1_ws<T, MI, NI, WGM, WGN, 1, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
-        case 2: return launch_1x1_ws<T, MI, NI, WGM, WGN, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
-        case 3: return launch_1x1_ws<T, MI, NI, WGM, WGN, 3, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
-        case 4: return launch_1x1_ws<T, MI, NI, WGM, WGN, 4, STATS>(s, w, bias, d, g, fin, is_dgrad, st);
+        case 1: return launch_1x1_ws<T, MI, NI, WGM, WGN, 1, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+        case 2: return launch_1x1_ws<T, MI, NI, WGM, WGN, 2, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+        case 3: return launch_1x1_ws<T, MI, NI, WGM, WGN, 3, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+        case 4: return launch_1x1_ws<T, MI, NI, WGM, WGN, 4, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
         default: return 1;
     }
 }
 
-template <typename T, bool STATS>
+template <typename T, int MODE>
 int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
-                      int is_dgrad, hipStream_t st, int ns) {
+                      int is_dgrad, hipStream_t st, int ns, const WsX& ex) {
     static const int force = [] { const char* e = getenv("DSN_WS_CFG"); return e ? atoi(e) : -1; }();     // tuning knob
     int cfg = force;
-    if (cfg < 0) cfg = g.Cd <= 32 ? 2 : (ns >= 3 ? 1 : 0);
+    if (cfg < 0 || cfg > 2) cfg = g.Cd <= 32 ? 2 : (ns >= 3 ? 1 : 0);
     switch (cfg) {
-        case 1: return launch_1x1_ws_ns<T, 1, 2, 2, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);     // 32 x 64
-        case 2: return launch_1x1_ws_ns<T, 2, 2, 4, 1, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);     // 128 x 32
-        case 3: return launch_1x1_ws_ns<T, 4, 2, 2, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);     // 128 x 64
-        default: return launch_1x1_ws_ns<T, 2, 2, 2, 2, STATS>(s, w, bias, d, g, fin, is_dgrad, st, ns);    // 64 x 64
+        case 1: return launch_1x1_ws_ns<T, 1, 2, 2, 2, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);     // 32 x 64
+        case 2: return launch_1x1_ws_ns<T, 2, 2, 4, 1, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);     // 128 x 32
+        default: return launch_1x1_ws_ns<T, 2, 2, 2, 2, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);    // 64 x 64
     }
 }
-
 
 // ================================================================================================================================
 // 3x3 / stride 1 / dilation d (padding d).  A block owns BN output channels -- ALL nine taps of their weights stay in LDS
@@ -449,10 +648,11 @@ int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, con
 // ================================================================================================================================
 __device__ __forceinline__ int hslot(int slot, int hx) { return (((slot >> 1) ^ ((hx >> 1) & 3)) << 1) | (slot & 1); }
 
-template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, int NS, bool STATS, int D, bool HP>
+template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, int NS, bool STATS, int D, bool HP, bool EX>
 __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                          const float* __restrict__ bias, T* __restrict__ dst, const BnAcc fin,
-                                                         const WGeom g) {
+                                                         const WGeom g, const WsX ex) {
+    static_assert(!EX || (D == 3 && NS == 1 && !STATS), "extras variant (data gradient): one slab, 3-stage ring");
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static_assert(BM == TH * TW, "the pixel tile is the TH x TW patch");
@@ -529,6 +729,26 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
     }
     StatRegs<NV, CPV, STATS> stat;
     stat.zero();
+    typedef WsXState<T, MI, NV, CPV> XS;
+    typedef WsXRegs<T, MI, NV, CPV> XR;
+    XS xs;
+    XR xa, xb;
+    int cabs[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) cabs[v] = n0 + OV::ch(wn, v, fg);
+    if constexpr (EX) xs.init(ex, dst, g.dst_bytes, cabs, g.Cd);
+    auto issue_x = [&](int tile, XR& x) {
+        int64_t pix[MI];
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = (wm * MI + i) * 16 + fr;
+            const int y = y0 + r / TW, xx = x0 + r % TW;
+            pix[i] = (tile < t_end && y < g.H && xx < g.W) ? ((int64_t)n * g.H + y) * g.W + xx : -1;
+        }
+        xs.issue(x, ex, pix, cabs, g.dld, g.Cd);
+    };
 
     // fragment addressing: MFMA column fr of pixel tile i is patch pixel r = (wm MI + i) 16 + fr = (r / TW, r % TW)
     int hp0[MI], hx0[MI];
@@ -561,14 +781,19 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
     load_w();
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_halo(j, j);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");         // weights + the first chunk
+    if constexpr (EX) {
+        issue_x(t_begin, xa);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH + XS::XL) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");         // weights + the first chunk
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int k = 0; k < CPV; ++k) asm volatile("" : "+v"(bv[v][k]));
 
     int stage = 0, c = 0;                    // c: chunk counter of this block
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    auto patch_step = [&](int tile, XR& cur, XR& nxt) {
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -580,6 +805,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (EX) issue_x(tile + 1, nxt);                   // issue order per patch: extras(t + 1), halo(t + D - 1), stores(t)
             load_halo(c + D - 1, stage == 0 ? D - 1 : stage - 1);      // into the stage chunk c - 1 has just released
             if constexpr (HP) {
             // 18 k-steps (tap, 64-byte half); the fragments of step k + PF are requested before the MFMAs of step k
@@ -665,6 +891,11 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
         // ---- epilogue: lane (fg, fr) owns patch pixel (r / TW, r % TW) of each 16-pixel tile, channels fg * CPV ..
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        if constexpr (EX) {     // (counts as in conv1x1_ws_kernel; c == patches done by this block)
+            if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL + IH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IH + ST + XS::XL) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int r = (wm * MI + i) * 16 + fr;
@@ -672,30 +903,86 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             const int64_t m = ((int64_t)n * g.H + y) * g.W + x;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const int c = n0 + OV::ch(wn, v, fg);
+                const int cc = n0 + OV::ch(wn, v, fg);
                 float o[CPV];
                 OV::get(acc[i], v, o);
-                const bool ok = y < g.H && x < g.W && c < g.Cd;
-                stat.add(v, o, ok);
+                const bool ok = y < g.H && x < g.W && cc < g.Cd;
+                const uint32_t off = ok ? (uint32_t)(m * g.dld + cc) * (uint32_t)sizeof(T) : OOB;
+                if constexpr (EX) {
+                    __builtin_amdgcn_raw_buffer_store_b128(xs.apply(cur, i, v, o, ok), drsrc, off, 0, 0);
+                } else {
+                    stat.add(v, o, ok);
 #pragma unroll
-                for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
-                if (g.act == DSN_ACT_SILU) {
+                    for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
+                    if (g.act == DSN_ACT_SILU) {
 #pragma unroll
-                    for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
-                } else if (g.act == DSN_ACT_SIGMOID) {
+                        for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
+                    } else if (g.act == DSN_ACT_SIGMOID) {
 #pragma unroll
-                    for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                        for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
                 }
-                const uint32_t off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
             }
         }
-        {   // as above, after this patch's ST stores (chunk c is a last-slab chunk)
+        if constexpr (EX) {
+            if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XS::XL + IH + ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + XS::XL + IH) : "memory");
+            ++c;
+        } else {   // as above, after this patch's ST stores (chunk c is a last-slab chunk)
             int nst = 0;
 #pragma unroll
             for (int b = 0; b <= D - 2; ++b) nst += (c - b >= 0 && (c - b) % NS == NS - 1) ? 1 : 0;
             wait_vm<(D - 2) * IH, ST>(nst);
             ++c;
+        }
+    };
+    {
+        int tile = t_begin;
+        while (tile < t_end) {
+            patch_step(tile, xa, xb);
+            if (++tile >= t_end) break;
+            patch_step(tile, xb, xa);
+            ++tile;
+        }
+    }
+
+    if constexpr (EX) {
+        if (ex.nseg > 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        xs.q0[v][k] += __shfl_xor(xs.q0[v][k], o);
+                        xs.q1[v][k] += __shfl_xor(xs.q1[v][k], o);
+                    }
+                }
+            __syncthreads();
+            if (fr == 0) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) {
+                        const int cl = OV::ch(wn, v, fg) + k;
+                        sRed[(wm * BN + cl) * 2] = xs.q0[v][k];
+                        sRed[(wm * BN + cl) * 2 + 1] = xs.q1[v][k];
+                    }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < g.Cd) {
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) {
+                    t0 += sRed[(w * BN + tid) * 2];
+                    t1 += sRed[(w * BN + tid) * 2 + 1];
+                }
+                const int ch = n0 + tid;
+                for (int sg = 0; sg < ex.nseg; ++sg)
+                    if (ch >= ex.seg[sg].c0 && ch < ex.seg[sg].c1)
+                        bn_acc_add(BnAcc{ex.seg[sg].acc, ex.seg[sg].acc_c, 0.0}, blockIdx.x, ex.seg[sg].ch0 + ch - ex.seg[sg].c0, t0, t1);
+            }
         }
     }
 
@@ -734,55 +1021,62 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
     }
 }
 
-template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, int NS, bool STATS>
+template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, int NS, int MODE>
 int launch_3x3_ws(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, WGeom g, const BnAcc& fin,
-                  hipStream_t st) {
+                  hipStream_t st, const WsX& ex) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
-    // halo stages: as many (<= 4) as fit next to the weights in 150 KB
-    constexpr int WB = 9 * NS * BN * ROWB, HS = IH * 32 * ROWB;
-    constexpr int RED = STATS ? WGM * BN * 2 * 4 : 0, CAP = 160 * 1024;
-    constexpr int D = (WB + 4 * HS + RED <= CAP) ? 4 : (WB + 3 * HS + RED <= CAP) ? 3 : 2;
-    g.tiles_y = (g.H + TH - 1) / TH;
-    g.tiles_x = (g.W + TW - 1) / TW;
-    g.tiles_m = g.N * g.tiles_y * g.tiles_x;
-    g.tiles_n = (g.Cd + BN - 1) / BN;
-    g.HW = TW + 2 * g.d;
-    g.NP = (TH + 2 * g.d) * g.HW;
-    if (g.NP > IH * 32) return 1;
-    const size_t lds = (size_t)WB + (size_t)D * HS + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
-    if (lds > 160 * 1024) return 1;
-    const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 2);
-    constexpr bool HP = TW == 8;          // hand-issued fragment reads: measured +10 % on 8 x 8 patches, -30 % on 8 x 16 ones
-    auto kern = conv3x3_ws_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, NS, STATS, D, HP>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+    constexpr bool STATS = MODE == 1, EX = MODE == 2;
+    if constexpr (EX && NS != 1) {
+        return 1;
+    } else {
+        // halo stages: as many (<= 4) as fit next to the weights in 160 KB; the extras variant runs 3
+        constexpr int WB = 9 * NS * BN * ROWB, HS = IH * 32 * ROWB;
+        constexpr int RED = (STATS || EX) ? WGM * BN * 2 * 4 : 0, CAP = 160 * 1024;
+        constexpr int D = EX ? 3 : ((WB + 4 * HS + RED <= CAP) ? 4 : (WB + 3 * HS + RED <= CAP) ? 3 : 2);
+        g.tiles_y = (g.H + TH - 1) / TH;
+        g.tiles_x = (g.W + TW - 1) / TW;
+        g.tiles_m = g.N * g.tiles_y * g.tiles_x;
+        g.tiles_n = (g.Cd + BN - 1) / BN;
+        g.HW = TW + 2 * g.d;
+        g.NP = (TH + 2 * g.d) * g.HW;
+        if (g.NP > IH * 32) return 1;
+        const size_t lds = (size_t)WB + (size_t)D * HS + RED;
+        if (lds > 160 * 1024) return 1;
+        const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 2);
+        constexpr bool HP = TW == 8;          // hand-issued fragment reads: measured +10 % on 8 x 8 patches, -30 % on 8 x 16 ones
+        auto kern = conv3x3_ws_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, NS, STATS, D, HP, EX>;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        double xch = (ex.res ? 1.0 : 0.0) + (ex.accumulate ? 1.0 : 0.0);
+        for (int i = 0; i < ex.nseg; ++i) xch += (double)(ex.seg[i].c1 - ex.seg[i].c0) / g.Cd;
+        const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1.0 + xch)) + 9.0 * g.Cs * g.Cd;
+        const ProfConv pc("conv3x3_ws_kernel", sizeof(T) == 2, BM, BN, g.flip != 0, 3, 1, g.d, g.Cs, g.Cd, g.N, g.H, g.W);
+        ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * sizeof(T), st);
+        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g, ex);
+        DSN_LAUNCH_CHECK("conv3x3 (weights-stationary)");
+        return DSN_OK;
     }
-    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd) + 9.0 * g.Cs * g.Cd;
-    const ProfConv pc("conv3x3_ws_kernel", sizeof(T) == 2, BM, BN, g.flip != 0, 3, 1, g.d, g.Cs, g.Cd, g.N, g.H, g.W);
-    ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * sizeof(T), st);
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g);
-    DSN_LAUNCH_CHECK("conv3x3 (weights-stationary)");
-    return DSN_OK;
 }
 
 // shape dispatch: dilation picks the halo size (IH), channels the (slabs, BN) pair whose weights fit LDS
-template <typename T, bool STATS>
+template <typename T, int MODE>
 int launch_3x3_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
-                      hipStream_t st, int ns) {
+                      hipStream_t st, int ns, const WsX& ex) {
     // 8 x 8 patches: (8 + 2d)^2 halo pixels = 100 / 144 / 196 -> IH 4 / 5 / 7
     if (ns == 1 && g.Cd > 32) {        // 64 output channels per block, one slab: 72 KB of weights
-        if (g.d == 1) return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 4, 1, STATS>(s, w, bias, d, g, fin, st);
-        if (g.d == 2) return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 5, 1, STATS>(s, w, bias, d, g, fin, st);
-        return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 7, 1, STATS>(s, w, bias, d, g, fin, st);
+        if (g.d == 1) return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 4, 1, MODE>(s, w, bias, d, g, fin, st, ex);
+        if (g.d == 2) return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 5, 1, MODE>(s, w, bias, d, g, fin, st, ex);
+        return launch_3x3_ws<T, 8, 8, 2, 2, 2, 2, 7, 1, MODE>(s, w, bias, d, g, fin, st, ex);
     }
     if (ns == 1) {                     // <= 32 output channels: 8 x 16 patches x 32 channels (36 KB of weights)
-        if (g.d == 1) return launch_3x3_ws<T, 8, 16, 2, 2, 4, 1, 6, 1, STATS>(s, w, bias, d, g, fin, st);
+        if (g.d == 1) return launch_3x3_ws<T, 8, 16, 2, 2, 4, 1, 6, 1, MODE>(s, w, bias, d, g, fin, st, ex);
         return 1;
     }
     if (ns == 2) {                     // two slabs: 32 output channels per block
-        if (g.d == 1) return launch_3x3_ws<T, 8, 16, 2, 2, 4, 1, 6, 2, STATS>(s, w, bias, d, g, fin, st);
+        if (g.d == 1) return launch_3x3_ws<T, 8, 16, 2, 2, 4, 1, 6, 2, MODE>(s, w, bias, d, g, fin, st, ex);
         return 1;
     }
     return 1;
@@ -790,14 +1084,51 @@ int launch_3x3_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, con
 
 }  // namespace
 
+// selection mode of the two kernels (environment DSN_WS / DSN_WS3 at load time; dsn_ws_mode() at run time: tests, A/B runs)
+static int g_ws_mode[2] = {getenv("DSN_WS") ? atoi(getenv("DSN_WS")) : 1, getenv("DSN_WS3") ? atoi(getenv("DSN_WS3")) : 1};
+extern "C" int dsn_ws_mode(int32_t mode_1x1, int32_t mode_3x3) {
+    if (mode_1x1 >= 0) g_ws_mode[0] = mode_1x1;
+    if (mode_3x3 >= 0) g_ws_mode[1] = mode_3x3;
+    return g_ws_mode[0] * 16 + g_ws_mode[1];
+}
+
+// extras of a data-gradient launch -> WsX (false: an operand the register-prefetch path does not take)
+static bool ws_extras(WsX& ex, const dsn_tensor* r, const dsn_tensor* d, const dsn_conv_params* p, const dsn_bnred* br, int es) {
+    ex = WsX{};
+    const int vec = 16 / es;
+    if (r) {
+        if (r->ldc % vec != 0 || (uintptr_t)r->ptr % 16 != 0 || r->dtype != d->dtype) return false;
+        const int64_t rb = ((npix(r) - 1) * r->ldc + r->c) * es;
+        if (rb >= (1ll << 32) - 64) return false;
+        ex.res = r->ptr; ex.rld = r->ldc; ex.res_bytes = (uint32_t)rb;
+    }
+    ex.accumulate = p->accumulate ? 1 : 0;
+    if (br && br->nseg > 0) {
+        if (br->nseg > 2) return false;
+        ex.nseg = br->nseg;
+        for (int i = 0; i < br->nseg; ++i) {
+            const dsn_bnred_seg& b = br->seg[i];
+            if (b.c0 % vec || b.c1 % vec || b.yld % vec || (uintptr_t)b.y % 16) return false;
+            const int64_t yb = ((npix(d) - 1) * b.yld + (b.c1 - b.c0)) * es;
+            if (yb >= (1ll << 32) - 64) return false;
+            WsX::Seg& sg = ex.seg[i];
+            sg.c0 = b.c0; sg.c1 = b.c1; sg.ch0 = b.ch0; sg.acc_c = b.acc_c; sg.act = b.act;
+            sg.y = b.y; sg.yld = b.yld; sg.y_bytes = (uint32_t)yb;
+            sg.scale = b.scale; sg.shift = b.shift; sg.mean = b.mean; sg.rstd = b.rstd; sg.acc = (double*)b.acc;
+        }
+    }
+    return true;
+}
+
 // Tried by the convolution entry points of igemm.hip BEFORE the one-trip kernels of conv3x3.hip.  Returns 1 when the launch is not
 // one this kernel takes (nothing launched), 0 when it ran, < 0 / hipError on failure.
 int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br) {
-    static const int mode = [] { const char* e = getenv("DSN_WS"); return e ? atoi(e) : 1; }();       // 0: never
+    const int mode = g_ws_mode[0];             // 0: never, 1: default, 2: no extras variants, 3: extras on every eligible launch
     if (!mode) return 1;
     if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0) return 1;
-    if (r || p->accumulate || (br && br->nseg > 0)) return 1;
+    const bool extras = r || p->accumulate || (br && br->nseg > 0);
+    if (extras && (mode == 2 || bias || p->act != DSN_ACT_NONE || (finp && finp->acc))) return 1;
     if (s->h != d->h || s->w != d->w || s->n != d->n || s->dtype != d->dtype) return 1;
     const int es = s->dtype == DSN_F32 ? 4 : 2, vec = 16 / es, kc = ROWB / es;
     const int ns = (s->c + kc - 1) / kc;
@@ -816,22 +1147,31 @@ int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
     BnAcc fin{};
     if (finp) fin = *finp;
     hipStream_t st = (hipStream_t)stream;
+    WsX ex{};
+    if (extras) {
+        // bf16 only: the fp32 form (twice the accumulator and operand registers) does not fit the 256-VGPR budget next to the two
+        // register sets of prefetched operands.  And only the long-K launches (>= 3 slabs: 32 x 64 tiles): measured inside the
+        // training step (profiles/r03f_*), the extras variant beats the one-trip kernel there (16.6 vs 19.1, 10.0 vs 11.7 us) and
+        // loses on the one- and two-slab layers (17.3 vs 12.7 us) -- DSN_WS=3 takes every eligible launch (tests do).
+        if (s->dtype == DSN_F32 || (ns < 3 && mode != 3) || !ws_extras(ex, r, d, p, br, es)) return 1;
+        return launch_1x1_ws_cfg<bf16_t, 2>(s, w, nullptr, d, g, fin, is_dgrad, st, ns, ex);
+    }
     if (fin.acc) {
         if (bias || p->act != DSN_ACT_NONE) return 1;
-        if (s->dtype == DSN_F32) return launch_1x1_ws_cfg<float, true>(s, w, bias, d, g, fin, is_dgrad, st, ns);
-        return launch_1x1_ws_cfg<bf16_t, true>(s, w, bias, d, g, fin, is_dgrad, st, ns);
+        if (s->dtype == DSN_F32) return launch_1x1_ws_cfg<float, 1>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);
+        return launch_1x1_ws_cfg<bf16_t, 1>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);
     }
-    if (s->dtype == DSN_F32) return launch_1x1_ws_cfg<float, false>(s, w, bias, d, g, fin, is_dgrad, st, ns);
-    return launch_1x1_ws_cfg<bf16_t, false>(s, w, bias, d, g, fin, is_dgrad, st, ns);
+    if (s->dtype == DSN_F32) return launch_1x1_ws_cfg<float, 0>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);
+    return launch_1x1_ws_cfg<bf16_t, 0>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);
 }
-
 
 int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br) {
-    static const int mode = [] { const char* e = getenv("DSN_WS3"); return e ? atoi(e) : 1; }();       // 0: never
+    const int mode = g_ws_mode[1];             // as in dsn_conv1x1_ws_try
     if (!mode) return 1;
     if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->dil < 1 || p->dil > 3) return 1;
-    if (r || p->accumulate || (br && br->nseg > 0)) return 1;
+    const bool extras = r || p->accumulate || (br && br->nseg > 0);
+    if (extras && (mode == 2 || bias || p->act != DSN_ACT_NONE || (finp && finp->acc))) return 1;
     if (s->h != d->h || s->w != d->w || s->n != d->n || s->dtype != d->dtype) return 1;
     const int es = s->dtype == DSN_F32 ? 4 : 2, vec = 16 / es, kc = ROWB / es;
     const int ns = (s->c + kc - 1) / kc;
@@ -850,11 +1190,18 @@ int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
     BnAcc fin{};
     if (finp) fin = *finp;
     hipStream_t st = (hipStream_t)stream;
+    WsX ex{};
+    if (extras) {
+        // (bf16, one slab: see conv1x1.)  Measured in the step: 34.4 vs 40.9 us on the 32 -> 32 @160 layer (implicit GEMM before),
+        // but 21 vs 16 us against the halo-tile ring kernel on the 64-channel layers -- those stay there unless DSN_WS3=3
+        if (s->dtype == DSN_F32 || ns != 1 || (d->c > 32 && mode != 3) || !ws_extras(ex, r, d, p, br, es)) return 1;
+        return launch_3x3_ws_cfg<bf16_t, 2>(s, w, nullptr, d, g, fin, st, ns, ex);
+    }
     if (fin.acc) {
         if (bias || p->act != DSN_ACT_NONE) return 1;
-        if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, true>(s, w, bias, d, g, fin, st, ns);
-        return launch_3x3_ws_cfg<bf16_t, true>(s, w, bias, d, g, fin, st, ns);
+        if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, 1>(s, w, bias, d, g, fin, st, ns, ex);
+        return launch_3x3_ws_cfg<bf16_t, 1>(s, w, bias, d, g, fin, st, ns, ex);
     }
-    if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, false>(s, w, bias, d, g, fin, st, ns);
-    return launch_3x3_ws_cfg<bf16_t, false>(s, w, bias, d, g, fin, st, ns);
+    if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, 0>(s, w, bias, d, g, fin, st, ns, ex);
+    return launch_3x3_ws_cfg<bf16_t, 0>(s, w, bias, d, g, fin, st, ns, ex);
 }

@@ -300,13 +300,17 @@ __device__ __forceinline__ bool iou_gt(const Box& a, const Box& b, float thr) {
     return ovr > thr;
 }
 
-__global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict__ pred, int n, int nc,
+// NW waves per image: wave 0 owns the 64 candidates of a chunk (and the serial sweep inside it), ALL waves hold copies of them
+// and split the list of boxes kept so far NW ways -- the long part once a few hundred boxes are kept (max_det 1000 at detect.py's
+// settings: 250 IoU evaluations per chunk and wave with 4 waves, 63 with 16).  Same comparisons, same order of decisions.
+constexpr int GREEDY_WAVES = 16;
+__global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const float* __restrict__ pred, int n, int nc,
                                                          const uint64_t* __restrict__ keys, int64_t cap,
                                                          const int32_t* __restrict__ counts, float iou_thres,
                                                          int agnostic, int max_det, float* __restrict__ out,
                                                          int32_t* __restrict__ out_count, const int32_t* __restrict__ starts) {
     extern __shared__ float kept[];   // [max_det][5]
-    __shared__ unsigned long long dead_s[4];
+    __shared__ unsigned long long dead_s[GREEDY_WAVES];
     __shared__ int nkept_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
     const int no = 5 + nc;
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
             me.x1 = raw[0] + off; me.y1 = raw[1] + off; me.x2 = raw[2] + off; me.y2 = raw[3] + off;
             me.area = (me.x2 - me.x1) * (me.y2 - me.y1);
         }
-        // (a) against boxes kept so far: the 4 waves split the kept list
+        // (a) against boxes kept so far: the waves split the kept list
         bool dead = !valid;
-        for (int q = part; q < nkept && !dead; q += 4) {
+        for (int q = part; q < nkept && !dead; q += GREEDY_WAVES) {
             const Box kb{kept[q * 5], kept[q * 5 + 1], kept[q * 5 + 2], kept[q * 5 + 3], kept[q * 5 + 4]};
             dead = iou_gt(kb, me, iou_thres);
         }
@@ -346,7 +350,10 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
         if (lane == 0) dead_s[part] = dm;
         __syncthreads();
         if (part == 0) {
-            unsigned long long alive = ~(dead_s[0] | dead_s[1] | dead_s[2] | dead_s[3]);
+            unsigned long long dm_all = 0ull;
+#pragma unroll
+            for (int q = 0; q < GREEDY_WAVES; ++q) dm_all |= dead_s[q];
+            unsigned long long alive = ~dm_all;
             // (b) inside the chunk: bit j of `sup` = candidate j (earlier, higher score) overlaps me
             unsigned long long sup = 0ull;
             for (int j = 0; j < 64; ++j) {
@@ -669,7 +676,7 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
         hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
     }
     DSN_LAUNCH_CHECK("nms sort");
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(256), (size_t)max_det * 5 * sizeof(float), st, pred, n, nc,
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(GREEDY_WAVES * 64), (size_t)max_det * 5 * sizeof(float), st, pred, n, nc,
                        sorted, cap, counts, iou_thres, agnostic, max_det, out, out_count, starts);
     DSN_LAUNCH_CHECK("nms greedy");
     return DSN_OK;

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
             // (lgkmcnt(0): this wave's fragment reads of chunk i - 1 have COMPLETED, not merely issued, before anyone may overwrite
             //  their stage -- the compiler is free to sink the MFMAs that consume them below the barrier; see conv3x3.hip)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GL - 2) * LPC) : "memory");     // this wave's pieces of chunk i have landed
+            __builtin_amdgcn_sched_barrier(0);             // (issue order pinned at the wait: nothing of chunk i - 1 is placed below it)
             __builtin_amdgcn_s_barrier();                  // everyone's have; and everyone is done reading stage lbuf (chunk i-1)
             asm volatile("" ::: "memory");
             load_chunk(i + GL - 1, rga[0], rgb[0], st_cb[0], st_ok[0], lbuf);

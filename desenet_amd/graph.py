@@ -49,7 +49,12 @@ class GraphedTrainStep:
         about half of the parameters lie behind; 0 disables the overlap)."""
         self.model, self.loss_and_grads, self.flat, self.opt, self.ema = model, loss_and_grads, flat, optimizer, ema
         if any(m.__dict__.get("_dsn_sync") is not None for m in model.modules()):
-            raise NotImplementedError("GraphedTrainStep with SyncBatchNorm: the per-layer collectives run eagerly; use eager steps")
+            # SyncBatchNorm (train.py:217-220): every BatchNorm exchanges its fp64 accumulators once per direction.  Those
+            # all-reduces are recorded INTO the captured graphs like any other launch -- possible with RCCL, whose collectives are
+            # kernels enqueued on the capturing stream; a host-side backend (gloo) cannot be captured.
+            if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+                raise NotImplementedError("GraphedTrainStep with SyncBatchNorm needs the nccl (RCCL) backend: the per-layer "
+                                          "all-reduces are captured into the hipGraph; with gloo use eager steps")
         if accumulate < 1:
             raise ValueError("accumulate must be >= 1")
         self.accumulate = int(accumulate)

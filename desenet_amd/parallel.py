@@ -75,14 +75,18 @@ def sgd_param_groups(model: torch.nn.Module, weight_decay: float = 5e-4):
             dict(params=g_b, weight_decay=0.0)]
 
 
-def convert_sync_batchnorm(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+def convert_sync_batchnorm(module: torch.nn.Module, process_group=None, force_collectives: bool = False) -> torch.nn.Module:
     """`torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` for the mirrored model (scripts/train.py:218-220): every
     BatchNorm2d computes its training statistics over the GLOBAL batch.  The modules keep their type and `state_dict` (same
     keys as SyncBatchNorm); the exchange is one all-reduce (SUM) of the layer's fp64 sum / sum-of-squares accumulators in the
     forward pass and one of its two backward sums -- the same two collectives per layer as torch's implementation, on raw sums
     instead of (mean, invstd, count) triples.  Per-rank batches must be equal (they are under the reference's DDP split,
-    train.py:223).  Returns `module`.  A graph-captured step does not support it (collectives per layer): use eager steps."""
+    train.py:223).  Returns `module`.  Under desenet_amd.graph.GraphedTrainStep the collectives are CAPTURED into the step's
+    hipGraph (backend "nccl" = RCCL only: its all-reduce is a kernel on the capturing stream; gloo's is a host operation and the
+    step refuses it).  force_collectives: issue the exchanges even with a single rank (tests of the captured path on one GPU)."""
     for m in module.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.__dict__["_dsn_sync"] = process_group if process_group is not None else True
+            if force_collectives:
+                m.__dict__["_dsn_sync_force"] = True
     return module

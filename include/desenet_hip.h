@@ -115,6 +115,11 @@ int dsn_conv2d_dgrad_bnred(const dsn_tensor* dy, const void* w_packed, const dsn
 int dsn_conv2d_dgrad_s2_bnred(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
                               const dsn_bnred* red, void* stream);
 
+/* Kernel selection of the weights-stationary persistent convolution kernels (csrc/conv_ws.hip) behind dsn_conv2d_fwd* /
+ * dsn_conv2d_dgrad*: per kernel (1x1, 3x3) 0 = never, 1 = default (per-shape choice measured on MI355X), 2 = without the
+ * data-gradient extras variants, 3 = every eligible launch.  A negative argument leaves that mode unchanged.  Returns
+ * 16 * mode_1x1 + mode_3x3 after the update.  Results do not depend on the mode beyond fp32 summation order. */
+int         dsn_ws_mode(int32_t mode_1x1, int32_t mode_3x3);
 int         dsn_version(void);
 const char* dsn_last_error(void);
 

@@ -9,6 +9,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 3], ids=["default", "ws_extras_everywhere"])
+def ws_mode(request):
+    """1: the library's per-shape kernel choice; 3: every eligible data-gradient launch through the weights-stationary kernels
+    with register-prefetched extras (conv_ws.hip) -- the default only picks them where they measured faster."""
+    from desenet_amd import _lib
+    L = _lib.lib()
+    L.dsn_ws_mode(request.param, request.param)
+    yield request.param
+    L.dsn_ws_mode(1, 1)
+
+
 def _rand(shape, dtype, seed, scale=1.0):
     g = torch.Generator(device="cuda").manual_seed(seed)
     return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
@@ -29,12 +40,23 @@ CASES = [  # k, stride, dil, ci (dx channels), co (dy channels), h, w, segments 
     (3, 2, 1, 64, 128, 16, 16, [(0, 64)], False, False),        # stride 2: parity classes
     (3, 2, 1, 32, 64, 17, 15, [(0, 32)], False, True),
     (5, 1, 1, 32, 16, 10, 10, [(0, 32)], False, False),
+    # maps of >= 2048 pixels: the weights-stationary persistent kernels (conv_ws.hip) with their register-prefetched extras
+    (1, 1, 1, 64, 128, 40, 40, [(0, 64)], False, False),
+    (1, 1, 1, 128, 64, 33, 31, [(0, 64), (64, 128)], True, False),
+    (1, 1, 1, 192, 64, 40, 40, [(64, 128)], False, True),
+    (1, 1, 1, 40, 96, 37, 29, [(8, 40)], True, True),           # ragged tiles, partial slabs, residual + accumulate + sums
+    (1, 1, 1, 32, 64, 64, 64, [(0, 32)], False, True),          # 128 x 32 tiles
+    (3, 1, 1, 64, 64, 40, 48, [(0, 64)], False, False),
+    (3, 1, 1, 64, 64, 33, 31, [(0, 32), (32, 64)], True, True),
+    (3, 1, 2, 64, 64, 40, 40, [(0, 64)], True, False),
+    (3, 1, 3, 64, 64, 40, 40, [(0, 64)], False, True),
+    (3, 1, 1, 32, 32, 64, 64, [(0, 32)], True, False),
 ]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k,stride,dil,ci,co,h,w,segs,use_res,accumulate", CASES)
-def test_dgrad_with_batchnorm_sums_in_its_epilogue(dtype, k, stride, dil, ci, co, h, w, segs, use_res, accumulate):
+def test_dgrad_with_batchnorm_sums_in_its_epilogue(ws_mode, dtype, k, stride, dil, ci, co, h, w, segs, use_res, accumulate):
     import desenet_amd
     from desenet_amd import hip_ops as ops
     from desenet_amd.hip_ops import ACT_SILU, ACT_NONE

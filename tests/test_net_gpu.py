@@ -507,14 +507,22 @@ def test_teacher_forced_layers_bf16_at_640(net, training):
     assert not bad, (bad, worst)
 
 
-def test_teacher_forced_layer_backward_bf16_at_640(net):
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-3), (torch.bfloat16, 6e-2)])
+def test_teacher_forced_layer_backward_at_640(net, dtype, tol):
     """bf16 BACKWARD where the headline runs (config 3: 8 x 640 x 640), against the ORACLE and per top-level layer, so that a
     dgrad / wgrad / BatchNorm-backward error cannot hide behind a comparison of the HIP path with itself: layer L of the mirrored
     model is fed the oracle's fp32 input to L and the oracle's upstream gradient d(total loss)/d(output of L) (train.py:352-367:
     detgain * det loss + seggain * seg loss), and its bf16 input gradient(s) and parameter gradients are held to the oracle's
     for the same isolated layer (torch.autograd.grad over oracle.desenet_ref.apply_layer in fp32 on the CPU).
-    rel err = max|a-b| / max|b| per tensor <= 6e-2; gradients whose oracle value is numerically zero (max|b| < 1e-12: the
-    BatchNorm before a 1x1-map Conv, quirk Q1) must be zero or absent."""
+    rel err = max|a-b| / max|b| per tensor <= 5e-3 in fp32 and <= 6e-2 in bf16; gradients whose oracle value is numerically zero
+    (max|b| < 1e-12: the BatchNorm before a 1x1-map Conv, quirk Q1) must be zero or absent.
+    One documented exception in bf16: SPP (layer 8).  Its three max pools route each output's gradient to the FIRST maximum of a
+    5x5 / 9x9 / 13x13 window; on bf16-rounded activations the largest values of a window tie in a sizeable share of the windows,
+    and the first of the tied pixels is not the pixel whose fp32 value is largest -- the gradient mass moves to another pixel of
+    the window (exactly what ATen's own bf16 max_pool2d does), which the per-element comparison with the fp32 oracle sees as a
+    large error in dx and in cv1's gradients although every kernel is exact (the fp32 run of this test holds layer 8 to 5e-3, and
+    tests/test_resample_r3_gpu.py pins values and arg-max indices bit for bit, ties included).  Bound there: the gradient NORM
+    within 25 % (the bound of the whole-net bf16 tests)."""
     import copy
     from oracle import desenet_ref as R
     from oracle import loss_ref
@@ -542,7 +550,7 @@ def test_teacher_forced_layer_backward_bf16_at_640(net):
     ins_of = lambda L: (x if L.i == 0 else ys[L.i - 1] if L.f == -1 else ys[L.f] if isinstance(L.f, int)
                         else [ys[L.i + j if j < 0 else j] for j in L.f])
     mm = copy.deepcopy(m).train()
-    dsn.set_compute_dtype(torch.bfloat16)
+    dsn.set_compute_dtype(dtype)
     worst, bad = {}, {}
     try:
         for L, HL in zip(layers, list(mm.model)):
@@ -578,7 +586,12 @@ def test_teacher_forced_layer_backward_bf16_at_640(net):
                 assert g is not None, (L.i, nme, "no HIP gradient")
                 e = rel_err(g.float().cpu(), o)
                 worst[(L.i, nme)] = e
-                if not e <= 6e-2:
+                if dtype == torch.bfloat16 and L.kind == "SPP" and not e <= tol:
+                    nerr = abs(float(g.float().norm()) - float(o.norm())) / float(o.norm())      # tie routing: see the docstring
+                    if not nerr <= 0.25:
+                        bad[(L.i, nme)] = ("norm", nerr)
+                    continue
+                if not e <= tol:
                     bad[(L.i, nme)] = e
     finally:
         dsn.set_compute_dtype(torch.float32)

@@ -87,3 +87,69 @@ def test_syncbn_two_ranks_equal_one_rank_on_the_whole_batch():
     for i, m in enumerate(bns):
         assert torch.allclose(r[0]["rm"][i], m.running_mean.cpu(), rtol=1e-5, atol=1e-6)
         assert torch.allclose(r[0]["rv"][i], m.running_var.cpu(), rtol=1e-5, atol=1e-6)      # unbiased over the GLOBAL count
+
+
+def _graph_worker(rank, port, path):
+    import copy
+    import torch.distributed as dist
+    import desenet_amd
+    from desenet_amd.core.models.yolo import Model
+    from desenet_amd.core.utils.hyp import DETGAIN, SEGGAIN, scale_hyp
+    from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
+    from desenet_amd.graph import GraphedTrainStep
+    from desenet_amd.optim import FusedSGD
+    from desenet_amd.parallel import FlatGradients, convert_sync_batchnorm, sgd_param_groups
+    from desenet_amd.synth import synth_images, synth_targets, synthetic_checkpoint
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        desenet_amd.set_compute_dtype(torch.float32)
+        base = Model("desenet_s.yaml", ch=3, nc=6)
+        sd = base.state_dict()
+        synthetic_checkpoint(sd)
+        base.load_state_dict(sd)
+        x = synth_images(2, 128, 31).cuda()
+        det_t, seg_t = synth_targets(2, 128, 31)
+        det_t, seg_t = det_t.cuda(), seg_t.cuda()
+        out = {}
+        for tag in ("plain", "sync"):
+            m = copy.deepcopy(base).cuda().train()
+            m.hyp = scale_hyp(6, 128)
+            if tag == "sync":
+                convert_sync_batchnorm(m, force_collectives=True)
+            flat = FlatGradients(m.parameters())
+            opt = FusedSGD(sgd_param_groups(m), lr=0.01, momentum=0.937, nesterov=True)
+            cl, sl = ComputeLoss(m), SegmentationLosses()
+
+            def lg(det, seg, dl, sg):
+                o, d_det = cl.forward_backward(det, dl, gain=DETGAIN)
+                so, d_seg = sl.forward_backward(seg, sg, gain=SEGGAIN)
+                return (o, so), d_det, d_seg
+            step = GraphedTrainStep(m, lg, flat, opt, x, det_targets=det_t, seg_targets=seg_t, max_targets=32)
+            for _ in range(2):
+                step(x, det_t, seg_t)
+            torch.cuda.synchronize()
+            out[tag] = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        torch.save(out, os.path.join(path, "sd.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_syncbn_collectives_inside_the_captured_step():
+    """GraphedTrainStep with SyncBatchNorm: the per-layer all-reduces of the BatchNorm accumulators are captured into the step's
+    hipGraph (RCCL).  One GPU, one rank, collectives forced on: two replayed optimizer steps must leave the model exactly where the
+    same steps without SyncBatchNorm leave it (a one-rank SUM is the identity) -- what is exercised is that ~135 captured RCCL
+    all-reduces per step replay correctly between the library's kernels.  The two-rank arithmetic is the eager test above."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_graph_worker, args=(port, d), nprocs=1, join=True)
+        sd = torch.load(os.path.join(d, "sd.pt"))
+    for k, v in sd["plain"].items():
+        if v.dtype.is_floating_point:
+            # (the synchronised path runs the two-launch conv + BatchNorm kernels, the plain one the deferred-statistics pair:
+            #  same arithmetic in another summation order)
+            assert torch.allclose(sd["sync"][k], v, rtol=2e-3, atol=1e-4), k
