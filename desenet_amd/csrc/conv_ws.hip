@@ -1082,6 +1082,222 @@ int launch_3x3_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, con
     return 1;
 }
 
+
+// ================================================================================================================================
+// 3x3 / stride 1 / pad 1 over a THIN input: 16 bf16 channels per pixel (32 bytes) -- Focus' convolution on the space-to-depth image
+// (common.py:618-627: 12 channels, zero-padded to 16; 819,200 output pixels per batch of 8, the largest map of the network).
+// With whole 128-byte slabs per tap (the kernels above, igemm.hip) three quarters of every LDS row and MFMA k-step are zeros.  Here
+// the three taps of one kernel ROW are one contiguous run: pixels x-1, x, x+1 of an NHWC row are 3 x 32 = 96 adjacent bytes, and the
+// packed weights [Co][ky][kx][16] hold the matching 48 coefficients contiguously -- K = 3 rows x 64 (48 + 16 zero-weight) channels,
+// 6 k-steps instead of 18, and the halo patch is stored as it lies in memory (no swizzle: 32-byte pixels at stride 32 are
+// conflict-free for the fragment reads by themselves).  Same persistent / ring / epilogue structure as conv3x3_ws_kernel.
+// ================================================================================================================================
+template <int MI, int NI, int WGN, bool STATS, int D>
+__global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ dst,
+                                                              const BnAcc fin, const WGeom g) {
+    typedef bf16_t T;
+    constexpr int WGM = 4 / WGN;
+    constexpr int TW = 16, TH = WGM * MI, BM = TH * TW, BN = WGN * NI * 16;
+    constexpr int PXB = 32;                              // bytes per input pixel
+    constexpr int HWP = TW + 2, HROWB = HWP * PXB;       // halo row: 18 pixels = 576 bytes
+    constexpr int NPIECE = (TH + 2) * HROWB / 16;        // 16-byte pieces of a halo patch
+    constexpr int IH = (NPIECE + 255) / 256;             // DMA instructions per wave and patch
+    // a stage is what the IH DMA instructions of a patch COVER (lanes past the patch write zeros: they must stay inside the stage);
+    // the over-reading last k-step of the last row lands in that zero tail
+    constexpr int HSTAGE = IH * 256 * 16;
+    static_assert(HSTAGE >= (TH + 2) * HROWB + 64, "zero tail behind the patch");
+    typedef OutVec<T, NI> OV;
+    constexpr int NV = OV::NV, CPV = OV::CPV;
+    constexpr int ST = MI * NV;
+    static_assert(BN % 32 == 0, "weight rows are filled 32 per DMA pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                  // [3 ky][BN rows][128 B]: 48 coefficients + 16 zeros
+    unsigned char* sH = smem + 3 * BN * ROWB;                  // [D][HSTAGE]
+    float* sRed = reinterpret_cast<float*>(sH + D * HSTAGE);   // [WGM][BN][2] (STATS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tn = blockIdx.x % g.tiles_n, grp = blockIdx.x / g.tiles_n, ngrp = gridDim.x / g.tiles_n;
+    const int n0 = tn * BN;
+    const int per = (g.tiles_m + ngrp - 1) / ngrp;
+    const int t_begin = grp * per, t_end = (t_begin + per < g.tiles_m) ? t_begin + per : g.tiles_m;
+    const int tiles_img = g.tiles_y * g.tiles_x;
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, g.dst_bytes, 0x00020000);
+
+    // weights: row q = 32 i + (tid >> 3) of kernel row ky; physical slot tid & 7 <- logical slot lsw (slots 6, 7: zeros)
+    const int r0 = tid >> 3;
+    const int lsw = (tid & 7) ^ ((r0 >> 1) & 7);
+    auto load_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int ch = n0 + wrow_channel<T>(32 * i + r0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const uint32_t off = (ch < g.Cd && lsw < 6) ? (uint32_t)(((int64_t)ch * 9 + ky * 3) * 16 + lsw * 8) * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + ((ky * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    // halo patch c of this block: rows y0 - 1 .. y0 + TH, columns x0 - 1 .. x0 + TW, stored row after row as in memory
+    auto load_halo = [&](int c, int stage) {
+        const int tile = t_begin + c;
+        const bool live = tile < t_end;
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < IH; ++j) {
+            const int q = j * 256 + tid;
+            const int hy = q / (HROWB / 16), piece = q - hy * (HROWB / 16);
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + (piece >> 1);
+            const bool ok = live && q < NPIECE && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + (piece & 1) * 8) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
+        }
+    };
+
+    float bv[NV][CPV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = n0 + OV::ch(wn, v, fg);
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) bv[v][k] = (bias && c + k < g.Cd) ? bias[c + k] : 0.f;
+    }
+    StatRegs<NV, CPV, STATS> stat;
+    stat.zero();
+
+    load_w();
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_halo(j, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) asm volatile("" : "+v"(bv[v][k]));
+
+    int stage = 0, c = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, ++c) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_halo(c + D - 1, stage == 0 ? D - 1 : stage - 1);
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* hb = sH + stage * HSTAGE;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 fx[MI], fw[NI];
+                const int slot = 4 * h + fg;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)       // pixel (row wm MI + i, column fr): its run starts at halo column fr (= x - 1)
+                    fx[i] = *reinterpret_cast<const u32x4*>(hb + ((wm * MI + i + ky) * HWP + fr) * PXB + slot * 16);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = (wn * NI + j) * 16 + fr;
+                    fw[j] = *reinterpret_cast<const u32x4*>(sW + (ky * BN + r) * ROWB + ((slot ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], fw[j], fx[i]);
+            }
+        }
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int y = y0 + wm * MI + i, x = x0 + fr;
+            const int64_t m = ((int64_t)n * g.H + y) * g.W + x;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cc = n0 + OV::ch(wn, v, fg);
+                float o[CPV];
+                OV::get(acc[i], v, o);
+                const bool ok = y < g.H && x < g.W && cc < g.Cd;
+                stat.add(v, o, ok);
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
+                if (g.act == DSN_ACT_SILU) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
+                } else if (g.act == DSN_ACT_SIGMOID) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                }
+                const uint32_t off = ok ? (uint32_t)(m * g.dld + cc) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
+            }
+        }
+        wait_vm<(D - 2) * IH, ST>(c + 1 < D - 1 ? c + 1 : D - 1);
+        stage = stage + 1 == D ? 0 : stage + 1;
+    }
+
+    if constexpr (STATS) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    stat.s[v][k] += __shfl_xor(stat.s[v][k], o);
+                    stat.ss[v][k] += __shfl_xor(stat.ss[v][k], o);
+                }
+            }
+        __syncthreads();
+        if (fr == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) {
+                    const int cl = OV::ch(wn, v, fg) + k;
+                    sRed[(wm * BN + cl) * 2] = stat.s[v][k];
+                    sRed[(wm * BN + cl) * 2 + 1] = stat.ss[v][k];
+                }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cd) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) {
+                t0 += sRed[(w * BN + tid) * 2];
+                t1 += sRed[(w * BN + tid) * 2 + 1];
+            }
+            bn_acc_add(fin, blockIdx.x, n0 + tid, t0, t1);
+        }
+    }
+}
+
+template <bool STATS>
+int launch_3x3_thin(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, WGeom g, const BnAcc& fin, hipStream_t st) {
+    constexpr int MI = 2, NI = 2, WGN = 1, WGM = 4, D = 4;
+    constexpr int TH = WGM * MI, TW = 16, BM = TH * TW, BN = WGN * NI * 16;
+    constexpr int HSTAGE = (((TH + 2) * 18 * 2 + 255) / 256) * 256 * 16;
+    static_assert(BM == 128, "8 x 16 patches");
+    g.tiles_y = (g.H + TH - 1) / TH;
+    g.tiles_x = (g.W + TW - 1) / TW;
+    g.tiles_m = g.N * g.tiles_y * g.tiles_x;
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    const size_t lds = (size_t)3 * BN * ROWB + (size_t)D * HSTAGE + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
+    const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 4);
+    auto kern = conv3x3_thin_ws_kernel<MI, NI, WGN, STATS, D>;
+    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd) + 9.0 * g.Cs * g.Cd;
+    const ProfConv pc("conv3x3_thin_ws_kernel", true, BM, BN, false, 3, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * 2, st);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const bf16_t*)s->ptr, (const bf16_t*)w, bias, (bf16_t*)d->ptr, fin, g);
+    DSN_LAUNCH_CHECK("conv3x3 (thin input, weights-stationary)");
+    return DSN_OK;
+}
+
 }  // namespace
 
 // selection mode of the two kernels (environment DSN_WS / DSN_WS3 at load time; dsn_ws_mode() at run time: tests, A/B runs)
@@ -1181,6 +1397,21 @@ int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
     const int64_t db = ((npix(d) - 1) * d->ldc + d->c) * es;
     if (sb >= (1ll << 31) || wb >= (1ll << 31) || db >= (1ll << 32) - 64) return 1;
     if (npix(d) < 2048) return 1;
+    if (s->dtype == DSN_BF16 && s->c == 16 && s->ldc == 16 && p->dil == 1 && !is_dgrad && !extras && d->c % 8 == 0) {
+        // thin input (Focus): three taps of a kernel row are one contiguous 96-byte run
+        WGeom t{};
+        t.N = s->n; t.H = s->h; t.W = s->w; t.Cs = 16; t.Cd = d->c; t.d = 1; t.act = p->act;
+        t.sld = s->ldc; t.dld = d->ldc;
+        t.src_bytes = (uint32_t)sb; t.w_bytes = (uint32_t)wb; t.dst_bytes = (uint32_t)db;
+        t.wrow = 9 * 16;
+        BnAcc f{};
+        if (finp) f = *finp;
+        if (f.acc) {
+            if (bias || p->act != DSN_ACT_NONE) return 1;
+            return launch_3x3_thin<true>(s, w, bias, d, t, f, (hipStream_t)stream);
+        }
+        return launch_3x3_thin<false>(s, w, bias, d, t, f, (hipStream_t)stream);
+    }
     WGeom g{};
     g.N = s->n; g.H = s->h; g.W = s->w; g.Cs = s->c; g.Cd = d->c; g.d = p->dil; g.flip = is_dgrad ? 1 : 0;
     g.act = p->act;

@@ -175,3 +175,33 @@ def test_conv3x3_ws_batchnorm_sums(ops, case, dtype):
     assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 2e-3 if dtype == torch.float32 else 2e-2, "batch mean")
     assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
     assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
+
+
+@pytest.mark.parametrize("case", [(8, 16, 320, 320, 32), (2, 16, 70, 67, 24), (1, 16, 48, 64, 32)])
+@pytest.mark.parametrize("mode", ["act", "stats"])
+def test_conv3x3_thin_input_focus_kernel(ops, case, mode):
+    """Focus' convolution shape: 16 bf16 channels per pixel (12 real + 4 zero lanes), 3x3 / stride 1 -- the three taps of a kernel row
+    as one contiguous 96-byte run (conv3x3_thin_ws_kernel), with the fused bias + SiLU epilogue and with BatchNorm sums."""
+    n, ci, h, w, co = case
+    dtype = torch.bfloat16
+    x = rnd((n, ci, h, w), 71)
+    x[:, 12:] = 0.0                                   # the padding lanes of the space-to-depth tensor
+    wt, b = rnd((co, ci, 3, 3), 72, -0.2, 0.2), rnd((co,), 73)
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, h, w, dtype, "cuda")
+    if mode == "act":
+        ref = F.silu(F.conv2d(q(x, dtype), q(wt, dtype), b, 1, 1))
+        _ran(ops, lambda: ops.conv2d_fwd(xd, wp, b.cuda(), None, y, ops.conv_params(3, act=ops.ACT_SILU)), "conv3x3_thin_ws_kernel")
+        assert_close(y.float().cpu(), ref, TOL[dtype], f"thin 3x3 {case}")
+    else:
+        g_, b_ = rnd((co,), 74, 0.5, 1.5), rnd((co,), 75, -0.2, 0.2)
+        yref = F.conv2d(q(x, dtype), q(wt, dtype), None, 1, 1)
+        zref = F.silu(F.batch_norm(yref, None, None, g_, b_, True, 0.03, 1e-3))
+        z = ops.new_act(n, co, h, w, dtype, "cuda")
+        rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+        stats = _ran(ops, lambda: ops.conv2d_fwd_bnstats(xd, wp, y, ops.conv_params(3), g_.cuda(), b_.cuda(), rm, rv, 0.03, 1e-3,
+                                                         ops.ACT_SILU, None, z), "conv3x3_thin_ws_kernel")
+        assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 2e-2, "batch mean")
+        assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
+        assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
