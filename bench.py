@@ -173,7 +173,9 @@ def roofline_from_profile(prof, steps, dtype):
     roof.update({"avg_launch_us": avg_ms * 1e3, "launches_per_step": r["launches"] / steps,
                  "algorithmic_GBs": r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9,
                  "algorithmic_TFLOPs": (r["flops"] / r["launches"] / (avg_ms * 1e-3) / 1e12) if r["flops"] else None,
-                 "flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "traffic": _traffic_table().get(name),
+                 "flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                 # PMC bytes per launch (profiles/traffic.json, keyed by symbol family / dtype / tile: fwd and dgrad share a symbol)
+                 "traffic": _traffic_table().get(name, _traffic_table().get(name.rsplit("/", 1)[0])),
                  "timing": "HIP events around the same launches on eager steps right after the timed hipGraph replays "
                            "(10-15 % above their duration under replay: profiles/*_kernel_stats.csv hold the rocprofv3 view)"})
     return roof, table
