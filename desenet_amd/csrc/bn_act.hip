@@ -13,7 +13,11 @@
 namespace {
 
 constexpr int THREADS = 256;
-constexpr int UNROLL = 4;
+// vectors per thread and batch.  4 cost the backward apply 136 VGPRs = 3 blocks per CU = 768 resident blocks, fewer than the
+// 800-1023 a batch-8 layer launches (two rounds of a latency-bound pass); 2 -> 96 VGPRs, 5 blocks per CU: config 3 +3 %.
+// (Issuing the first batch above the prologue -- to overlap the accumulator fold with the operands' latency -- measured 2.6 %
+// SLOWER at equal occupancy, and 1 vector per batch 1.2 % slower than 2.)
+constexpr int UNROLL = 2;
 constexpr int MAX_RED_BLOCKS = 1024;
 
 // V consecutive per-channel fp32 constants (c0 is a multiple of V, arrays are 32-byte aligned): 16-byte loads instead of V
@@ -48,9 +52,13 @@ template <int V> struct BwdRedF {           // sum g, sum g*yhat with g = dz * a
         ldvec<V>(p.scale + c0, sc); ldvec<V>(p.shift + c0, sh); ldvec<V>(p.mean + c0, mu); ldvec<V>(p.rstd + c0, rs);
     }
     __device__ __forceinline__ void acc(const float (&y)[V], const float (&dz)[V], float (&q0)[V], float (&q1)[V]) const {
+        float u[V], gr[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) u[k] = y[k] * sc[k] + sh[k];
+        act_grad_vec<V>(u, p.act, gr);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float g = dz[k] * act_grad(y[k] * sc[k] + sh[k], p.act);
+            const float g = dz[k] * gr[k];
             q0[k] += g;
             q1[k] += g * ((y[k] - mu[k]) * rs[k]);
         }
@@ -71,11 +79,12 @@ template <int V> struct FwdF {              // act(y*scale + shift) [+ res]
         }
     }
     __device__ __forceinline__ void apply(const float (&y)[V], const float (&r)[V], float (&o)[V]) const {
+        float u[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float u = apply_act(y[k] * sc[k] + sh[k], p.act);
-            o[k] = has_res ? u + r[k] : u;
-        }
+        for (int k = 0; k < V; ++k) u[k] = y[k] * sc[k] + sh[k];
+        apply_act_vec<V>(u, p.act);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = has_res ? u[k] + r[k] : u[k];
     }
 };
 template <int V> struct BwdApplyF {         // BN: scale*(g - mean_g - yhat*mean_gyhat);  no BN: dz*act'(y)
@@ -95,14 +104,20 @@ template <int V> struct BwdApplyF {         // BN: scale*(g - mean_g - yhat*mean
         }
     }
     __device__ __forceinline__ void apply(const float (&y)[V], const float (&dz)[V], float (&o)[V]) const {
+        float u[V], gr[V];
+        if (p.scale) {
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            if (p.scale) {
-                const float g = dz[k] * act_grad(y[k] * sc[k] + sh[k], p.act);
+            for (int k = 0; k < V; ++k) u[k] = y[k] * sc[k] + sh[k];
+            act_grad_vec<V>(u, p.act, gr);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float g = dz[k] * gr[k];
                 o[k] = sc[k] * g + (ka[k] * (y[k] - mu[k]) + kb[k]);
-            } else {
-                o[k] = dz[k] * act_grad(y[k], p.act);
             }
+        } else {
+            act_grad_vec<V>(y, p.act, gr);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = dz[k] * gr[k];
         }
     }
 };
@@ -311,11 +326,16 @@ __global__ __launch_bounds__(THREADS) void lazy_ew_kernel(const T* __restrict__ 
         auto one = [&](const float (&va)[V], const float (&vr)[V], int64_t p) {
             float vo[V];
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                float u = apply_act(va[k] * asc[k] + ash[k], aact);
+            for (int k = 0; k < V; ++k) vo[k] = va[k] * asc[k] + ash[k];
+            apply_act_vec<V>(vo, aact);
+            if (HAS_R) {
+                float ur[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) ur[k] = vr[k] * rsc[k] + rsh[k];
+                apply_act_vec<V>(ur, ract);
                 // a deferred residual is what its own materialisation would have stored: rounded to T before the add
-                if (HAS_R) u += to_f32<T>(from_f32<T>(apply_act(vr[k] * rsc[k] + rsh[k], ract)));
-                vo[k] = u;
+#pragma unroll
+                for (int k = 0; k < V; ++k) vo[k] += to_f32<T>(from_f32<T>(ur[k]));
             }
             VecIO<T, V>::store(op + p * old_, vo);
         };

@@ -300,11 +300,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
         const float bv = (bias && col < g.Cd) ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
+        {
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = acc[i][j][e] + bv;
+            apply_act_vec<4>(v4, g.act);          // (the activation code is tested per 4 values, not per value)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rl = (wm * MI + i) * 16 + fg * 4 + e;
-                sC[rl * LDC + cl] = apply_act(acc[i][j][e] + bv, g.act);
+                sC[rl * LDC + cl] = v4[e];
             }
+        }
     }
     __syncthreads();
     if (fin.acc) {
@@ -569,11 +575,17 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
         const float bv = (bias && col < g.Cd) ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
+        {
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = acc[i][j][e] + bv;
+            apply_act_vec<4>(v4, g.act);          // (the activation code is tested per 4 values, not per value)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rl = (wm * MI + i) * 16 + fg * 4 + e;
-                sC[rl * LDC + cl] = apply_act(acc[i][j][e] + bv, g.act);
+                sC[rl * LDC + cl] = v4[e];
             }
+        }
     }
     __syncthreads();
     if (fin.acc) {

@@ -242,10 +242,14 @@ template <typename T, int MI, int NV, int CPV> struct WsXState {
         if (segv[v] >= 0 && ok) {
             T outv[CPV];
             *reinterpret_cast<u32x4*>(outv) = packed;
+            float u[CPV], gr[CPV];
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) u[k] = to_f32<T>(yv[k]) * sc[v][k] + sh[v][k];
+            act_grad_vec<CPV>(u, actv[v], gr);
 #pragma unroll
             for (int k = 0; k < CPV; ++k) {
                 const float y = to_f32<T>(yv[k]);
-                const float gk = to_f32<T>(outv[k]) * act_grad(y * sc[v][k] + sh[v][k], actv[v]);
+                const float gk = to_f32<T>(outv[k]) * gr[k];
                 q0[v][k] += gk;
                 q1[v][k] += gk * ((y - mu[v][k]) * rs[v][k]);
             }
