@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--model", choices=["s", "m"], default="s", help="s = DeSeNet-s (configs 1-4, the headline), m = config 5's graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-layers", default="", help="write the per-(kernel label, layer) table of the profiled eager steps to this file")
     ap.add_argument("--no-ema", action="store_true", help="train: leave out the rank-0 ModelEMA update (train.py:374)")
     ap.add_argument("--eager", action="store_true", help="train: launch every kernel from Python instead of hipGraph replay")
     ap.add_argument("--accumulate", type=int, default=1, help="train: micro-batches per optimizer step (train.py:146; 1 = step every batch)")
@@ -418,6 +419,13 @@ def main():
             torch.cuda.synchronize()
         prof, prof_layers = ops.profile_collect(by_layer=True)
         ops.profile_enable(False)
+        if a.dump_layers and rank == 0:
+            with open(a.dump_layers, "w") as f:
+                f.write(f"{'us/step':>9s} {'n/step':>6s} {'avg us':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}  kernel label | layer\n")
+                for (label, layer), r in sorted(prof_layers.items(), key=lambda kv: -kv[1]["ms"]):
+                    sec = max(r["ms"] * 1e-3, 1e-12)
+                    f.write(f"{r['ms'] * 1e3 / prof_steps:9.1f} {r['launches'] / prof_steps:6.1f} {r['ms'] * 1e3 / max(r['launches'], 1):8.1f} "
+                            f"{r['flops'] / sec / 1e12:8.1f} {r['bytes'] / sec / 1e9:7.0f}  {label} | {layer}\n")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

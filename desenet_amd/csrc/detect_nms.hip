@@ -180,24 +180,32 @@ __device__ __forceinline__ uint64_t make_key_flat(int b, float conf, uint32_t id
     return ((uint64_t)b << 48) | ((uint64_t)(~__float_as_uint(conf) & 0x3FFFFFFFu) << FLAT_IDX_BITS) | idx;
 }
 
-// One returning atomic per WAVE, not per candidate: the lanes that keep a candidate are counted with a ballot, the first of them
-// reserves the slots, every lane takes base + (kept lanes below it).  (One atomicAdd per candidate on the image's counter
-// serialised at ~100 ns each: 2.6 ms for 16 x 25200 rows when every row survives the threshold.)  blockIdx.y = image.
-__device__ __forceinline__ int wave_slot(bool want, int32_t* counter) {
+// One returning atomic per 256-thread BLOCK, not per candidate: the lanes that keep a candidate are counted with a ballot, the four
+// waves' counts meet in LDS, ONE lane reserves the block's slots and every lane takes base + (kept lanes before it).  (One atomicAdd
+// per candidate on the image's counter serialised at ~100 ns each: 2.6 ms for 16 x 25200 rows when every row survives the
+// threshold; one per wave, 6300 of them, still cost 77 us.)  Uniform call sites only; blockIdx.y = image.
+__device__ __forceinline__ int block_slot(bool want, int32_t* counter, int* s_cnt) {
     const uint64_t mask = __ballot(want);
-    if (mask == 0) return -1;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((unsigned long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader);
-    return want ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_cnt[4] = total ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    int base = s_cnt[4];
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
+    const int slot = want ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+    __syncthreads();
+    return slot;
 }
 
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int bs, int n, int nc,
                                                              float conf_thres, int multi_label, uint64_t classes_mask,
                                                              uint64_t* __restrict__ keys, int64_t cap,
                                                              int32_t* __restrict__ counts, int flat) {
+    __shared__ int s_cnt[5];
     const int no = 5 + nc;
     const int b = blockIdx.y;
     uint64_t* kb = keys + (int64_t)b * cap;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
             for (int j = 0; j < nc; ++j) {
                 const float conf = live ? r[5 + j] * obj : 0.f;
                 const bool want = live && conf > conf_thres && (classes_mask == 0 || ((classes_mask >> j) & 1));
-                const int slot = wave_slot(want, &counts[b]);
+                const int slot = block_slot(want, &counts[b], s_cnt);
                 if (want) kb[slot] = flat ? make_key_flat(b, conf, (uint32_t)(row * nc + j)) : make_key(conf, (uint32_t)(row * nc + j));
             }
         } else {
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
                 }
             }
             const bool want = live && best > conf_thres && (classes_mask == 0 || ((classes_mask >> bj) & 1));
-            const int slot = wave_slot(want, &counts[b]);
+            const int slot = block_slot(want, &counts[b], s_cnt);
             if (want) kb[slot] = flat ? make_key_flat(b, best, (uint32_t)(row * nc + bj)) : make_key(best, (uint32_t)(row * nc + bj));
         }
     }
@@ -296,75 +304,136 @@ __device__ __forceinline__ bool iou_gt(const Box& a, const Box& b, float thr) {
     const float xx2 = fminf(a.x2, b.x2), yy2 = fminf(a.y2, b.y2);
     const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
     const float inter = w * h;
+    // inter == 0: ovr is 0 (or NaN for two empty boxes), never > thr >= 0 -- the common case skips the IEEE division
+    if (!(inter > 0.f)) return false;
     const float ovr = inter / (a.area + b.area - inter);
     return ovr > thr;
 }
 
-// NW waves per image: wave 0 owns the 64 candidates of a chunk (and the serial sweep inside it), ALL waves hold copies of them
-// and split the list of boxes kept so far NW ways -- the long part once a few hundred boxes are kept (max_det 1000 at detect.py's
-// settings: 250 IoU evaluations per chunk and wave with 4 waves, 63 with 16).  Same comparisons, same order of decisions.
-constexpr int GREEDY_WAVES = 16;
-__global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const float* __restrict__ pred, int n, int nc,
+// Stage 3a (all CUs): the sorted candidates of every image as rows [x1, y1, x2, y2, conf, cls] (general.py:688-699: xywh2xyxy, conf =
+// obj * cls) -- the key -> row -> prediction chain is two dependent trips to memory, which the serial sweep below used to pay once
+// per 64 candidates.
+constexpr int CAND_W = 6;
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ pred, int n, int nc,
                                                          const uint64_t* __restrict__ keys, int64_t cap,
-                                                         const int32_t* __restrict__ counts, float iou_thres,
-                                                         int agnostic, int max_det, float* __restrict__ out,
-                                                         int32_t* __restrict__ out_count, const int32_t* __restrict__ starts) {
-    extern __shared__ float kept[];   // [max_det][5]
-    __shared__ unsigned long long dead_s[GREEDY_WAVES];
-    __shared__ int nkept_s;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ starts,
+                                                         float* __restrict__ cand, int64_t cand_cap) {
+    const int b = blockIdx.y;
     const int no = 5 + nc;
     const uint64_t* k = starts ? keys + starts[b] : keys + (int64_t)b * cap;      // flat (one sort over all images) / per-image
     const uint32_t idx_mask = starts ? ((1u << FLAT_IDX_BITS) - 1u) : 0xFFFFFFFFu;
     int cnt = counts[b];
     if (cnt > MAX_NMS) cnt = MAX_NMS;
+    float* cb = cand + (int64_t)b * cand_cap * CAND_W;
+    for (int ci = blockIdx.x * 256 + threadIdx.x; ci < cnt; ci += gridDim.x * 256) {
+        const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu) & idx_mask;
+        const int row = idx / nc, cls = idx - row * nc;
+        const float* r = pred + ((int64_t)b * n + row) * no;
+        const float hw = r[2] / 2.0f, hh = r[3] / 2.0f;
+        float* o = cb + (int64_t)ci * CAND_W;
+        o[0] = r[0] - hw; o[1] = r[1] - hh; o[2] = r[0] + hw; o[3] = r[1] + hh;
+        o[4] = r[5 + cls] * r[4];
+        o[5] = (float)cls;
+    }
+}
+
+// Stage 3b: greedy suppression, one workgroup of NW waves per image, 64 candidates (one per lane, every wave holds a copy) per
+// round.  Per round: (a) the waves split the list of boxes kept so far (max_det 1000 at detect.py's settings: 63 IoU evaluations
+// per wave with 16 waves); (b) the 64 x 64 comparisons INSIDE the chunk are split NW ways as well (4 earlier candidates per wave:
+// one wave doing all 64 was the longest part of a round, 3 us); (c) wave 0 sweeps the chunk with the two bit masks, jumping from
+// kept box to kept box (s_ff1) instead of visiting all 64 positions.  The next chunk's rows are requested before (a) and the
+// barriers wait for LDS only, so no round waits on memory.  Same comparisons and the same order of decisions as the serial
+// reference (torchvision.ops.nms semantics, general.py:714).
+constexpr int GREEDY_WAVES = 16;
+__global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const float* __restrict__ cand, int64_t cand_cap,
+                                                                       const int32_t* __restrict__ counts, float iou_thres,
+                                                                       int agnostic, int max_det, float* __restrict__ out,
+                                                                       int32_t* __restrict__ out_count) {
+    static_assert(GREEDY_WAVES == 16, "4 in-chunk candidates per wave, 16 nibbles per lane");
+    extern __shared__ __attribute__((aligned(16))) float kept[];   // [max_det rounded up to 4][5]
+    __shared__ unsigned long long dead_s[GREEDY_WAVES];
+    __shared__ __attribute__((aligned(16))) unsigned char sup_s[64][GREEDY_WAVES];      // [lane][wave]: 4 bits each
+    __shared__ int nkept_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+    int cnt = counts[b];
+    if (cnt > MAX_NMS) cnt = MAX_NMS;
+    const float* cb = cand + (int64_t)b * cand_cap * CAND_W;
     if (tid == 0) nkept_s = 0;
     __syncthreads();
     float* ob = out + (int64_t)b * max_det * 6;
+    auto fetch = [&](int base, float (&raw)[6]) {
+        const int ci = base + lane;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) raw[e] = 0.f;
+        if (ci < cnt) {
+            const float2* r = reinterpret_cast<const float2*>(cb + (int64_t)ci * CAND_W);
+            const float2 v0 = r[0], v1 = r[1], v2 = r[2];
+            raw[0] = v0.x; raw[1] = v0.y; raw[2] = v1.x; raw[3] = v1.y; raw[4] = v2.x; raw[5] = v2.y;
+        }
+    };
+    auto lds_barrier = [&]() {           // (workgroup traffic is LDS only: leave the prefetch in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    float raw[6], nxt[6];
+    fetch(0, raw);
     for (int base = 0; base < cnt; base += 64) {
         const int nkept = nkept_s;
         if (nkept >= max_det) break;
-        const int ci = base + lane;
-        const bool valid = ci < cnt;
+        fetch(base + 64, nxt);
+        const bool valid = base + lane < cnt;
         Box me{0.f, 0.f, 0.f, 0.f, 0.f};
-        float raw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu) & idx_mask;
-            const int row = idx / nc, cls = idx - row * nc;
-            const float* r = pred + ((int64_t)b * n + row) * no;
-            const float hw = r[2] / 2.0f, hh = r[3] / 2.0f;
-            raw[0] = r[0] - hw; raw[1] = r[1] - hh; raw[2] = r[0] + hw; raw[3] = r[1] + hh;
-            raw[4] = r[5 + cls] * r[4];
-            raw[5] = (float)cls;
             const float off = raw[5] * (agnostic ? 0.f : (float)MAX_WH);
             me.x1 = raw[0] + off; me.y1 = raw[1] + off; me.x2 = raw[2] + off; me.y2 = raw[3] + off;
             me.area = (me.x2 - me.x1) * (me.y2 - me.y1);
         }
         // (a) against boxes kept so far: the waves split the kept list
+        // wave w takes boxes 4 (w + NW s) .. + 3: twenty consecutive floats = five broadcast ds_read_b128 per step
         bool dead = !valid;
-        for (int q = part; q < nkept && !dead; q += GREEDY_WAVES) {
-            const Box kb{kept[q * 5], kept[q * 5 + 1], kept[q * 5 + 2], kept[q * 5 + 3], kept[q * 5 + 4]};
-            dead = iou_gt(kb, me, iou_thres);
+        for (int q0 = 4 * part; q0 < nkept; q0 += 4 * GREEDY_WAVES) {
+            float kb[20];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&kept[q0 * 5 + 4 * v]);
+                kb[4 * v] = t[0]; kb[4 * v + 1] = t[1]; kb[4 * v + 2] = t[2]; kb[4 * v + 3] = t[3];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + u < nkept && iou_gt(Box{kb[5 * u], kb[5 * u + 1], kb[5 * u + 2], kb[5 * u + 3], kb[5 * u + 4]}, me, iou_thres))
+                    dead = true;
         }
         const unsigned long long dm = __ballot(dead);
         if (lane == 0) dead_s[part] = dm;
-        __syncthreads();
+        // (b) inside the chunk: bit jj of `bits` = candidate 4 * part + jj (earlier, higher score) overlaps me
+        unsigned bits = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = part * 4 + jj;
+            Box o;
+            o.x1 = __shfl(me.x1, j); o.y1 = __shfl(me.y1, j); o.x2 = __shfl(me.x2, j); o.y2 = __shfl(me.y2, j);
+            o.area = __shfl(me.area, j);
+            if (j < lane && iou_gt(o, me, iou_thres)) bits |= 1u << jj;
+        }
+        sup_s[lane][part] = (unsigned char)bits;
+        lds_barrier();
         if (part == 0) {
             unsigned long long dm_all = 0ull;
 #pragma unroll
             for (int q = 0; q < GREEDY_WAVES; ++q) dm_all |= dead_s[q];
-            unsigned long long alive = ~dm_all;
-            // (b) inside the chunk: bit j of `sup` = candidate j (earlier, higher score) overlaps me
+            const u32x4 sv = *reinterpret_cast<const u32x4*>(&sup_s[lane][0]);
             unsigned long long sup = 0ull;
-            for (int j = 0; j < 64; ++j) {
-                Box o;
-                o.x1 = __shfl(me.x1, j); o.y1 = __shfl(me.y1, j); o.x2 = __shfl(me.x2, j); o.y2 = __shfl(me.y2, j);
-                o.area = __shfl(me.area, j);
-                if (j < lane && iou_gt(o, me, iou_thres)) sup |= (1ull << j);
-            }
+#pragma unroll
+            for (int q = 0; q < GREEDY_WAVES; ++q)
+                sup |= (unsigned long long)((sv[q >> 2] >> (8 * (q & 3))) & 15u) << (4 * q);
+            const unsigned long long a0 = ~dm_all;
+            // (readfirstlane returns int: widen through unsigned, or bit 31 of the low word smears over the high one)
+            unsigned long long alive = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) |
+                                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a0);
             int nk = nkept;
-            for (int j = 0; j < 64 && nk < max_det; ++j) {
-                if (!((alive >> j) & 1ull)) continue;     // wave-uniform
+            while (alive != 0ull && nk < max_det) {          // wave-uniform
+                const int j = __ffsll((long long)alive) - 1;
                 if (lane == j) {
                     kept[nk * 5] = me.x1; kept[nk * 5 + 1] = me.y1; kept[nk * 5 + 2] = me.x2; kept[nk * 5 + 3] = me.y2;
                     kept[nk * 5 + 4] = me.area;
@@ -372,11 +441,14 @@ __global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const flo
                     for (int e = 0; e < 6; ++e) ob[nk * 6 + e] = raw[e];
                 }
                 ++nk;
+                alive &= ~(1ull << j);
                 alive &= ~__ballot((sup >> j) & 1ull);
             }
             if (lane == 0) nkept_s = nk;
         }
-        __syncthreads();
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 6; ++e) raw[e] = nxt[e];
     }
     if (tid == 0) out_count[b] = nkept_s;
 }
@@ -637,6 +709,8 @@ extern "C" int64_t dsn_nms_workspace_bytes(int32_t bs, int32_t n, int32_t nc, in
     int64_t bytes = (int64_t)bs * cap * 8 + (int64_t)((bs * 4 + 255) / 256) * 256;
     if (cap > RADIX_FROM && cap <= (1ll << FLAT_IDX_BITS) && bs <= 256 && (int64_t)bs * cap < (1ll << 31))
         bytes += (int64_t)bs * cap * 8 + 256 + dsn_nms_radix_temp_bytes(bs, cap);     // second key buffer + sort temp
+    bytes = (bytes + 255) / 256 * 256;
+    bytes += (int64_t)bs * (cap < MAX_NMS ? cap : MAX_NMS) * CAND_W * 4;              // gathered candidate rows
     return bytes;
 }
 
@@ -650,8 +724,8 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
     DSN_CHECK_ARG(max_det > 0 && max_det <= MAX_DET_CAP, "nms: max_det must be in 1..%d", MAX_DET_CAP);
     DSN_CHECK_ARG((int64_t)n * nc < (1ll << 31), "nms: too many candidates");
     multi_label = multi_label && nc > 1;   // general.py:679
-    if (workspace_bytes < dsn_nms_workspace_bytes(bs, n, nc, multi_label))
-        DSN_FAIL(DSN_EWORKSPACE, "nms: workspace too small");
+    const int64_t workspace_bytes_needed = dsn_nms_workspace_bytes(bs, n, nc, multi_label);
+    if (workspace_bytes < workspace_bytes_needed) DSN_FAIL(DSN_EWORKSPACE, "nms: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int64_t cap = key_cap(n, nc, multi_label);
     int32_t* counts = (int32_t*)workspace;
@@ -676,8 +750,14 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
         hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
     }
     DSN_LAUNCH_CHECK("nms sort");
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(GREEDY_WAVES * 64), (size_t)max_det * 5 * sizeof(float), st, pred, n, nc,
-                       sorted, cap, counts, iou_thres, agnostic, max_det, out, out_count, starts);
+    const int64_t cand_cap = cap < MAX_NMS ? cap : MAX_NMS;
+    float* cand = (float*)((char*)workspace + workspace_bytes_needed - (int64_t)bs * cand_cap * CAND_W * 4);
+    const int gb = (int)((cand_cap + 255) / 256);
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(gb < 128 ? gb : 128, bs), dim3(256), 0, st, pred, n, nc, sorted, cap, counts, starts,
+                       cand, cand_cap);
+    DSN_LAUNCH_CHECK("nms gather");
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(GREEDY_WAVES * 64), (size_t)((max_det + 3) / 4 * 4) * 5 * sizeof(float), st, cand, cand_cap,
+                       counts, iou_thres, agnostic, max_det, out, out_count);
     DSN_LAUNCH_CHECK("nms greedy");
     return DSN_OK;
 }

@@ -761,40 +761,41 @@ __device__ __forceinline__ void wgrad_halo_body(const bf16_t* __restrict__ x, co
 // dw (+)= sum_s slab[s].  A 256-thread block owns 64 consecutive packed elements: 16 lanes x float4 cover them, and the 16
 // lane-groups each add every 16th slab with four 16-byte loads in flight (the old one-float-per-lane loop was pure load
 // latency: 64 dependent 256-byte reads per wave).  The 16 partial sums are combined in a fixed order -> deterministic.
+// A block folds RED_W = 256 consecutive outputs (1 KB per slab: whole DRAM bursts; 64 outputs per block ran at 2.6 TB/s): lane q of
+// every wave owns outputs 4q .. 4q+3, the four waves take the slabs k = wave (mod 4), four loads in flight per lane.
+constexpr int RED_W = 256;
 template <bool VEC4>
 __device__ __forceinline__ void wgrad_reduce_group(const float* __restrict__ slabs, float* __restrict__ dw, int64_t n, int S,
                                                    int accumulate, int oihw, int Ci, int Cip, int taps, int64_t base,
-                                                   float (*part)[65]) {
-    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+                                                   float (*part)[RED_W + 4]) {
+    const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t j = base + q * 4;
     f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (VEC4) {
         if (j < n) {
             const float* src = slabs + j;
             int k = grp;
-            for (; k + 48 < S; k += 64) {
+            for (; k + 12 < S; k += 16) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 16) * n);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 32) * n);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 48) * n);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 4) * n);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 8) * n);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 12) * n);
                 s0 += a; s1 += b; s2 += c; s3 += d;
             }
-            for (; k < S; k += 16) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
+            for (; k < S; k += 4) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * n);
         }
     } else {
         for (int e = 0; e < 4; ++e)
             if (j + e < n)
-                for (int k = grp; k < S; k += 16) s0[e] += slabs[(int64_t)k * n + j + e];
+                for (int k = grp; k < S; k += 4) s0[e] += slabs[(int64_t)k * n + j + e];
     }
     const f32x4 sum = (s0 + s1) + (s2 + s3);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) part[grp][q * 4 + e] = sum[e];
+    *reinterpret_cast<f32x4*>(&part[grp][q * 4]) = sum;
     __syncthreads();
-    if (threadIdx.x < 64) {
+    {
         const int t = threadIdx.x;
-        float v = 0.f;
-#pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) v += part[g2][t];
+        const float v0 = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        float v = v0;
         const int64_t jj = base + t;
         if (jj < n) {
             int64_t dst = jj;
@@ -820,8 +821,8 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                            int64_t n, int S, int accumulate, int oihw, int Ci, int Cip,
                                                            int taps) {
-    __shared__ float part[16][65];
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64)
+    __shared__ __attribute__((aligned(16))) float part[4][RED_W + 4];
+    for (int64_t base = (int64_t)blockIdx.x * RED_W; base < n; base += (int64_t)gridDim.x * RED_W)
         wgrad_reduce_group<VEC4>(slabs, dw, n, S, accumulate, oihw, Ci, Cip, taps, base, part);
 }
 
@@ -917,10 +918,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_grouped_kernel(const WJob* 
     else wgrad_halo_body<1>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, b, sA, sB);
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
-    __shared__ float part[16][65];
+    __shared__ __attribute__((aligned(16))) float part[4][RED_W + 4];
     const int l = find_job(jobs, n, blockIdx.x, 2);
     const WJob& j = jobs[l];
-    const int64_t base = (int64_t)(blockIdx.x - j.start[2]) * 64;
+    const int64_t base = (int64_t)(blockIdx.x - j.start[2]) * RED_W;
     const int taps = j.g.KH * j.g.KW;
     if (j.n_out % 4 == 0)    // slabs come 256-byte aligned out of the queue's arena
         wgrad_reduce_group<true>(j.out, j.dw, j.n_out, j.g.S, j.g.accumulate, j.g.oihw, j.g.Ci, j.g.Cip, taps, base, part);
@@ -1084,7 +1085,7 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     job->kind = halo ? 4 : alltaps ? 1 : (t128 ? 3 : 0);
     job->dtype = x->dtype;
     job->blocks[job->kind] = g.tiles_ci * g.tiles_co * ((alltaps || halo) ? 1 : g.KH * g.KW) * g.S;
-    job->blocks[2] = g.S > 1 ? (int32_t)((n_out + 63) / 64) : 0;
+    job->blocks[2] = g.S > 1 ? (int32_t)((n_out + RED_W - 1) / RED_W) : 0;
     job->n_out = n_out;
     job->flops = 2.0 * (double)npix(dy) * g.Co * g.Ci * g.KH * g.KW;
     job->bytes = ((double)npix(x) * g.Ci + (double)npix(dy) * g.Co) * es + (double)n_out * 4;
