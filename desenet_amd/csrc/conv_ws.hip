@@ -1302,6 +1302,220 @@ int launch_3x3_thin(const dsn_tensor* s, const void* w, const float* bias, const
     return DSN_OK;
 }
 
+// ---- the same for the fp32 path: 12 channels per pixel (48 bytes: Focus.fwd pads to the 16-byte vector only) ----------------------
+// A kernel row's three taps are 36 contiguous floats; K per row = 3 steps of 16 floats (64 bytes per lane group of four), the last
+// one reading 12 floats past the run -- the next pixel's finite values (or the zero tail of the stage) against zero weights.  The
+// general kernel spends a whole 32-float slab per tap (18 k-steps, 62 % zeros, MFMA-bound at 264 us for 16 x 320 x 320 pixels).
+// LDS: weights [3 ky x 3 steps][BN rows][64 B] (a fragment read covers one contiguous KB: no swizzle), halo patches as in memory.
+template <int MI, int NI, int WGN, bool STATS, int D>
+__global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* __restrict__ src, const float* __restrict__ wpk,
+                                                                  const float* __restrict__ bias, float* __restrict__ dst,
+                                                                  const BnAcc fin, const WGeom g) {
+    typedef float T;
+    constexpr int WGM = 4 / WGN;
+    constexpr int TW = 16, TH = WGM * MI, BN = WGN * NI * 16;
+    constexpr int PXB = 48;                              // bytes per input pixel
+    constexpr int HWP = TW + 2, HROWB = HWP * PXB;       // halo row: 18 pixels = 864 bytes = 54 pieces
+    constexpr int RP = HROWB / 16;
+    constexpr int NPIECE = (TH + 2) * RP;
+    constexpr int IH = (NPIECE + 255) / 256;
+    constexpr int HSTAGE = IH * 256 * 16;                // (lanes past the patch write zeros: the over-read of the last run lands there)
+    static_assert(HSTAGE >= (TH + 2) * HROWB + 64, "zero tail behind the patch");
+    constexpr int WPIECE = 9 * BN * 4, IW = (WPIECE + 255) / 256;
+    constexpr int WBYTES = IW * 256 * 16;
+    typedef OutVec<T, NI> OV;
+    constexpr int NV = OV::NV, CPV = OV::CPV;
+    constexpr int ST = MI * NV;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                  // [9][BN][64 B]
+    unsigned char* sH = smem + WBYTES;                         // [D][HSTAGE]
+    float* sRed = reinterpret_cast<float*>(sH + D * HSTAGE);   // [WGM][BN][2] (STATS)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tn = blockIdx.x % g.tiles_n, grp = blockIdx.x / g.tiles_n, ngrp = gridDim.x / g.tiles_n;
+    const int n0 = tn * BN;
+    const int per = (g.tiles_m + ngrp - 1) / ngrp;
+    const int t_begin = grp * per, t_end = (t_begin + per < g.tiles_m) ? t_begin + per : g.tiles_m;
+    const int tiles_img = g.tiles_y * g.tiles_x;
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, g.dst_bytes, 0x00020000);
+
+    auto load_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < IW; ++j) {
+            const int q = j * 256 + tid;
+            const int kys = q / (BN * 4), rem = q - kys * (BN * 4);
+            const int row = rem >> 2, pc = rem & 3;
+            const int ky = kys / 3, st = kys - ky * 3;
+            const int pp = st * 4 + pc;                       // 16-byte piece of the 144-byte coefficient run
+            const int ch = n0 + row;
+            const uint32_t off = (q < WPIECE && ch < g.Cd && pp < 9) ? (uint32_t)(((int64_t)ch * 9 + ky * 3) * 12 * 4 + pp * 16) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
+        }
+    };
+    auto load_halo = [&](int c, int stage) {
+        const int tile = t_begin + c;
+        const bool live = tile < t_end;
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < IH; ++j) {
+            const int q = j * 256 + tid;
+            const int hy = q / RP, piece = q - hy * RP;
+            const int px = piece / 3, sub = piece - px * 3;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + px;
+            const bool ok = live && q < NPIECE && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + sub * 4) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
+        }
+    };
+
+    float bv[NV][CPV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = n0 + OV::ch(wn, v, fg);
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) bv[v][k] = (bias && c + k < g.Cd) ? bias[c + k] : 0.f;
+    }
+    StatRegs<NV, CPV, STATS> stat;
+    stat.zero();
+
+    load_w();
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_halo(j, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < CPV; ++k) asm volatile("" : "+v"(bv[v][k]));
+
+    int stage = 0, c = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, ++c) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_halo(c + D - 1, stage == 0 ? D - 1 : stage - 1);
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* hb = sH + stage * HSTAGE;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                u32x4 fx[MI], fw[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)       // pixel (row wm MI + i, column fr): its run starts at halo column fr (= x - 1)
+                    fx[i] = *reinterpret_cast<const u32x4*>(hb + ((wm * MI + i + ky) * HWP + fr) * PXB + h * 64 + fg * 16);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = (wn * NI + j) * 16 + fr;
+                    fw[j] = *reinterpret_cast<const u32x4*>(sW + ((ky * 3 + h) * BN + r) * 64 + fg * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], fw[j], fx[i]);
+            }
+        }
+        const int n = tile / tiles_img, trem = tile - n * tiles_img;
+        const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int y = y0 + wm * MI + i, x = x0 + fr;
+            const int64_t m = ((int64_t)n * g.H + y) * g.W + x;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cc = n0 + OV::ch(wn, v, fg);
+                float o[CPV];
+                OV::get(acc[i], v, o);
+                const bool ok = y < g.H && x < g.W && cc < g.Cd;
+                stat.add(v, o, ok);
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) o[k] += bv[v][k];
+                if (g.act == DSN_ACT_SILU) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] *= sigmoidf_(o[k]);
+                } else if (g.act == DSN_ACT_SIGMOID) {
+#pragma unroll
+                    for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
+                }
+                const uint32_t off = ok ? (uint32_t)(m * g.dld + cc) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
+            }
+        }
+        wait_vm<(D - 2) * IH, ST>(c + 1 < D - 1 ? c + 1 : D - 1);
+        stage = stage + 1 == D ? 0 : stage + 1;
+    }
+
+    if constexpr (STATS) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < CPV; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    stat.s[v][k] += __shfl_xor(stat.s[v][k], o);
+                    stat.ss[v][k] += __shfl_xor(stat.ss[v][k], o);
+                }
+            }
+        __syncthreads();
+        if (fr == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int k = 0; k < CPV; ++k) {
+                    const int cl = OV::ch(wn, v, fg) + k;
+                    sRed[(wm * BN + cl) * 2] = stat.s[v][k];
+                    sRed[(wm * BN + cl) * 2 + 1] = stat.ss[v][k];
+                }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cd) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) {
+                t0 += sRed[(w * BN + tid) * 2];
+                t1 += sRed[(w * BN + tid) * 2 + 1];
+            }
+            bn_acc_add(fin, blockIdx.x, n0 + tid, t0, t1);
+        }
+    }
+}
+
+template <bool STATS>
+int launch_3x3_thin_f32(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, WGeom g, const BnAcc& fin, hipStream_t st) {
+    constexpr int MI = 2, NI = 2, WGN = 1, WGM = 4, D = 4;
+    constexpr int TH = WGM * MI, TW = 16, BM = TH * TW, BN = WGN * NI * 16;
+    constexpr int HSTAGE = (((TH + 2) * 18 * 3 + 255) / 256) * 256 * 16;
+    constexpr int WBYTES = ((9 * BN * 4 + 255) / 256) * 256 * 16;
+    g.tiles_y = (g.H + TH - 1) / TH;
+    g.tiles_x = (g.W + TW - 1) / TW;
+    g.tiles_m = g.N * g.tiles_y * g.tiles_x;
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    const size_t lds = (size_t)WBYTES + (size_t)D * HSTAGE + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
+    const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 4);
+    auto kern = conv3x3_thin_f32_ws_kernel<MI, NI, WGN, STATS, D>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr = true;
+    }
+    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd) + 9.0 * g.Cs * g.Cd;
+    const ProfConv pc("conv3x3_thin_f32_ws_kernel", false, BM, BN, false, 3, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * 4, st);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const float*)s->ptr, (const float*)w, bias, (float*)d->ptr, fin, g);
+    DSN_LAUNCH_CHECK("conv3x3 (thin fp32 input, weights-stationary)");
+    return DSN_OK;
+}
+
 }  // namespace
 
 // selection mode of the two kernels (environment DSN_WS / DSN_WS3 at load time; dsn_ws_mode() at run time: tests, A/B runs)
@@ -1415,6 +1629,21 @@ int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
             return launch_3x3_thin<true>(s, w, bias, d, t, f, (hipStream_t)stream);
         }
         return launch_3x3_thin<false>(s, w, bias, d, t, f, (hipStream_t)stream);
+    }
+    if (s->dtype == DSN_F32 && s->c == 12 && s->ldc == 12 && p->dil == 1 && !is_dgrad && !extras) {
+        // the fp32 Focus shape: 12-channel pixels, a kernel row = 36 contiguous floats
+        WGeom t{};
+        t.N = s->n; t.H = s->h; t.W = s->w; t.Cs = 12; t.Cd = d->c; t.d = 1; t.act = p->act;
+        t.sld = s->ldc; t.dld = d->ldc;
+        t.src_bytes = (uint32_t)sb; t.w_bytes = (uint32_t)wb; t.dst_bytes = (uint32_t)db;
+        t.wrow = 9 * 12;
+        BnAcc f{};
+        if (finp) f = *finp;
+        if (f.acc) {
+            if (bias || p->act != DSN_ACT_NONE) return 1;
+            return launch_3x3_thin_f32<true>(s, w, bias, d, t, f, (hipStream_t)stream);
+        }
+        return launch_3x3_thin_f32<false>(s, w, bias, d, t, f, (hipStream_t)stream);
     }
     WGeom g{};
     g.N = s->n; g.H = s->h; g.W = s->w; g.Cs = s->c; g.Cd = d->c; g.d = p->dil; g.flip = is_dgrad ? 1 : 0;

@@ -205,3 +205,32 @@ def test_conv3x3_thin_input_focus_kernel(ops, case, mode):
         assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 2e-2, "batch mean")
         assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
         assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
+
+
+@pytest.mark.parametrize("case", [(16, 12, 320, 320, 32), (2, 12, 70, 67, 24), (1, 12, 48, 64, 48)])
+@pytest.mark.parametrize("mode", ["act", "stats"])
+def test_conv3x3_thin_fp32_focus_kernel(ops, case, mode):
+    """The fp32 Focus shape: 12 channels per pixel (48 bytes), 3x3 / stride 1 -- a kernel row's three taps as one run of 36 floats
+    (conv3x3_thin_f32_ws_kernel: 9 k-steps instead of 18), fused bias + SiLU epilogue and BatchNorm sums."""
+    n, ci, h, w, co = case
+    dtype = torch.float32
+    x = rnd((n, ci, h, w), 81)
+    wt, b = rnd((co, ci, 3, 3), 82, -0.2, 0.2), rnd((co,), 83)
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    y = ops.new_act(n, co, h, w, dtype, "cuda")
+    if mode == "act":
+        ref = F.silu(F.conv2d(x, wt, b, 1, 1))
+        _ran(ops, lambda: ops.conv2d_fwd(xd, wp, b.cuda(), None, y, ops.conv_params(3, act=ops.ACT_SILU)), "conv3x3_thin_f32_ws_kernel")
+        assert_close(y.float().cpu(), ref, TOL[dtype], f"thin fp32 3x3 {case}")
+    else:
+        g_, b_ = rnd((co,), 84, 0.5, 1.5), rnd((co,), 85, -0.2, 0.2)
+        yref = F.conv2d(x, wt, None, 1, 1)
+        zref = F.silu(F.batch_norm(yref, None, None, g_, b_, True, 0.03, 1e-3))
+        z = ops.new_act(n, co, h, w, dtype, "cuda")
+        rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+        stats = _ran(ops, lambda: ops.conv2d_fwd_bnstats(xd, wp, y, ops.conv_params(3), g_.cuda(), b_.cuda(), rm, rv, 0.03, 1e-3,
+                                                         ops.ACT_SILU, None, z), "conv3x3_thin_f32_ws_kernel")
+        assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 1e-3, "batch mean")
+        assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
+        assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
