@@ -1268,7 +1268,11 @@ extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, v
     const int V = x->dtype == DSN_F32 ? 4 : 8;
     const size_t lds = (size_t)HW * V * 3 * sizeof(float);
     // cascade form: outputs k0, 2 k0 - 1, 3 k0 - 2 in this order (SPP's 5 / 9 / 13)
-    bool cascade = vec && (size_t)HW * V * 4 * sizeof(float) <= 64 * 1024;
+    // (whole map x channel vector x two (value, index) planes in LDS: 16-byte vectors up to 32 x 32 maps, 8-byte bf16 vectors up
+    //  to 48 x 48 -- config 5's SPP sits at 40 x 40, where the one-thread-per-output kernel below took 3 x 112 us)
+    const size_t l_full = (size_t)HW * V * 4 * sizeof(float), l_half = l_full / 2;
+    const bool narrow = x->dtype == DSN_BF16 && l_full > 64 * 1024 && l_half <= 150 * 1024 && x->c % 4 == 0;
+    bool cascade = vec && (l_full <= 64 * 1024 || narrow);
     for (int i = 0; i < n_out; ++i) cascade = cascade && ks[i] == (i + 1) * (ks[0] - 1) + 1;
     static const bool no_cascade = getenv("DSN_MAXPOOL_CASCADE") && atoi(getenv("DSN_MAXPOOL_CASCADE")) == 0;
     if (cascade && !no_cascade) {
@@ -1277,14 +1281,22 @@ extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, v
         for (int i = 0; i < n_out; ++i) {
             out.y[i] = ys[i].ptr; out.ld[i] = ys[i].ldc; out.idx[i] = idxs ? (int32_t*)idxs[i] : nullptr; out.k[i] = ks[i];
         }
-        const dim3 grid(x->n * (x->c / V));
-        const size_t l4 = (size_t)HW * V * 4 * sizeof(float);
-        if (x->dtype == DSN_F32)
-            hipLaunchKernelGGL((maxpool_cascade_kernel<float, 4, 512>), grid, dim3(512), l4, st, (const float*)x->ptr, x->ldc, out,
-                               x->h, x->w, x->c, ks[0] / 2);
-        else
-            hipLaunchKernelGGL((maxpool_cascade_kernel<bf16_t, 8, 1024>), grid, dim3(1024), l4, st, (const bf16_t*)x->ptr, x->ldc,
-                               out, x->h, x->w, x->c, ks[0] / 2);
+        if (x->dtype == DSN_F32) {
+            hipLaunchKernelGGL((maxpool_cascade_kernel<float, 4, 512>), dim3(x->n * (x->c / 4)), dim3(512), l_full, st,
+                               (const float*)x->ptr, x->ldc, out, x->h, x->w, x->c, ks[0] / 2);
+        } else if (narrow) {
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)maxpool_cascade_kernel<bf16_t, 4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          150 * 1024);
+                attr = true;
+            }
+            hipLaunchKernelGGL((maxpool_cascade_kernel<bf16_t, 4, 1024>), dim3(x->n * (x->c / 4)), dim3(1024), l_half, st,
+                               (const bf16_t*)x->ptr, x->ldc, out, x->h, x->w, x->c, ks[0] / 2);
+        } else {
+            hipLaunchKernelGGL((maxpool_cascade_kernel<bf16_t, 8, 1024>), dim3(x->n * (x->c / 8)), dim3(1024), l_full, st,
+                               (const bf16_t*)x->ptr, x->ldc, out, x->h, x->w, x->c, ks[0] / 2);
+        }
     } else if (vec && lds <= 60 * 1024) {
         MaxFwd out{};
         out.n = n_out;

@@ -20,7 +20,7 @@ def ops():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(8, 256, 20, 20), (2, 16, 13, 17)])
+@pytest.mark.parametrize("shape", [(8, 256, 20, 20), (2, 16, 13, 17), (2, 24, 40, 40)])
 @pytest.mark.parametrize("levels", [0, 5])
 def test_maxpool_cascade_values_and_first_max_indices(ops, shape, dtype, levels):
     """5 / 9 / 13 pools as pool_5 applied 1x / 2x / 3x over (value, flat index) pairs: outputs equal ATen's bit for bit and the
