@@ -11,7 +11,11 @@ plots, CLI helpers) stays the reference's.  After it,
     non_max_suppression, ComputeLoss, SegmentationLosses, ModelEMA                    -> the HIP-backed mirrors
 
 Call it before the scripts import their model code, e.g. `python -c "import desenet_amd.shim as s; s.install(); import
-runpy; runpy.run_module('scripts.train', run_name='__main__')"` from the reference checkout."""
+runpy; runpy.run_module('scripts.train', run_name='__main__')"` from the reference checkout.
+
+Limitation: scripts/train.py:427-438 pickles `deepcopy(model).half()` itself; under the shim those objects are the mirrored
+classes, so the last.pt / best.pt it writes need desenet_amd to be read back (a plain reference checkout cannot).  For checkpoints
+that travel to the plain reference use desenet_amd.checkpoint.save_reference_checkpoint ("checkpoints")."""
 from __future__ import annotations
 
 import importlib
