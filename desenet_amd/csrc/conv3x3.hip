@@ -765,6 +765,14 @@ int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, 
         return launch_halo<float, 8, 8, 2, 2, 2, 2, 7>(s, w, bias, r, d, g, fin, st, la);
     }
     if (big && g.d == 1) return launch_halo<bf16_t, 8, 16, 4, 4, 2, 2, 6>(s, w, bias, r, d, g, fin, st, la);
+    // 8 x 16 x 64 (round 3): 16 MFMAs per wave between two barriers instead of 8, half as many weight fetches per pixel, still two
+    // blocks per CU.  Per layer (config 5, HIP events) 17-18 % faster than 8 x 8 x 64: 128 -> 128 @160 dgrad 78 -> 64 us, 256 -> 256
+    // @80 64 -> 52 / 59 -> 50 us.  Under replay the config-5 STEP gains only 0.3-0.6 % (rocprofv3: these launches -0.45 ms, every
+    // other kernel of the step 2-4 % slower -- at ~1150 W the part runs at 2.31 GHz, not 2.4: the step is energy-bound); config 3 flat.
+    // DSN_HALO_MID_MIN=0 turns it off, larger values set a block-count threshold.
+    static const int mid_min = [] { const char* e = getenv("DSN_HALO_MID_MIN"); return e ? atoi(e) : 1; }();
+    if (mid_min > 0 && mode != 3 && g.d == 1 && d->c >= 64 && s->w % 16 == 0 && s->h % 8 == 0 && (px / 128) * ((d->c + 63) / 64) >= mid_min)
+        return launch_halo<bf16_t, 8, 16, 4, 2, 2, 2, 6>(s, w, bias, r, d, g, fin, st, la);
     if (g.d == 1) return launch_halo<bf16_t, 8, 8, 2, 2, 2, 2, 4>(s, w, bias, r, d, g, fin, st, la);
     return launch_halo<bf16_t, 8, 8, 2, 2, 2, 2, 7>(s, w, bias, r, d, g, fin, st, la);
 }
