@@ -35,6 +35,11 @@ struct WGeom {
     int32_t tiles_y, tiles_x;
     int32_t HW, NP;           // 3x3: halo columns / pixels
     int32_t wrow;             // elements per weight row (taps * Cs)
+    // gather forms of the 1x1 kernel (G > 0): rows are pixels of the (H, W) grid above, K = taps x gCt channels fetched from
+    // source pixel (y * gS + dy, x * gS + dx) of a (gHs, gWs) map; Cs = taps * gCt.  d2s_c > 0: GEMM column (cls, ci) of row
+    // (n, y, x) is stored at pixel (n, 2y + cls / 2, 2x + cls % 2), channel ci, of a (Hout, Wout) map (stride-2 data gradient).
+    int32_t gS, gHs, gWs, gCt;
+    int32_t d2s_c, Hout, Wout;
 };
 
 template <typename T> struct WMma;
@@ -230,6 +235,24 @@ template <typename T, int MI, int NV, int CPV> struct WsXState {
                 BUF_LOAD_B128(x.y1[i][v], o_y1, r_y1);
             }
     }
+    // the same with a destination pixel per (tile row, vector) and the vectors' channels given (depth-to-space store)
+    __device__ __forceinline__ void issue_pv(WsXRegs<T, MI, NV, CPV>& x, const WsX& ex, const int64_t (&pix)[MI][NV], const int (&cv)[NV],
+                                             int64_t dld) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const bool ok = pix[i][v] >= 0;
+                const uint32_t o_res = ok ? (uint32_t)(pix[i][v] * ex.rld + cv[v]) * (uint32_t)sizeof(T) : OOB;
+                const uint32_t o_old = ok ? (uint32_t)(pix[i][v] * dld + cv[v]) * (uint32_t)sizeof(T) : OOB;
+                const uint32_t o_y0 = (ok && segv[v] == 0) ? (uint32_t)(pix[i][v] * ex.seg[0].yld + (cv[v] - ex.seg[0].c0)) * (uint32_t)sizeof(T) : OOB;
+                const uint32_t o_y1 = (ok && segv[v] == 1) ? (uint32_t)(pix[i][v] * ex.seg[1].yld + (cv[v] - ex.seg[1].c0)) * (uint32_t)sizeof(T) : OOB;
+                BUF_LOAD_B128(x.res[i][v], o_res, r_res);
+                BUF_LOAD_B128(x.old[i][v], o_old, r_old);
+                BUF_LOAD_B128(x.y0[i][v], o_y0, r_y0);
+                BUF_LOAD_B128(x.y1[i][v], o_y1, r_y1);
+            }
+    }
     // o: accumulator values of (tile row i, vector v) -> + residual + old; returns the packed stored value and adds the BN sums
     __device__ __forceinline__ u32x4 apply(const WsXRegs<T, MI, NV, CPV>& x, int i, int v, float (&o)[CPV], bool ok) {
         T rv[CPV], ov[CPV], yv[CPV];
@@ -262,7 +285,13 @@ template <typename T, int MI, int NV, int CPV> struct WsXState {
 // 1x1 / stride 1.  Block tile BM pixels x BN channels, K = NS slabs of 128 bytes (any channel count that is a multiple of the
 // 16-byte vector: lanes past the last channel fetch nothing and leave zeros).  LDS: [weights NS x BN rows][2 stages x NS x BM rows].
 // ================================================================================================================================
-template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS, int D, bool EX>
+// G: 0 = 1x1 / stride 1.  Gather forms (round 3) -- the same GEMM with the K axis assembled from several source pixels per row:
+//    1 = 3x3 / stride 2 / pad 1 forward (K = 9 taps x gCt channels, tap (ky, kx) of output (y, x) at source (2y + ky - 1, 2x + kx - 1));
+//    2 = its data gradient as the 2x2 / stride-1 convolution over dy of igemm.hip (K = 4 taps x gCt, tap (ty, tx) at (y + ty, x + tx),
+//        4 * Ci columns, depth-to-space store).  A 16-byte slot never straddles a tap (gCt % 8 == 0); slots past the last tap, and
+//        taps that fall outside the map, are out-of-range lanes of the DMA = zeros.  The implicit-GEMM kernel ran these layers at
+//        145-220 TFLOP/s with 18 VALU instructions per MFMA and the weights re-fetched per 64-pixel block.
+template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool STATS, int D, bool EX, int G = 0>
 __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                          const float* __restrict__ bias, T* __restrict__ dst, const BnAcc fin,
                                                          const WGeom g, const WsX ex) {
@@ -281,7 +310,9 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
     static_assert(D >= 2 && D <= 4, "ring of 2 .. 4 pixel-tile stages");
     constexpr int LPT = NS * AR;                      // LDS-DMA instructions per wave and pixel tile
     unsigned char* sA = smem + NS * BN * ROWB;                 // [D][NS][BM][128 B]
-    float* sRed = reinterpret_cast<float*>(sA + D * NS * BM * ROWB);     // [WGM][BN][2] (STATS)
+    // [WGM][BN][2] fold buffer of the sums (STATS / extras): behind the ring; the gather forms reuse the weight area (dead after the
+    // last tile, and no DMA targets it) so that weights + ring may fill the LDS exactly
+    float* sRed = G > 0 ? reinterpret_cast<float*>(sW) : reinterpret_cast<float*>(sA + D * NS * BM * ROWB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -297,7 +328,20 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
     // ---- DMA plan: pass i of a tile covers rows 32 i + (tid >> 3); the lane that owns physical slot tid & 7 fetches logical slot ls
     const int r0 = tid >> 3;
     const int ls = (tid & 7) ^ ((r0 >> 1) & 7);
-    const bool kin[4] = {ls * VEC < g.Cs, KC + ls * VEC < g.Cs, 2 * KC + ls * VEC < g.Cs, 3 * KC + ls * VEC < g.Cs};
+    bool kin[NS];
+    int gdy[G > 0 ? NS : 1], gdx[G > 0 ? NS : 1];
+    uint32_t gco[G > 0 ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = s * KC + ls * VEC;                 // first K index of the slot this lane fetches in slab s
+        kin[s] = e < g.Cs;
+        if constexpr (G > 0) {
+            const int tap = e / g.gCt;
+            gco[s] = (uint32_t)(e - tap * g.gCt) * (uint32_t)sizeof(T);
+            if constexpr (G == 1) { const int ky = tap / 3; gdy[s] = ky - 1; gdx[s] = tap - ky * 3 - 1; }
+            else { gdy[s] = tap >> 1; gdx[s] = tap & 1; }
+        }
+    }
     auto load_w = [&]() {
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
@@ -314,11 +358,25 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int64_t m = (int64_t)tm * BM + 32 * i + r0;
-            const uint32_t base = (tm < g.tiles_m && m < M) ? (uint32_t)(m * g.sld + ls * VEC) * (uint32_t)sizeof(T) : OOB;
+            const bool live = tm < g.tiles_m && m < M;
+            if constexpr (G == 0) {
+                const uint32_t base = live ? (uint32_t)(m * g.sld + ls * VEC) * (uint32_t)sizeof(T) : OOB;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint32_t off = (base == OOB || !kin[s]) ? OOB : base + (uint32_t)(s * ROWB);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t off = (base == OOB || !kin[s]) ? OOB : base + (uint32_t)(s * ROWB);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                }
+            } else {
+                const int mi = live ? (int)m : 0;
+                const int x = mi % g.W, t = mi / g.W;
+                const int y = t % g.H, n = t / g.H;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int iy = y * g.gS + gdy[s], ix = x * g.gS + gdx[s];
+                    const bool ok = live && kin[s] && (unsigned)iy < (unsigned)g.gHs && (unsigned)ix < (unsigned)g.gWs;
+                    const uint32_t off = ok ? (uint32_t)(((int64_t)(n * g.gHs + iy) * g.gWs + ix) * g.sld) * (uint32_t)sizeof(T) + gco[s] : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                }
             }
         }
     };
@@ -338,17 +396,44 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
     XS xs;
     XR xa, xb;
     int cabs[NV];
+    int ccls[G == 2 ? NV : 1];                           // depth-to-space: sub-pixel class of the lane's vector v; cabs = its channel
 #pragma unroll
-    for (int v = 0; v < NV; ++v) cabs[v] = n0 + OV::ch(wn, v, fg);
-    if constexpr (EX) xs.init(ex, dst, g.dst_bytes, cabs, g.Cd);
-    auto issue_x = [&](int tm, XR& x) {
-        int64_t pix[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int64_t m = (int64_t)tm * BM + (wm * MI + i) * 16 + fr;
-            pix[i] = (tm < g.tiles_m && m < M) ? m : -1;
+    for (int v = 0; v < NV; ++v) {
+        cabs[v] = n0 + OV::ch(wn, v, fg);
+        if constexpr (G == 2) {
+            const int c = cabs[v];
+            ccls[v] = c < g.Cd ? c / g.d2s_c : -1;
+            cabs[v] = c < g.Cd ? c - ccls[v] * g.d2s_c : 0;
         }
-        xs.issue(x, ex, pix, cabs, g.dld, g.Cd);
+    }
+    if constexpr (EX) xs.init(ex, dst, g.dst_bytes, cabs, G == 2 ? g.d2s_c : g.Cd);
+    // destination pixel of GEMM row m for vector v (-1: not stored)
+    auto d2s_pixel = [&](int64_t m, bool live, int v) -> int64_t {
+        const int mi = live ? (int)m : 0;
+        const int x = mi % g.W, t = mi / g.W;
+        const int y = t % g.H, n = t / g.H;
+        const int oy = 2 * y + (ccls[G == 2 ? v : 0] >> 1), ox = 2 * x + (ccls[G == 2 ? v : 0] & 1);
+        return (live && ccls[G == 2 ? v : 0] >= 0 && oy < g.Hout && ox < g.Wout) ? ((int64_t)n * g.Hout + oy) * g.Wout + ox : -1;
+    };
+    auto issue_x = [&](int tm, XR& x) {
+        if constexpr (G == 2) {
+            int64_t pixv[MI][NV];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int64_t m = (int64_t)tm * BM + (wm * MI + i) * 16 + fr;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) pixv[i][v] = d2s_pixel(m, tm < g.tiles_m && m < M, v);
+            }
+            xs.issue_pv(x, ex, pixv, cabs, g.dld);
+        } else {
+            int64_t pix[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int64_t m = (int64_t)tm * BM + (wm * MI + i) * 16 + fr;
+                pix[i] = (tm < g.tiles_m && m < M) ? m : -1;
+            }
+            xs.issue(x, ex, pix, cabs, g.dld, g.Cd);
+        }
     };
 
     // LDS byte offsets of the fragment reads (slab 0): pixel row / weight row of MFMA index fr, logical slot 4 h + fg swizzled by row
@@ -451,8 +536,15 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                 const int c = n0 + OV::ch(wn, v, fg);
                 float o[CPV];
                 OV::get(acc[i], v, o);
-                const bool ok = m < M && c < g.Cd;
-                const uint32_t off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
+                bool ok = m < M && c < g.Cd;
+                uint32_t off;
+                if constexpr (G == 2) {
+                    const int64_t dp = d2s_pixel(m, ok, v);
+                    ok = dp >= 0;
+                    off = ok ? (uint32_t)(dp * g.dld + cabs[v]) * (uint32_t)sizeof(T) : OOB;
+                } else {
+                    off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
+                }
                 if constexpr (EX) {
                     __builtin_amdgcn_raw_buffer_store_b128(xs.apply(cur, i, v, o, ok), drsrc, off, 0, 0);
                 } else {
@@ -524,7 +616,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                     t0 += sRed[(w * BN + tid) * 2];
                     t1 += sRed[(w * BN + tid) * 2 + 1];
                 }
-                const int ch = n0 + tid;
+                const int ch = G == 2 ? (n0 + tid) % g.d2s_c : n0 + tid;      // (depth-to-space: the four sub-pixel columns of a channel)
                 for (int sg = 0; sg < ex.nseg; ++sg)
                     if (ch >= ex.seg[sg].c0 && ch < ex.seg[sg].c1)
                         bn_acc_add(BnAcc{ex.seg[sg].acc, ex.seg[sg].acc_c, 0.0}, blockIdx.x, ex.seg[sg].ch0 + ch - ex.seg[sg].c0, t0, t1);
@@ -641,6 +733,42 @@ int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, con
         case 2: return launch_1x1_ws_ns<T, 2, 2, 4, 1, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);     // 128 x 32
         default: return launch_1x1_ws_ns<T, 2, 2, 2, 2, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ns, ex);    // 64 x 64
     }
+}
+
+// ---- gather forms (G = 1: 3x3 / stride 2 forward, G = 2: its data gradient with depth-to-space store) ---------------------------
+// MODE as above.  The ring depth is what fits 160 KB next to the resident weights (the extras variant needs exactly three stages).
+template <typename T, int MI, int NI, int WGM, int WGN, int NS, int MODE, int G>
+int launch_gather_ws(const dsn_tensor* s, const void* w, const dsn_tensor* d, WGeom g, const BnAcc& fin, hipStream_t st, const WsX& ex) {
+    constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    constexpr bool STATS = MODE == 1, EX = MODE == 2;
+    constexpr int TILEB = NS * BM * ROWB, WB1 = NS * BN * ROWB, RED = 0;      // (the fold buffer reuses the weight area)
+    static_assert(WGM * BN * 2 * 4 <= WB1, "fold buffer inside the weight area");
+    // two blocks per CU with a 2-stage ring where that fits, else the deepest ring one block can have
+    constexpr int DFIT = (160 * 1024 - WB1) / TILEB;
+    constexpr int D = EX ? 3 : (WB1 + 2 * TILEB <= 80 * 1024 ? 2 : (DFIT >= 3 ? 3 : 2));
+    static_assert(WB1 + D * TILEB + RED <= 160 * 1024, "weights + ring exceed the LDS of a CU");
+    const int64_t M = (int64_t)g.N * g.H * g.W;
+    g.tiles_m = (int)((M + BM - 1) / BM);
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    const size_t lds = (size_t)WB1 + (size_t)D * TILEB + RED;
+    const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 4);
+    auto kern = conv1x1_ws_kernel<T, MI, NI, WGM, WGN, NS, STATS, D, EX, G>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    double xch = 0.0;
+    for (int i = 0; i < ex.nseg; ++i) xch += (double)(ex.seg[i].c1 - ex.seg[i].c0) / (G == 2 ? g.d2s_c : g.Cd);
+    const double src_el = (double)g.N * g.gHs * g.gWs * g.gCt;
+    const double elems = src_el + (double)M * g.Cd * (1.0 + xch) + (double)g.Cs * g.Cd;
+    // flops as the implicit-GEMM launch counts them (the 2x2 form of the data gradient: 16 / 9 of the convolution's)
+    const ProfConv pc("conv1x1_ws_kernel", sizeof(T) == 2, BM, BN, G == 2, G == 1 ? 3 : 2, 2, 1, g.gCt, G == 1 ? g.Cd : g.d2s_c,
+                      g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, (const float*)nullptr, (T*)d->ptr, fin, g, ex);
+    DSN_LAUNCH_CHECK("conv (weights-stationary, gathered K)");
+    return DSN_OK;
 }
 
 // ================================================================================================================================
@@ -1668,4 +1796,70 @@ int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
     }
     if (s->dtype == DSN_F32) return launch_3x3_ws_cfg<float, 0>(s, w, bias, d, g, fin, st, ns, ex);
     return launch_3x3_ws_cfg<bf16_t, 0>(s, w, bias, d, g, fin, st, ns, ex);
+}
+
+// 3x3 / stride 2 / pad 1 forward through the gather form (bf16; K = 9 * Ci <= 9 slabs).  Returns 1 when the layer is not taken.
+int dsn_conv3x3s2_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                         const dsn_conv_params* p, const BnAcc* finp, void* stream) {
+    static const int mode = [] { const char* e = getenv("DSN_WS_S2"); return e ? atoi(e) : 1; }();
+    if (!mode || !g_ws_mode[0]) return 1;
+    if (p->kh != 3 || p->kw != 3 || p->stride != 2 || p->pad != 1 || p->dil != 1 || p->accumulate) return 1;
+    if (s->dtype != DSN_BF16 || d->dtype != DSN_BF16 || r || bias || p->act != DSN_ACT_NONE) return 1;      // (training forward: conv + BatchNorm sums)
+    if (s->n != d->n || d->h != (s->h - 1) / 2 + 1 || d->w != (s->w - 1) / 2 + 1) return 1;
+    if (s->c % 8 != 0 || d->c % 8 != 0 || s->ldc % 8 != 0 || d->ldc % 8 != 0) return 1;
+    if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
+    const int K = 9 * s->c, ns = (K + 63) / 64;
+    const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * 2, wb = (int64_t)d->c * K * 2, db = ((npix(d) - 1) * d->ldc + d->c) * 2;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || db >= (1ll << 32) - 64 || npix(d) < 16384) return 1;
+    WGeom g{};
+    g.N = d->n; g.H = d->h; g.W = d->w; g.Cs = K; g.Cd = d->c; g.act = DSN_ACT_NONE;
+    g.sld = s->ldc; g.dld = d->ldc;
+    g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb; g.dst_bytes = (uint32_t)db;
+    g.wrow = K; g.gS = 2; g.gHs = s->h; g.gWs = s->w; g.gCt = s->c;
+    BnAcc fin{};
+    if (finp) fin = *finp;
+    hipStream_t st = (hipStream_t)stream;
+    const WsX ex{};
+    if (ns == 5) {             // 32 -> 64 @ 320 -> 160: 32 x 64 tiles, 40 KB of weights + 2 x 20 KB: two blocks per CU
+        if (fin.acc) return launch_gather_ws<bf16_t, 1, 2, 2, 2, 5, 1, 1>(s, w, d, g, fin, st, ex);
+        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 5, 0, 1>(s, w, d, g, fin, st, ex);
+    }
+    if (ns == 9) {             // 64 -> 128 @ 160 -> 80: 32 x 64 tiles, 72 KB of weights per 64 output channels
+        if (fin.acc) return launch_gather_ws<bf16_t, 1, 2, 2, 2, 9, 1, 1>(s, w, d, g, fin, st, ex);
+        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 9, 0, 1>(s, w, d, g, fin, st, ex);
+    }
+    return 1;
+}
+
+// its data gradient (igemm.hip: 2x2 / stride-1 convolution over dy, [4 Ci][2][2][Co] weights, depth-to-space store), with the
+// BatchNorm backward sums of the block(s) whose dz it completes.
+int dsn_dgrad_s2_ws_try(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p, const dsn_bnred* br,
+                        void* stream) {
+    static const int mode = [] { const char* e = getenv("DSN_WS_S2"); return e ? atoi(e) : 1; }();
+    if (!mode || !g_ws_mode[0]) return 1;
+    if (dy->dtype != DSN_BF16 || dx->dtype != DSN_BF16) return 1;
+    if (dy->c % 8 != 0 || dx->c % 8 != 0 || dy->ldc % 8 != 0 || dx->ldc % 8 != 0) return 1;
+    if (((uintptr_t)dy->ptr | (uintptr_t)dx->ptr | (uintptr_t)w_s2) % 16 != 0) return 1;
+    const int K = 4 * dy->c, ns = (K + 63) / 64;
+    if (K % 64 != 0) return 1;
+    const int64_t sb = ((npix(dy) - 1) * dy->ldc + dy->c) * 2, wb = (int64_t)4 * dx->c * K * 2, db = ((npix(dx) - 1) * dx->ldc + dx->c) * 2;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || db >= (1ll << 32) - 64 || npix(dy) < 16384) return 1;
+    WGeom g{};
+    g.N = dy->n; g.H = dy->h; g.W = dy->w; g.Cs = K; g.Cd = 4 * dx->c; g.act = DSN_ACT_NONE;
+    g.sld = dy->ldc; g.dld = dx->ldc;
+    g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb; g.dst_bytes = (uint32_t)db;
+    g.wrow = K; g.gS = 1; g.gHs = dy->h; g.gWs = dy->w; g.gCt = dy->c;
+    g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
+    WsX ex{};
+    if (!ws_extras(ex, nullptr, dx, p, br, 2)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    static const int cfg = [] { const char* e = getenv("DSN_WS_S2_CFG"); return e ? atoi(e) : 0; }();     // tuning knob
+    if (ns == 4) {             // 64 -> (4 x 32) @160
+        if (cfg == 1) return launch_gather_ws<bf16_t, 1, 4, 2, 2, 4, 2, 2>(dy, w_s2, dx, g, BnAcc{}, st, ex);   // 32 x 128: dy fetched once
+        if (cfg == 2) return launch_gather_ws<bf16_t, 2, 2, 2, 2, 4, 2, 2>(dy, w_s2, dx, g, BnAcc{}, st, ex);   // 64 x 64
+        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 4, 2, 2>(dy, w_s2, dx, g, BnAcc{}, st, ex);                 // 32 x 64, two blocks per CU
+    }
+    if (ns == 8 && cfg != 3)   // 128 -> (4 x 64) @80: 64 KB of weights + 3 x 32 KB = the whole LDS
+        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 8, 2, 2>(dy, w_s2, dx, g, BnAcc{}, st, ex);
+    return 1;
 }

@@ -744,7 +744,9 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     // tile choice: wide-N tiles for wide layers, tall-skinny for narrow ones; small M prefers smaller tiles so the
     // grid still covers the 256 CUs.
     static const int force = [] { const char* e = getenv("DSN_IGEMM_CFG"); return e ? atoi(e) : -1; }();    // tuning knob
-    switch (force) {
+    static const int force_s2 = [] { const char* e = getenv("DSN_IGEMM_S2_CFG"); return e ? atoi(e) : -1; }();    // tuning knob: stride-2 layers only
+    const bool is_s2 = g.d2s_c > 0 || (g.a == 2 && g.KH == 3);
+    switch (is_s2 && force_s2 >= 0 ? force_s2 : force) {
         case 0: return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
         case 1: return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
         case 2: return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
@@ -807,6 +809,8 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
         rc = dsn_conv1x1_ws_try(x, w, bias, residual, y, p, 0, finp, stream);       // 1x1, weights-stationary persistent blocks
         if (rc != 1) return rc;
         rc = dsn_conv3x3_ws_try(x, w, bias, residual, y, p, 0, finp, stream);       // 3x3 / stride 1, the same
+        if (rc != 1) return rc;
+        rc = dsn_conv3x3s2_ws_try(x, w, bias, residual, y, p, finp, stream);        // 3x3 / stride 2 stems: gathered K
         if (rc != 1) return rc;
         rc = dsn_conv3x3_halo_try(x, w, bias, residual, y, p, 0, finp, stream);
         if (rc != 1) return rc;
@@ -949,6 +953,8 @@ static int conv_dgrad_s2_impl(const dsn_tensor* dy, const void* w_s2, const dsn_
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
     g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
+    rc = dsn_dgrad_s2_ws_try(dy, w_s2, dx, p, br, stream);                          // the large stems: weights-stationary, gathered K
+    if (rc != 1) return rc;
     if (dy->dtype == DSN_F32)
         return launch<float>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
     return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);

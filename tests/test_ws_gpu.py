@@ -234,3 +234,113 @@ def test_conv3x3_thin_fp32_focus_kernel(ops, case, mode):
         assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 1e-3, "batch mean")
         assert_close(y.float().cpu(), yref, TOL[dtype], "conv output")
         assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
+
+
+def _layers_of(ops, fn):
+    ops.profile_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        _, layers = ops.profile_collect(by_layer=True)
+    finally:
+        ops.profile_enable(False)
+    return out, layers
+
+
+# n, ci, h, w, co  (3x3 / stride 2 / pad 1; >= 16384 output pixels so that the gather form takes the launch)
+CASES_S2 = [
+    (8, 32, 320, 320, 64),     # DeSeNet-s layer 1: K = 288 = 4.5 slabs, 2 blocks per CU
+    (4, 32, 150, 134, 64),     # odd output map (75 x 67), ragged last tile
+    (8, 64, 160, 160, 128),    # layer 3: K = 576 = 9 slabs, two output-channel tiles
+    (3, 64, 166, 150, 72),     # odd sizes, ragged channel tile (72 of 128)
+]
+
+
+@pytest.mark.parametrize("case", CASES_S2)
+def test_stride2_forward_gathered_k(ops, case):
+    """3x3 / stride-2 forward through the weights-stationary kernel's gather form (K = 9 taps x Ci fetched by LDS-DMA from per-tap source
+    pixels; borders = out-of-range lanes): conv output and the BatchNorm sums of its epilogue against ATen."""
+    n, ci, h, w, co = case
+    dtype = torch.bfloat16
+    x = rnd((n, ci, h, w), 111)
+    wt = rnd((co, ci, 3, 3), 112, -0.2, 0.2)
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    ho, wo = ops.conv_out_hw(h, w, 3, 2, 1, 1)
+    y = ops.new_act(n, co, ho, wo, dtype, "cuda")
+    yref = F.conv2d(q(x, dtype), q(wt, dtype), None, 2, 1)
+    _, layers = _layers_of(ops, lambda: ops.conv2d_fwd(xd, wp, None, None, y, ops.conv_params(3, 2, 1, 1)))
+    assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k3s2") for k in layers), list(layers)
+    assert_close(y.float().cpu(), yref, TOL[dtype], f"s2 fwd {case}")
+    g_, b_ = rnd((co,), 113, 0.5, 1.5), rnd((co,), 114, -0.2, 0.2)
+    z = ops.new_act(n, co, ho, wo, dtype, "cuda")
+    y2 = ops.new_act(n, co, ho, wo, dtype, "cuda")
+    rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+    stats, layers = _layers_of(ops, lambda: ops.conv2d_fwd_bnstats(xd, wp, y2, ops.conv_params(3, 2, 1, 1), g_.cuda(), b_.cuda(), rm, rv,
+                                                                    0.03, 1e-3, ops.ACT_SILU, None, z))
+    assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k3s2") for k in layers), list(layers)
+    assert torch.equal(y2, y)
+    assert_close(stats[2].cpu(), yref.mean((0, 2, 3)), 2e-2, "batch mean")
+    zref = F.silu(F.batch_norm(yref, None, None, g_, b_, True, 0.03, 1e-3))
+    assert_close(z.float().cpu(), zref, 2 * TOL[dtype], "BN + SiLU output")
+
+
+# n, ci, h, w, co: dx is [n, ci, h, w], dy [n, co, ho, wo]; 4 * co must be whole slabs and <= 4 of them
+CASES_S2_DGRAD = [
+    (8, 32, 320, 320, 64),     # layer 1's data gradient: K = 256, 128 GEMM columns -> 4 sub-pixel classes x 32 channels
+    (4, 32, 149, 135, 64),     # odd destination map: the last row / column of classes is cut
+    (4, 24, 160, 128, 64),     # a class boundary inside a 64-column tile that is not a multiple of 32
+    (8, 64, 160, 160, 128),    # layer 3's data gradient: K = 512 = 8 slabs, weights + 3-stage ring fill the LDS exactly
+]
+
+
+@pytest.mark.parametrize("case", CASES_S2_DGRAD)
+@pytest.mark.parametrize("mode", ["plain", "accumulate", "bnred"])
+def test_stride2_dgrad_gathered_k_depth_to_space(ops, case, mode):
+    """The stride-2 data gradient (2x2 form, [4 Ci][2][2][Co] weights) through the gather form with the depth-to-space store, plain /
+    accumulating / with the BatchNorm backward sums of the block it completes -- against the implicit-GEMM launch (bit-equal
+    stores, the same sums)."""
+    import os
+    n, ci, h, w, co = case
+    dtype = torch.bfloat16
+    conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(rnd((co, ci, 3, 3), 120, -0.2, 0.2))
+    bank = ops.WeightBank([conv], [ci], dtype, "cuda")
+    bank.pack()
+    s2 = bank.dgrad_s2[0]
+    ho, wo = ops.conv_out_hw(h, w, 3, 2, 1, 1)
+    gy = rnd((n, co, ho, wo), 121)
+    gyd = to_dev(ops, gy, dtype)
+    p = ops.conv_params(3, 2, 1, 1, accumulate=(mode == "accumulate"))
+    base = rnd((n, ci, h, w), 122)
+    red = red_ref = None
+    if mode == "bnred":
+        yb = to_dev(ops, rnd((n, ci, h, w), 123), dtype)
+        st = torch.stack([torch.rand(ci, device="cuda") + 0.5, torch.rand(ci, device="cuda") - 0.5,
+                          torch.randn(ci, device="cuda") * 0.1, torch.rand(ci, device="cuda") + 0.5])
+        acc, _ = ops.bn_acc(ci, "cuda")
+        acc_ref, _ = ops.bn_acc(ci, "cuda")
+        red = ops.bnred([(0, ci, yb, st[0], st[1], st[2], st[3], ops.ACT_SILU, acc, ci, 0)])
+        red_ref = ops.bnred([(0, ci, yb, st[0], st[1], st[2], st[3], ops.ACT_SILU, acc_ref, ci, 0)])
+    dx = to_dev(ops, base, dtype)
+    _, layers = _layers_of(ops, lambda: ops.conv2d_dgrad_s2(gyd, s2, dx, p, red=red))
+    assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k2s2") for k in layers), list(layers)
+    ops._lib.lib().dsn_ws_mode(0, -1)                   # reference: the implicit-GEMM launch
+    try:
+        dx_ref = to_dev(ops, base, dtype)
+        _, layers = _layers_of(ops, lambda: ops.conv2d_dgrad_s2(gyd, s2, dx_ref, p, red=red_ref))
+        assert any(k[0].startswith("igemm_kernel") for k in layers), list(layers)
+    finally:
+        ops._lib.lib().dsn_ws_mode(1, -1)
+    xr = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(xr, q(conv.weight.detach().cpu(), dtype), None, 2, 1).backward(q(gy, dtype))
+    want = xr.grad + (q(base, dtype) if mode == "accumulate" else 0)
+    assert_close(dx.float().cpu(), want, 2 * TOL[dtype], f"dgrad_s2 gather {case} {mode}")
+    assert_close(dx.float().cpu(), dx_ref.float().cpu(), 1e-2, "gather form vs implicit GEMM")
+    if mode == "bnred":
+        def fold(a):
+            return a.view(torch.float64)[:8 * 2 * ci].view(8, 2, ci).sum(0).float()
+        got, ref = fold(acc), fold(acc_ref)
+        scale = float(ref.abs().max())
+        assert scale > 0 and float((got - ref).abs().max()) <= 3e-3 * scale, float((got - ref).abs().max()) / scale
