@@ -738,7 +738,8 @@ int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, con
 // ---- gather forms (G = 1: 3x3 / stride 2 forward, G = 2: its data gradient with depth-to-space store) ---------------------------
 // MODE as above.  The ring depth is what fits 160 KB next to the resident weights (the extras variant needs exactly three stages).
 template <typename T, int MI, int NI, int WGM, int WGN, int NS, int MODE, int G>
-int launch_gather_ws(const dsn_tensor* s, const void* w, const dsn_tensor* d, WGeom g, const BnAcc& fin, hipStream_t st, const WsX& ex) {
+int launch_gather_ws(const dsn_tensor* s, const void* w, const dsn_tensor* d, WGeom g, const BnAcc& fin, hipStream_t st, const WsX& ex,
+                     const float* bias = nullptr) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr bool STATS = MODE == 1, EX = MODE == 2;
     constexpr int TILEB = NS * BM * ROWB, WB1 = NS * BN * ROWB, RED = 0;      // (the fold buffer reuses the weight area)
@@ -766,7 +767,7 @@ int launch_gather_ws(const dsn_tensor* s, const void* w, const dsn_tensor* d, WG
     const ProfConv pc("conv1x1_ws_kernel", sizeof(T) == 2, BM, BN, G == 2, G == 1 ? 3 : 2, 2, 1, g.gCt, G == 1 ? g.Cd : g.d2s_c,
                       g.N, g.H, g.W);
     ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, (const float*)nullptr, (T*)d->ptr, fin, g, ex);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, st, (const T*)s->ptr, (const T*)w, bias, (T*)d->ptr, fin, g, ex);
     DSN_LAUNCH_CHECK("conv (weights-stationary, gathered K)");
     return DSN_OK;
 }
@@ -1803,30 +1804,37 @@ int dsn_conv3x3s2_ws_try(const dsn_tensor* s, const void* w, const float* bias, 
                          const dsn_conv_params* p, const BnAcc* finp, void* stream) {
     static const int mode = [] { const char* e = getenv("DSN_WS_S2"); return e ? atoi(e) : 1; }();
     if (!mode || !g_ws_mode[0]) return 1;
-    if (p->kh != 3 || p->kw != 3 || p->stride != 2 || p->pad != 1 || p->dil != 1 || p->accumulate) return 1;
-    if (s->dtype != DSN_BF16 || d->dtype != DSN_BF16 || r || bias || p->act != DSN_ACT_NONE) return 1;      // (training forward: conv + BatchNorm sums)
+    if (p->kh != 3 || p->kw != 3 || p->stride != 2 || p->pad != 1 || p->dil != 1 || p->accumulate || r) return 1;
+    if (s->dtype != d->dtype) return 1;
+    const int es = s->dtype == DSN_F32 ? 4 : 2, vec = 16 / es, kc = ROWB / es;
     if (s->n != d->n || d->h != (s->h - 1) / 2 + 1 || d->w != (s->w - 1) / 2 + 1) return 1;
-    if (s->c % 8 != 0 || d->c % 8 != 0 || s->ldc % 8 != 0 || d->ldc % 8 != 0) return 1;
+    if (s->c % vec != 0 || d->c % vec != 0 || s->ldc % vec != 0 || d->ldc % vec != 0) return 1;
     if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
-    const int K = 9 * s->c, ns = (K + 63) / 64;
-    const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * 2, wb = (int64_t)d->c * K * 2, db = ((npix(d) - 1) * d->ldc + d->c) * 2;
+    const int K = 9 * s->c, ns = (K + kc - 1) / kc;
+    const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * es, wb = (int64_t)d->c * K * es, db = ((npix(d) - 1) * d->ldc + d->c) * es;
     if (sb >= (1ll << 31) || wb >= (1ll << 31) || db >= (1ll << 32) - 64 || npix(d) < 16384) return 1;
     WGeom g{};
-    g.N = d->n; g.H = d->h; g.W = d->w; g.Cs = K; g.Cd = d->c; g.act = DSN_ACT_NONE;
+    g.N = d->n; g.H = d->h; g.W = d->w; g.Cs = K; g.Cd = d->c; g.act = p->act;
     g.sld = s->ldc; g.dld = d->ldc;
     g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb; g.dst_bytes = (uint32_t)db;
     g.wrow = K; g.gS = 2; g.gHs = s->h; g.gWs = s->w; g.gCt = s->c;
     BnAcc fin{};
     if (finp) fin = *finp;
+    if (fin.acc && (bias || p->act != DSN_ACT_NONE)) return 1;       // (training forward: plain conv + BatchNorm sums)
     hipStream_t st = (hipStream_t)stream;
     const WsX ex{};
+    if (s->dtype == DSN_F32) {
+        // 32 -> 64 @ 320 -> 160 in fp32: K = 288 floats = 9 slabs, 32 x 64 tiles (config 2's second layer)
+        if (ns == 9 && !fin.acc) return launch_gather_ws<float, 1, 2, 2, 2, 9, 0, 1>(s, w, d, g, fin, st, ex, bias);
+        return 1;
+    }
     if (ns == 5) {             // 32 -> 64 @ 320 -> 160: 32 x 64 tiles, 40 KB of weights + 2 x 20 KB: two blocks per CU
         if (fin.acc) return launch_gather_ws<bf16_t, 1, 2, 2, 2, 5, 1, 1>(s, w, d, g, fin, st, ex);
-        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 5, 0, 1>(s, w, d, g, fin, st, ex);
+        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 5, 0, 1>(s, w, d, g, fin, st, ex, bias);
     }
     if (ns == 9) {             // 64 -> 128 @ 160 -> 80: 32 x 64 tiles, 72 KB of weights per 64 output channels
         if (fin.acc) return launch_gather_ws<bf16_t, 1, 2, 2, 2, 9, 1, 1>(s, w, d, g, fin, st, ex);
-        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 9, 0, 1>(s, w, d, g, fin, st, ex);
+        return launch_gather_ws<bf16_t, 1, 2, 2, 2, 9, 0, 1>(s, w, d, g, fin, st, ex, bias);
     }
     return 1;
 }

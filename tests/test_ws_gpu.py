@@ -344,3 +344,20 @@ def test_stride2_dgrad_gathered_k_depth_to_space(ops, case, mode):
         got, ref = fold(acc), fold(acc_ref)
         scale = float(ref.abs().max())
         assert scale > 0 and float((got - ref).abs().max()) <= 3e-3 * scale, float((got - ref).abs().max()) / scale
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(4, 32, 160, 160, 64), (4, 32, 150, 134, 40)])
+def test_stride2_forward_gathered_k_fused_epilogue(ops, case, dtype):
+    """The inference form of the same launch: bias + SiLU in the epilogue, fp32 (K = 288 floats = 9 slabs) and bf16."""
+    n, ci, h, w, co = case
+    x = rnd((n, ci, h, w), 131)
+    wt, b = rnd((co, ci, 3, 3), 132, -0.2, 0.2), rnd((co,), 133)
+    xd = to_dev(ops, x, dtype)
+    wp = ops.pack_weight_fwd(wt.cuda(), dtype)
+    ho, wo = ops.conv_out_hw(h, w, 3, 2, 1, 1)
+    y = ops.new_act(n, co, ho, wo, dtype, "cuda")
+    ref = F.silu(F.conv2d(q(x, dtype), q(wt, dtype), b, 2, 1))
+    _, layers = _layers_of(ops, lambda: ops.conv2d_fwd(xd, wp, b.cuda(), None, y, ops.conv_params(3, 2, 1, 1, act=ops.ACT_SILU)))
+    assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k3s2") for k in layers), list(layers)
+    assert_close(y.float().cpu(), ref, TOL[dtype], f"s2 fwd fused {case}")
