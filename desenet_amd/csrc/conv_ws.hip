@@ -725,6 +725,18 @@ int launch_1x1_ws_ns(const dsn_tensor* s, const void* w, const float* bias, cons
 template <typename T, int MODE>
 int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
                       int is_dgrad, hipStream_t st, int ns, const WsX& ex) {
+    if (ns > 4) {      // 5 .. 8 slabs (K <= 512 bf16): 32 x 64 tiles, 64 KB of weights + a 2-stage ring, one block per CU; no extras
+        if constexpr (MODE != 2 && sizeof(T) == 2) {
+            switch (ns) {
+                case 5: return launch_1x1_ws<T, 1, 2, 2, 2, 5, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+                case 6: return launch_1x1_ws<T, 1, 2, 2, 2, 6, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+                case 7: return launch_1x1_ws<T, 1, 2, 2, 2, 7, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+                case 8: return launch_1x1_ws<T, 1, 2, 2, 2, 8, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
+                default: return 1;
+            }
+        }
+        return 1;
+    }
     static const int force = [] { const char* e = getenv("DSN_WS_CFG"); return e ? atoi(e) : -1; }();     // tuning knob
     int cfg = force;
     if (cfg < 0 || cfg > 2) cfg = g.Cd <= 32 ? 2 : (ns >= 3 ? 1 : 0);
@@ -1695,7 +1707,12 @@ int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
     if (s->h != d->h || s->w != d->w || s->n != d->n || s->dtype != d->dtype) return 1;
     const int es = s->dtype == DSN_F32 ? 4 : 2, vec = 16 / es, kc = ROWB / es;
     const int ns = (s->c + kc - 1) / kc;
-    if (s->c % vec != 0 || ns > 4 || d->c % vec != 0 || s->ldc % vec != 0 || d->ldc % vec != 0) return 1;
+    // 5 .. 8 slabs (K <= 512 bf16, no extras): 64 KB of resident weights per 64 output channels, one block per CU -- the implicit
+    // GEMM fetched those 64 KB once per 32 / 64 pixels (DSN_WS_LONGK=0: off; DSN_WS_LONGK_MINPX: smallest map taken)
+    static const int longk = [] { const char* e = getenv("DSN_WS_LONGK"); return e ? atoi(e) : 1; }();
+    static const int longk_minpx = [] { const char* e = getenv("DSN_WS_LONGK_MINPX"); return e ? atoi(e) : 2048; }();
+    const int ns_max = (longk && !extras && s->dtype == DSN_BF16 && npix(d) >= longk_minpx) ? 8 : 4;
+    if (s->c % vec != 0 || ns > ns_max || d->c % vec != 0 || s->ldc % vec != 0 || d->ldc % vec != 0) return 1;
     if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
     const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * es, wb = (int64_t)d->c * s->c * es;
     const int64_t db = ((npix(d) - 1) * d->ldc + d->c) * es;

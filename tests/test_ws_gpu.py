@@ -41,6 +41,9 @@ CASES_1X1 = [
     (1, 256, 48, 48, 200),     # four slabs (32 x 64 tiles), ragged last channel tile
     (3, 40, 31, 33, 72),       # nothing aligned to a tile
     (4, 128, 40, 40, 128),
+    (8, 512, 20, 20, 256),     # eight slabs (bf16 only): 64 KB of resident weights, 2-stage ring, one block per CU
+    (2, 448, 40, 40, 72),      # seven slabs, ragged channel tile
+    (8, 256, 20, 20, 512),     # the data gradient's K = 512
 ]
 
 
@@ -69,6 +72,8 @@ def test_conv1x1_ws_dgrad(ops, case, dtype):
     n, ci, h, w, co = case
     if dtype == torch.float32 and co > 128:
         pytest.skip("more than four fp32 slabs: not a weights-stationary launch")
+    if ci > 256 and co < 64:
+        pytest.skip("fewer than 64 source channels with a long destination: fine, but not a case worth its time")
     dy, wt = rnd((n, co, h, w), 21), rnd((co, ci, 1, 1), 22, -0.3, 0.3)
     ref = F.conv_transpose2d(q(dy, dtype), q(wt, dtype))
     dyd = to_dev(ops, dy, dtype)
