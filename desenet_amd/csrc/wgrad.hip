@@ -1232,6 +1232,20 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
     launch_out[7] = (double)any_lazy;       // some x operand carries deferred-BatchNorm segments: the LAZY instantiations run
     launch_out[8] = (double)start[3];       // grid of the 128 x 128-tile launch
     launch_out[9] = (double)start[4];       // grid of the halo-tile all-taps launch
+    static const bool dump = getenv("DSN_WGRAD_DUMP") && atoi(getenv("DSN_WGRAD_DUMP"));     // the plan, one line per job (stderr)
+    if (dump) {
+        static const char* kinds[5] = {"tap64", "alltaps", "-", "tap128", "halo"};
+        double kb[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < n; ++i) {
+            const WGeom& g = jobs[i].g;
+            fprintf(stderr, "wgrad job %2d %-7s %4d->%4d k%dx%d s%d out %3dx%3d  S %3d ppb %6d tiles %dx%d blocks %4d  operands %6.1f MB slabs %6.1f MB\n",
+                    i, kinds[jobs[i].kind], g.Ci, g.Co, g.KH, g.KW, g.stride, g.Ho, g.Wo, g.S, g.ppb, g.tiles_co, g.tiles_ci,
+                    jobs[i].blocks[jobs[i].kind], jobs[i].bytes / 1e6, g.S > 1 ? (double)g.S * jobs[i].n_out * 4 / 1e6 : 0.0);
+            kb[jobs[i].kind] += jobs[i].bytes;
+        }
+        fprintf(stderr, "wgrad plan: operands by kind: tap64 %.1f MB, tap128 %.1f MB, halo %.1f MB, alltaps %.1f MB\n", kb[0] / 1e6, kb[3] / 1e6,
+                kb[4] / 1e6, kb[1] / 1e6);
+    }
     return DSN_OK;
 }
 
