@@ -79,6 +79,21 @@ class dsn_bn_final(C.Structure):
                 ("rstd", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float)]
 
 
+PP_MAXSTAGE = 4
+
+
+class dsn_pp_stage(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("z", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("dy", C.c_void_p), ("dx", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dw", C.c_void_p),
+                ("zld", C.c_int64), ("yld", C.c_int64), ("dyld", C.c_int64), ("P", C.c_int32), ("has_bn", C.c_int32)]
+
+
+class dsn_pp_args(C.Structure):
+    _fields_ = [("s", dsn_pp_stage * PP_MAXSTAGE), ("nstage", C.c_int32), ("C", C.c_int32), ("Co", C.c_int32),
+                ("dtype", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float)]
+
+
 TP = C.POINTER(dsn_tensor)
 CP = C.POINTER(dsn_conv_params)
 vp, i32, i64, f32, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_double
@@ -174,6 +189,9 @@ PROTOTYPES = {
     "dsn_profile_kernel_name": (C.c_char_p, [i32]),
     "dsn_profile_dump": (i64, [vp, i64]),
     "dsn_ws_mode": (i32, [i32, i32]),
+    "dsn_pp_stages_supported": (i32, [i32, i32, i32, i32]),
+    "dsn_pp_stages_fwd": (i32, [C.POINTER(dsn_pp_args), vp]),
+    "dsn_pp_stages_bwd": (i32, [C.POINTER(dsn_pp_args), vp]),
 }
 
 _lib = None

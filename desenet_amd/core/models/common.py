@@ -21,8 +21,8 @@ import torch
 import torch.nn as nn
 
 from ... import hip_ops as ops
-from ...conv_impl import (act_code, conv_block_bwd, conv_block_fwd, out_shape, pair_block_bwd, pair_block_fwd,
-                          pair_ready)
+from ...conv_impl import (BN_MOMENTUM, _bn_sync, _conv_geom, _grad_slot, act_code, conv_block_bwd, conv_block_fwd, out_shape,
+                          packed_fwd, pair_block_bwd, pair_block_fwd, pair_ready)
 from ...hip_ops import ACT_NONE, ACT_SIGMOID, ACT_SILU
 from ...runtime import compute_dtype, run_module
 
@@ -415,11 +415,83 @@ class PyramidPooling(HipModule):
         # each stage of the four branches is ONE launch: pools (x read once), then the tiny convs, then the upsampling
         ks = [p.output_size if isinstance(p.output_size, int) else p.output_size[0] for p, _ in self._branches()]
         pooled = ops.adaptive_avgpool_multi(x, [ops.new_act(n, c, k, k, x.dtype, x.device) for k in ks])
-        fs = [conv.fwd(pooled[j], tape) for j, (_, conv) in enumerate(self._branches())]
+        fs = self._fwd_branches_fused(pooled, tape) if self._fusable(x, ks, tape) else None
+        if fs is None:
+            fs = [conv.fwd(pooled[j], tape) for j, (_, conv) in enumerate(self._branches())]
         ops.bilinear_ac_multi(fs, [out[:, base + j * oc: base + (j + 1) * oc] for j in range(len(fs))])
         if tape is not None:
             tape.push((n, c, h, w))
         return out
+
+    # ---- the four branches' conv + BatchNorm + act as ONE launch each way (csrc/pp_fused.hip) ---------------------------------
+    def _fusable(self, x, ks, tape) -> bool:
+        """Training step in bf16, ordinary (un-fused, un-synchronised, trainable) branches that fit the kernel's LDS budget."""
+        import os
+        if not self.training or tape is None or x.dtype != torch.bfloat16 or os.environ.get("DSN_PP_FUSED", "1") == "0":
+            return False
+        convs = [cv for _, cv in self._branches()]
+        if len(convs) > 4:
+            return False
+        bn0 = convs[0].bn if not convs[0].fused else None
+        for cv in convs:
+            if cv.fused or cv.conv.bias is not None or not cv.conv.weight.requires_grad or _conv_geom(cv.conv) != (1, 1, 0, 1):
+                return False
+            bn = cv.bn
+            if _bn_sync(bn) is not None or bn.weight is None or not (bn.weight.requires_grad and bn.bias.requires_grad):
+                return False
+            if bn.eps != bn0.eps or bn.momentum != bn0.momentum or act_code(cv.act) != act_code(convs[0].act):
+                return False
+        n, c = x.shape[0], x.shape[1]
+        return ops.pp_stages_supported(n * max(ks) ** 2, c, convs[0].conv.out_channels, x.dtype)
+
+    def _fwd_branches_fused(self, pooled, tape):
+        convs = [cv for _, cv in self._branches()]
+        dtype, dev = pooled[0].dtype, pooled[0].device
+        n, oc = pooled[0].shape[0], convs[0].conv.out_channels
+        act = act_code(convs[0].act)
+        ws = [packed_fwd(cv.conv, dtype, None, None)[0] for cv in convs]
+        # quirk Q1 (common.py:53): no BatchNorm on a 1 x 1 map
+        bns = [None if p.shape[2] * p.shape[3] == 1 else cv.bn for p, cv in zip(pooled, convs)]
+        zs = [ops.new_act(n, oc, p.shape[2], p.shape[3], dtype, dev) for p in pooled]
+        ys = [ops.new_act(n, oc, p.shape[2], p.shape[3], dtype, dev) for p in pooled]
+        stats = [None if bn is None else torch.empty((4, oc), dtype=torch.float32, device=dev) for bn in bns]
+        bn0 = convs[0].bn
+        ops.pp_stages_fwd(pooled, ws, bns, zs, ys, stats, act, bn0.momentum if bn0.momentum is not None else BN_MOMENTUM, bn0.eps)
+        for p, cv, bn, z, st in zip(pooled, convs, bns, zs, stats):
+            # the records conv_block_bwd reads: the per-branch backward stays valid on them
+            rec = dict(conv=cv.conv, bn=bn, act=act, x=p, x_in=p, ci_pad=None, geom=_conv_geom(cv.conv), plain=False, y=z, pp_fused=True)
+            if bn is not None:
+                if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
+                    bn.num_batches_tracked.add_(1)
+                rec.update(scale=st[0], shift=st[1], mean=st[2], rstd=st[3], stats=st, frozen=False, sync=None)
+            tape.push(rec)
+        return ys
+
+    def _bwd_branches_fused(self, tape, dfs):
+        """dpools (one per branch) or None when the branches were not recorded by the fused forward / have no gradient slots."""
+        nb = len(self._branches())
+        recs = [tape.pop() for _ in range(nb)][::-1]
+        slots = []
+        ok = all(isinstance(r, dict) and r.get("pp_fused") for r in recs)
+        if ok:
+            for r in recs:
+                bn = r["bn"]
+                sl = (_grad_slot(r["conv"].weight), _grad_slot(bn.weight) if bn is not None else None,
+                      _grad_slot(bn.bias) if bn is not None else None)
+                if sl[0] is None or (bn is not None and (sl[1] is None or sl[2] is None)) or r["conv"].weight in tape.grads:
+                    ok = False
+                    break
+                slots.append(sl)
+        if not ok:
+            tape.cursor += nb                        # un-pop: the per-branch backward walks the same records
+            return None
+        dtype = dfs[0].dtype
+        xs = [r["x"] for r in recs]
+        dxs = [ops.new_act(*x.shape, dtype, x.device) for x in xs]
+        ops.pp_stages_bwd(xs, [packed_fwd(r["conv"], dtype, None, None)[0] for r in recs], [r["y"] for r in recs], dfs, dxs,
+                          [r.get("stats") for r in recs], [s[1] for s in slots], [s[2] for s in slots], [s[0] for s in slots],
+                          recs[0]["act"], accumulate=True)
+        return dxs
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         n, c, h, w = tape.pop()
@@ -437,9 +509,11 @@ class PyramidPooling(HipModule):
         ks = [p.output_size if isinstance(p.output_size, int) else p.output_size[0] for _, (p, _) in br]
         dfs = ops.bilinear_ac_bwd_multi([dy[:, base + j * oc: base + (j + 1) * oc] for j, _ in br],
                                         [ops.new_act(n, oc, k, k, dy.dtype, dy.device) for k in ks])    # one launch pair
-        dpools = [None] * len(br)
-        for j, (_, conv) in reversed(br):             # tape order: the branches' convs were recorded 0..3
-            dpools[j] = conv.bwd(tape, dfs[j])
+        dpools = self._bwd_branches_fused(tape, dfs)
+        if dpools is None:
+            dpools = [None] * len(br)
+            for j, (_, conv) in reversed(br):         # tape order: the branches' convs were recorded 0..3
+                dpools[j] = conv.bwd(tape, dfs[j])
         ops.adaptive_avgpool_bwd_multi(dpools[::-1], dx, accumulate=acc)      # the four grids in one pass over dx
         return dx
 

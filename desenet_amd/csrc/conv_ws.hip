@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
                                                               const BnAcc fin, const WGeom g) {
     typedef bf16_t T;
     constexpr int WGM = 4 / WGN;
-    constexpr int TW = 16, TH = WGM * MI, BM = TH * TW, BN = WGN * NI * 16;
+    constexpr int TW = 16, TH = WGM * MI, BN = WGN * NI * 16;
     constexpr int PXB = 32;                              // bytes per input pixel
     constexpr int HWP = TW + 2, HROWB = HWP * PXB;       // halo row: 18 pixels = 576 bytes
     constexpr int NPIECE = (TH + 2) * HROWB / 16;        // 16-byte pieces of a halo patch

@@ -1109,6 +1109,53 @@ def profile_collect(by_layer: bool = False):
     return (out, layers) if by_layer else out
 
 
+# ------------------------------------------------------------------------------------------------ PyramidPooling branches
+def pp_stages_supported(max_pixels: int, c: int, co: int, dtype) -> bool:
+    """Can dsn_pp_stages_fwd / _bwd take branches of up to max_pixels pooled pixels, c -> co channels (bf16, fits LDS)?"""
+    if dtype != torch.bfloat16:
+        return False
+    return bool(_lib.lib().dsn_pp_stages_supported(int(max_pixels), int(c), int(co), DSN_BF16))
+
+
+def _pp_args(stages, c, co, act, accumulate=0, momentum=0.0, eps=0.0):
+    a = _lib.dsn_pp_args()
+    a.nstage, a.C, a.Co, a.dtype, a.act, a.accumulate = len(stages), c, co, DSN_BF16, act, int(accumulate)
+    a.momentum, a.eps = float(momentum), float(eps)
+    for j, st in enumerate(stages):
+        for k, v in st.items():
+            setattr(a.s[j], k, v)
+    return a
+
+
+def pp_stages_fwd(xs, ws, bns, zs, ys, stats, act, momentum, eps):
+    """xs[j]: pooled map [n, c, k, k] (contiguous NHWC), ws[j]: forward-packed [co, c] weights, bns[j]: the branch's BatchNorm2d or
+    None (1x1 map), zs / ys[j]: raw and activated outputs [n, co, k, k], stats[j]: fp32 [4, co] or None.  One launch."""
+    n, c = xs[0].shape[0], xs[0].shape[1]
+    co = zs[0].shape[1]
+    stages = []
+    for x, w, bn, z, y, st in zip(xs, ws, bns, zs, ys, stats):
+        _require_gpu(x)
+        stages.append(dict(x=x.data_ptr(), w=w.data_ptr(), z=z.data_ptr(), y=y.data_ptr(), stats=_p(st),
+                           gamma=_p(bn.weight) if bn is not None else None, beta=_p(bn.bias) if bn is not None else None,
+                           running_mean=_p(bn.running_mean) if bn is not None else None,
+                           running_var=_p(bn.running_var) if bn is not None else None,
+                           zld=_nhwc_ldc(z), yld=_nhwc_ldc(y), P=x.shape[0] * x.shape[2] * x.shape[3], has_bn=int(bn is not None)))
+    a = _pp_args(stages, c, co, act, 0, momentum, eps)
+    _lib.check(_lib.lib().dsn_pp_stages_fwd(C.byref(a), stream_ptr()), "pp_stages_fwd")
+
+
+def pp_stages_bwd(xs, ws, zs, dys, dxs, stats, dgammas, dbetas, dws, act, accumulate):
+    """Backward of pp_stages_fwd: dxs[j] [n, c, k, k] written; dgammas / dbetas / dws[j] fp32 (+= when accumulate)."""
+    c, co = xs[0].shape[1], zs[0].shape[1]
+    stages = []
+    for x, w, z, dy, dx, st, dg, db, dw in zip(xs, ws, zs, dys, dxs, stats, dgammas, dbetas, dws):
+        stages.append(dict(x=x.data_ptr(), w=w.data_ptr(), z=z.data_ptr(), dy=dy.data_ptr(), dx=dx.data_ptr(), stats=_p(st),
+                           dgamma=_p(dg), dbeta=_p(db), dw=_p(dw), zld=_nhwc_ldc(z), dyld=_nhwc_ldc(dy),
+                           P=x.shape[0] * x.shape[2] * x.shape[3], has_bn=int(st is not None)))
+    a = _pp_args(stages, c, co, act, accumulate)
+    _lib.check(_lib.lib().dsn_pp_stages_bwd(C.byref(a), stream_ptr()), "pp_stages_bwd")
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def det_loss(p, targets, anchors_host, balance, h_box, h_obj, h_cls, cls_pw, obj_pw, anchor_t, cp, cn, nc, gain=1.0):
     """p: list of fp32 contiguous [bs,na,ny,nx,5+nc] raw Detect outputs.  Returns (out [4] = {gain*(lbox+lobj+lcls)*bs,

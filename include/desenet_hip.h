@@ -534,6 +534,39 @@ const char* dsn_profile_kernel_name(int32_t kid);
  * exceed `cap` nothing is written and the records are kept (call again with a larger buffer).  < 0: -hipError_t. */
 int64_t     dsn_profile_dump(char* out, int64_t cap);
 
+/* ---- PyramidPooling branches in one launch each way (common.py:588-615) ------------------------------------------------------
+ * Branch j: x_j [P_j pixels][C] (the adaptive-average-pooled map, contiguous NHWC) -> 1x1 convolution with the forward-packed
+ * weights w_j [Co][C] -> training-mode BatchNorm over the P_j pixels (has_bn = 0 on 1x1 maps: quirk Q1, common.py:53) -> act.
+ *   dsn_pp_stages_fwd: writes z_j (raw convolution output, rounded to the activation dtype), y_j = act(z_j * scale + shift),
+ *     stats_j = [scale | shift | mean | rstd] (Co floats each) and updates running_mean / running_var (momentum, unbiased variance).
+ *   dsn_pp_stages_bwd: from dy_j, z_j, x_j, w_j, stats_j: dx_j [P_j][C], dgamma_j / dbeta_j and dw_j [Co][C] fp32 (accumulate = 1:
+ *     added to what they hold; 0: overwritten); null dgamma / dbeta / dw pointers are skipped.
+ * bf16 with C % 8 == 0 and Co % 8 == 0, and every branch must fit the 160 KB of LDS of one CU (dsn_pp_stages_supported; DeSeNet-s:
+ * 288 pixels x 128 -> 32 channels does): otherwise DSN_EUNSUPPORTED and the caller runs the branches as ordinary layers. */
+#define DSN_PP_MAXSTAGE 4
+typedef struct {
+    const void* x;
+    const void* w;
+    void* z;
+    void* y;                 /* forward */
+    float* stats;            /* [4][Co]; unused when has_bn == 0 */
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    const void* dy;          /* backward */
+    void* dx;
+    float *dgamma, *dbeta, *dw;
+    int64_t zld, yld, dyld;  /* row strides of z, y, dy in elements */
+    int32_t P, has_bn;
+} dsn_pp_stage;
+typedef struct {
+    dsn_pp_stage s[DSN_PP_MAXSTAGE];
+    int32_t nstage, C, Co, dtype, act, accumulate;
+    float momentum, eps;
+} dsn_pp_args;
+int dsn_pp_stages_supported(int32_t max_pixels, int32_t c, int32_t co, int32_t dtype);
+int dsn_pp_stages_fwd(const dsn_pp_args* a, void* stream);
+int dsn_pp_stages_bwd(const dsn_pp_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

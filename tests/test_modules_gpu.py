@@ -195,3 +195,59 @@ def test_concat_zero_copy_and_fallback(dsn):
         z = cat([buf[:, :8], buf[:, 8:]])         # adjacent slices -> the covering view, no copy
     assert z.data_ptr() == buf.data_ptr()
     assert np.array_equal(z.cpu().numpy(), g["upcat_eval/y0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 128, 80, 80), (3, 64, 37, 41)])
+def test_pyramid_pooling_fused_branches_match_the_per_branch_path(shape, monkeypatch):
+    """PyramidPooling's four conv + BatchNorm + SiLU branches as one launch each way (csrc/pp_fused.hip, bf16 training) against the
+    per-branch kernels on the same module: output, input gradient, every parameter gradient, running statistics."""
+    import copy
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.core.models.common import PyramidPooling
+    from desenet_amd.parallel import FlatGradients
+    desenet_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        n, c, h, w = shape
+        torch.manual_seed(5)
+        ref = PyramidPooling(c).cuda().train()
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.2, 0.2)
+        fused = copy.deepcopy(ref)
+        x = torch.randn(n, c, h, w, device="cuda")
+        gy = torch.randn(n, 4 * (c // 4), h, w, device="cuda")
+        outs = {}
+        calls = {"fwd": 0, "bwd": 0}
+        real_fwd, real_bwd = ops.pp_stages_fwd, ops.pp_stages_bwd
+        monkeypatch.setattr(ops, "pp_stages_fwd", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), real_fwd(*a, **k))[1])
+        monkeypatch.setattr(ops, "pp_stages_bwd", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), real_bwd(*a, **k))[1])
+        for name, mod, flag in (("ref", ref, "0"), ("fused", fused, "1")):
+            monkeypatch.setenv("DSN_PP_FUSED", flag)
+            flat = FlatGradients(mod.parameters())
+            flat.zero()
+            xin = x.clone().requires_grad_(True)
+            ops.profile_enable(True)
+            y = mod(xin)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            prof = ops.profile_collect()
+            ops.profile_enable(False)
+            outs[name] = (y.detach().float(), xin.grad.float(), {k: p.grad.clone() for k, p in mod.named_parameters()},
+                          {k: b.clone() for k, b in mod.named_buffers()})
+        assert calls == {"fwd": 1, "bwd": 1}, calls          # the fused launches ran once each, for the second module only
+        for a, b, what in ((outs["ref"][0], outs["fused"][0], "output"), (outs["ref"][1], outs["fused"][1], "input gradient")):
+            scale = float(a.abs().max())
+            assert float((a - b).abs().max()) <= 2e-2 * scale, (what, float((a - b).abs().max()) / scale)
+        for k, g in outs["ref"][2].items():
+            scale = float(g.abs().max()) + 1e-12
+            assert float((g - outs["fused"][2][k]).abs().max()) <= 2e-2 * scale, (k, float((g - outs["fused"][2][k]).abs().max()) / scale)
+        for k, b in outs["ref"][3].items():
+            if b.dtype.is_floating_point:
+                assert torch.allclose(b, outs["fused"][3][k], rtol=1e-4, atol=1e-6), k
+            else:
+                assert torch.equal(b, outs["fused"][3][k]), k
+    finally:
+        desenet_amd.set_compute_dtype(torch.float32)
