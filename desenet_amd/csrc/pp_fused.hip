@@ -13,6 +13,10 @@
 namespace {
 
 constexpr int PP_THREADS = 1024, PP_WAVES = PP_THREADS / 64;
+// LDS rows are padded by 16 bytes: an MFMA fragment read takes 16 rows at one column position, and with 64- / 256-byte rows those
+// land in the same four banks (16-way conflicts: 12 of the forward kernel's 15.5 us at 288 pixels were this); + 16 bytes rotates
+// every row by four banks.  The fp32 accumulator tile gets + 4 floats for the per-pixel-strided reads of the statistics pass.
+constexpr int PADE = 8, PADF = 4;
 
 __device__ __forceinline__ f32x4 mma(const bf16_t* a_row, const bf16_t* b_row, f32x4 acc) {
     // D[a-row 4 fg + e][b-row fr] += sum_k A[.][k] B[.][k], k = 8 fg .. 8 fg + 7 of this 32-wide step
@@ -24,7 +28,7 @@ __device__ __forceinline__ f32x4 mma(const bf16_t* a_row, const bf16_t* b_row, f
 // Copy a [rows][cols] bf16 matrix (row stride lds elements, 16-byte aligned rows) into a zero-padded [rows_p][cols_p] LDS tile, four
 // 16-byte loads in flight per thread (a plain copy loop waits for every load before it issues the next: ~1.5 us per trip here).
 __device__ __forceinline__ void stage_tile(bf16_t* dst, int cols_p, int rows_p, const bf16_t* src, int64_t lds, int rows, int cols) {
-    const int vpr = cols_p / 8, total = rows_p * vpr;
+    const int vpr = cols_p / 8, total = rows_p * vpr, dld = cols_p + PADE;      // (padded destination rows: see PADE)
     for (int base = threadIdx.x; base < total; base += 4 * PP_THREADS) {
         u32x4 v[4];
 #pragma unroll
@@ -37,7 +41,8 @@ __device__ __forceinline__ void stage_tile(bf16_t* dst, int cols_p, int rows_p, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = base + u * PP_THREADS;
-            if (i < total) *reinterpret_cast<u32x4*>(dst + (size_t)i * 8) = v[u];
+            const int r = i / vpr, c8 = (i - r * vpr) * 8;
+            if (i < total) *reinterpret_cast<u32x4*>(dst + (size_t)r * dld + c8) = v[u];
         }
     }
 }
@@ -50,10 +55,11 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_fwd_kernel(const dsn_pp_
     const dsn_pp_stage& s = a.s[blockIdx.x];
     const int P = s.P, C = a.C, Co = a.Co;
     const int Pp = up(P, 16), Cp = up(C, 32), Cop = up(Co, 16);
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [Pp][Cp]
-    bf16_t* ws = xs + (size_t)Pp * Cp;                                  // [Cop][Cp]
-    float* zf = reinterpret_cast<float*>(ws + (size_t)Cop * Cp);        // [Pp][Cop] fp32 accumulators
-    float* sc = zf + (size_t)Pp * Cop;                                  // [Cop] scale, [Cop] shift
+    const int XL = Cp + PADE, ZL = Cop + PADF;                          // row strides of the bf16 tiles / the fp32 tile
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [Pp][XL]
+    bf16_t* ws = xs + (size_t)Pp * XL;                                  // [Cop][XL]
+    float* zf = reinterpret_cast<float*>(ws + (size_t)Cop * XL);        // [Pp][ZL] fp32 accumulators
+    float* sc = zf + (size_t)Pp * ZL;                                   // [Cop] scale, [Cop] shift
     float* sh = sc + Cop;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -69,8 +75,8 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_fwd_kernel(const dsn_pp_
         const int mt = t / tiles_n, nt = t - mt * tiles_n;
         f32x4 acc{0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < Cp; k0 += 32)
-            acc = mma(ws + (size_t)(nt * 16 + fr) * Cp + k0 + fg * 8, xs + (size_t)(mt * 16 + fr) * Cp + k0 + fg * 8, acc);
-        *reinterpret_cast<f32x4*>(zf + (size_t)(mt * 16 + fr) * Cop + nt * 16 + fg * 4) = acc;
+            acc = mma(ws + (size_t)(nt * 16 + fr) * XL + k0 + fg * 8, xs + (size_t)(mt * 16 + fr) * XL + k0 + fg * 8, acc);
+        *reinterpret_cast<f32x4*>(zf + (size_t)(mt * 16 + fr) * ZL + nt * 16 + fg * 4) = acc;
     }
     __syncthreads();
     // ---- batch statistics (fp64, fixed order): 32 partial sums per channel, then one thread per channel
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_fwd_kernel(const dsn_pp_
             double s0 = 0.0, s1 = 0.0;
             if (co < Co)
                 for (int p = part; p < P; p += 32) {
-                    const double v = (double)zf[(size_t)p * Cop + co];
+                    const double v = (double)zf[(size_t)p * ZL + co];
                     s0 += v; s1 += v * v;
                 }
 #pragma unroll
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_fwd_kernel(const dsn_pp_
         float u[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            zv[k] = (bf16_t)zf[(size_t)p * Cop + c8 + k];
+            zv[k] = (bf16_t)zf[(size_t)p * ZL + c8 + k];
             u[k] = (float)zv[k] * sc[c8 + k] + sh[c8 + k];
         }
         apply_act_vec<8>(u, a.act);
@@ -128,13 +134,15 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_fwd_kernel(const dsn_pp_
     }
 }
 
-// gather 8 K-values of a "transposed" MFMA operand: element k of the fragment is src[(k0 + k) * ld + col] (the K axis runs down the
-// rows of a pixel-major / row-major tile; these GEMMs are a handful of MFMAs per wave, the scalar reads do not matter)
-__device__ __forceinline__ bf16x8 gather8(const bf16_t* src, int ld, int k0, int col) {
-    bf16x8 v;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(k0 + k) * ld + col];
-    return v;
+// Fragment of a "transposed" MFMA operand: row (lane & 15) of the operand is COLUMN col0 + (lane & 15) of a row-major LDS tile, its 8
+// K-values run down the tile's rows k0 + 8 fg .. + 7.  ds_read_b64_tr_b16 (wgrad.hip's pattern): lane 4q + p of a 16-lane group
+// addresses row q, columns 4p .. 4p + 3 of a 4 x 16 block and receives column (lane & 15), rows 0 .. 3; two reads = 8 rows.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* tile, int ld, int k0, int col0, int fr, int fg) {
+    const bf16_t* base = tile + (size_t)(k0 + 8 * fg + (fr >> 2)) * ld + col0 + 4 * (fr & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)base);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * (size_t)ld));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 __global__ __launch_bounds__(PP_THREADS) void pp_stages_bwd_kernel(const dsn_pp_args a) {
@@ -142,65 +150,71 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_bwd_kernel(const dsn_pp_
     const dsn_pp_stage& s = a.s[blockIdx.x];
     const int P = s.P, C = a.C, Co = a.Co;
     const int Pp = up(P, 32), Cp = up(C, 32), Cop = up(Co, 32);
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [Pp][Cp]   x, pixel rows
-    bf16_t* ws = xs + (size_t)Pp * Cp;                                  // [Cop][Cp]  W, output-channel rows
-    bf16_t* zb = ws + (size_t)Cop * Cp;                                 // [Pp][Cop]  z
-    bf16_t* dyb = zb + (size_t)Pp * Cop;                                // [Pp][Cop]  dy
-    bf16_t* dzs = dyb + (size_t)Pp * Cop;                               // [Pp][Cop]  dz
-    float* ka = reinterpret_cast<float*>(dzs + (size_t)Pp * Cop);       // [Cop] x 2
-    float* kb = ka + Cop;
+    const int XL = Cp + PADE, OL = Cop + PADE;                          // padded row strides
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [Pp][XL]   x, pixel rows
+    bf16_t* ws = xs + (size_t)Pp * XL;                                  // [Cop][XL]  W, output-channel rows
+    bf16_t* zb = ws + (size_t)Cop * XL;                                 // [Pp][OL]   z
+    bf16_t* dyb = zb + (size_t)Pp * OL;                                 // [Pp][OL]   dy
+    bf16_t* dzs = dyb + (size_t)Pp * OL;                                // [Pp][OL]   dz
+    float* cst = reinterpret_cast<float*>(dzs + (size_t)Pp * OL);       // [4][Cop]: scale, shift, mean, rstd
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const bf16_t* x = (const bf16_t*)s.x;
     const bf16_t* w = (const bf16_t*)s.w;
     const bf16_t* z = (const bf16_t*)s.z;
     const bf16_t* dy = (const bf16_t*)s.dy;
-    const float *scale = s.stats, *shift = s.stats + Co, *mean = s.stats + 2 * Co, *rstd = s.stats + 3 * Co;
+    const float *scale = cst, *shift = cst + Cop, *mean = cst + 2 * Cop, *rstd = cst + 3 * Cop;
+    if (s.has_bn)
+        for (int i = tid; i < 4 * Co; i += PP_THREADS) cst[(i / Co) * Cop + (i % Co)] = s.stats[i];
     // ---- stage x, W, z, dy with 16-byte copies (zero padding beyond the real rows / columns)
     stage_tile(xs, Cp, Pp, x, C, P, C);
     stage_tile(ws, Cp, Cop, w, C, Co, C);
     stage_tile(zb, Cop, Pp, z, s.zld, P, Co);
     stage_tile(dyb, Cop, Pp, dy, s.dyld, P, Co);
     __syncthreads();
-    auto gval = [&](int p, int co) {                                   // g = dy * act'(u), recomputed where needed
-        const float zv = (float)zb[(size_t)p * Cop + co];
-        const float u = s.has_bn ? zv * scale[co] + shift[co] : zv;
-        return (float)dyb[(size_t)p * Cop + co] * act_grad(u, a.act);
-    };
-    if (s.has_bn) {
-        for (int base = 0; base < Cop; base += PP_THREADS / 32) {
-            const int co = base + (tid >> 5), part = tid & 31;
-            double s0 = 0.0, s1 = 0.0;
-            if (co < Co) {
-                const float mu = mean[co], rs = rstd[co];
-                for (int p = part; p < P; p += 32) {
-                    const float gv = gval(p, co);
-                    s0 += (double)gv;
-                    s1 += (double)(gv * (((float)zb[(size_t)p * Cop + co] - mu) * rs));
-                }
-            }
+    // ---- one pass per element, values in registers: half-wave h owns channel cbase + h, lane `part` its pixels part, part + 32, ..
+    //      g = dy * act'(u) once, the two sums by a fixed shuffle tree, their means broadcast from lane 0 of the half, dz written
+    constexpr int MAXK = 16;                                            // P <= 512 (pp_check)
+    for (int cbase = 0; cbase < Cop; cbase += PP_THREADS / 32) {
+        const int co = cbase + (tid >> 5), part = tid & 31;
+        const bool live = co < Co;
+        const float scv = live && s.has_bn ? scale[co] : 1.f, shv = live && s.has_bn ? shift[co] : 0.f;
+        const float mu = live && s.has_bn ? mean[co] : 0.f, rs = live && s.has_bn ? rstd[co] : 0.f;
+        float gk[MAXK], zk[MAXK];
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
-            if (part == 0 && co < Co) {
-                const double count = (double)P;
-                const float m1 = (float)(s0 / count), m2 = (float)(s1 / count);
-                ka[co] = -scale[co] * rstd[co] * m2;
-                kb[co] = -scale[co] * m1;
+        for (int k = 0; k < MAXK; ++k) {
+            const int p = part + 32 * k;
+            gk[k] = 0.f; zk[k] = 0.f;
+            if (live && p < P) {
+                zk[k] = (float)zb[(size_t)p * OL + co];
+                gk[k] = (float)dyb[(size_t)p * OL + co] * act_grad(zk[k] * scv + shv, a.act);
+                s0 += (double)gk[k];
+                s1 += (double)(gk[k] * ((zk[k] - mu) * rs));
+            }
+        }
+        float kav = 0.f, kbv = 0.f;
+        if (s.has_bn) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }      // (every lane of the half ends with the totals)
+            const double count = (double)P;
+            const float m1 = (float)(s0 / count), m2 = (float)(s1 / count);
+            kav = -scv * rs * m2;
+            kbv = -scv * m1;
+            if (part == 0 && live) {
                 if (s.dbeta) s.dbeta[co] = a.accumulate ? s.dbeta[co] + (float)s0 : (float)s0;
                 if (s.dgamma) s.dgamma[co] = a.accumulate ? s.dgamma[co] + (float)s1 : (float)s1;
             }
         }
-        __syncthreads();
-    }
-    // ---- dz (rounded to bf16 as the elementwise pass stores it); padding rows / columns are zeros
-    for (int i = tid; i < Pp * Cop; i += PP_THREADS) {
-        const int p = i / Cop, co = i - p * Cop;
-        float dzv = 0.f;
-        if (p < P && co < Co) {
-            dzv = gval(p, co);
-            if (s.has_bn) dzv = scale[co] * dzv + (ka[co] * ((float)zb[(size_t)p * Cop + co] - mean[co]) + kb[co]);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            const int p = part + 32 * k;
+            if (co < Cop && p < Pp) {            // padding rows / columns are zeros (gk = 0 there, and kb must not leak into them)
+                float dzv = gk[k];
+                if (s.has_bn && live && p < P) dzv = scv * dzv + (kav * (zk[k] - mu) + kbv);
+                dzs[(size_t)p * OL + co] = (bf16_t)dzv;
+            }
         }
-        dzs[i] = (bf16_t)dzv;
     }
     __syncthreads();
     // ---- dx[p][c] = sum_co dz[p][co] W[co][c]: A = W "transposed" (rows = input channels, K = output channels down the rows of ws),
@@ -212,8 +226,8 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_bwd_kernel(const dsn_pp_
             const int mt = t / tiles_n, nt = t - mt * tiles_n;
             f32x4 acc{0.f, 0.f, 0.f, 0.f};
             for (int k0 = 0; k0 < Cop; k0 += 32) {
-                const bf16x8 av = gather8(ws, Cp, k0 + fg * 8, nt * 16 + fr);
-                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(dzs + (size_t)(mt * 16 + fr) * Cop + k0 + fg * 8);
+                const bf16x8 av = frag_tr(ws, XL, k0, nt * 16, fr, fg);
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(dzs + (size_t)(mt * 16 + fr) * OL + k0 + fg * 8);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
             }
             const int p = mt * 16 + fr, c = nt * 16 + fg * 4;
@@ -230,8 +244,8 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_bwd_kernel(const dsn_pp_
             const int mt = t / tiles_n, nt = t - mt * tiles_n;
             f32x4 acc{0.f, 0.f, 0.f, 0.f};
             for (int k0 = 0; k0 < Pp; k0 += 32) {
-                const bf16x8 av = gather8(dzs, Cop, k0 + fg * 8, nt * 16 + fr);
-                const bf16x8 bv = gather8(xs, Cp, k0 + fg * 8, mt * 16 + fr);
+                const bf16x8 av = frag_tr(dzs, OL, k0, nt * 16, fr, fg);
+                const bf16x8 bv = frag_tr(xs, XL, k0, mt * 16, fr, fg);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
             }
             const int c = mt * 16 + fr;
@@ -249,11 +263,11 @@ __global__ __launch_bounds__(PP_THREADS) void pp_stages_bwd_kernel(const dsn_pp_
 
 size_t pp_fwd_lds(int P, int C, int Co) {
     const int Pp = (P + 15) / 16 * 16, Cp = (C + 31) / 32 * 32, Cop = (Co + 15) / 16 * 16;
-    return (size_t)Pp * Cp * 2 + (size_t)Cop * Cp * 2 + (size_t)Pp * Cop * 4 + 2 * Cop * 4;
+    return ((size_t)Pp + Cop) * (Cp + PADE) * 2 + (size_t)Pp * (Cop + PADF) * 4 + 2 * Cop * 4;
 }
 size_t pp_bwd_lds(int P, int C, int Co) {
     const int Pp = (P + 31) / 32 * 32, Cp = (C + 31) / 32 * 32, Cop = (Co + 31) / 32 * 32;
-    return ((size_t)Pp * Cp + (size_t)Cop * Cp + 3 * (size_t)Pp * Cop) * 2 + 2 * Cop * 4;
+    return (((size_t)Pp + Cop) * (Cp + PADE) + 3 * (size_t)Pp * (Cop + PADE)) * 2 + 4 * Cop * 4;
 }
 
 int pp_check(const dsn_pp_args* a, bool bwd, size_t* lds_out) {
@@ -263,6 +277,7 @@ int pp_check(const dsn_pp_args* a, bool bwd, size_t* lds_out) {
     for (int j = 0; j < a->nstage; ++j) {
         const dsn_pp_stage& s = a->s[j];
         DSN_CHECK_ARG(s.P > 0 && s.x && s.w && s.z, "pp_stages: null operand in branch %d", j);
+        if (s.P > 512) DSN_FAIL(DSN_EUNSUPPORTED, "pp_stages: more than 512 pixels in a branch");
         DSN_CHECK_ARG(!s.has_bn || s.stats, "pp_stages: branch %d has BatchNorm but no statistics buffer", j);
         if (((uintptr_t)s.x | (uintptr_t)s.w | (uintptr_t)s.z) % 16 != 0 || s.zld % 8 != 0) DSN_FAIL(DSN_EUNSUPPORTED, "pp_stages: unaligned operand");
         if (bwd) {
@@ -283,7 +298,7 @@ int pp_check(const dsn_pp_args* a, bool bwd, size_t* lds_out) {
 }  // namespace
 
 extern "C" int dsn_pp_stages_supported(int32_t max_pixels, int32_t c, int32_t co, int32_t dtype) {
-    if (dtype != DSN_BF16 || c % 8 != 0 || co % 8 != 0 || max_pixels <= 0) return 0;
+    if (dtype != DSN_BF16 || c % 8 != 0 || co % 8 != 0 || max_pixels <= 0 || max_pixels > 512) return 0;
     return pp_fwd_lds(max_pixels, c, co) <= 160 * 1024 && pp_bwd_lds(max_pixels, c, co) <= 160 * 1024;
 }
 
