@@ -251,3 +251,44 @@ def test_pyramid_pooling_fused_branches_match_the_per_branch_path(shape, monkeyp
                 assert torch.equal(b, outs["fused"][3][k]), k
     finally:
         desenet_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+def test_ffm_attention_fused_small_convs_match_the_layer_path(monkeypatch):
+    """FFM's channel attention (two bias-free 1x1 convs on the pooled [n, c, 1, 1] vector, SiLU / Sigmoid: common.py:222-242) through
+    the one-block kernels of csrc/pp_fused.hip against the conv + activation launches: output, input and weight gradients."""
+    import copy
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.core.models.common import FFM
+    from desenet_amd.parallel import FlatGradients
+    desenet_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(7)
+        ref = FFM(64, 128, k=3, is_cat=False).cuda().train()
+        fused = copy.deepcopy(ref)
+        x = torch.randn(4, 64, 40, 40, device="cuda")
+        gy = torch.randn(4, 128, 40, 40, device="cuda")
+        calls = {"fwd": 0, "bwd": 0}
+        real_fwd, real_bwd = ops.pp_stages_fwd, ops.pp_stages_bwd
+        monkeypatch.setattr(ops, "pp_stages_fwd", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), real_fwd(*a, **k))[1])
+        monkeypatch.setattr(ops, "pp_stages_bwd", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), real_bwd(*a, **k))[1])
+        outs = {}
+        for name, mod, flag in (("ref", ref, "0"), ("fused", fused, "3")):      # (3: off by default -- measured slower in the step)
+            monkeypatch.setenv("DSN_PP_FUSED", flag)
+            flat = FlatGradients(mod.parameters())
+            flat.zero()
+            xin = x.clone().requires_grad_(True)
+            y = mod(xin)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            outs[name] = (y.detach().float(), xin.grad.float(), {k: p.grad.clone() for k, p in mod.named_parameters()})
+        assert calls == {"fwd": 2, "bwd": 2}, calls
+        for a, b, what in ((outs["ref"][0], outs["fused"][0], "output"), (outs["ref"][1], outs["fused"][1], "input gradient")):
+            scale = float(a.abs().max())
+            assert float((a - b).abs().max()) <= 2e-2 * scale, (what, float((a - b).abs().max()) / scale)
+        for k, g in outs["ref"][2].items():
+            scale = float(g.abs().max()) + 1e-12
+            assert float((g - outs["fused"][2][k]).abs().max()) <= 3e-2 * scale, (k, float((g - outs["fused"][2][k]).abs().max()) / scale)
+    finally:
+        desenet_amd.set_compute_dtype(torch.float32)
