@@ -512,9 +512,6 @@ class Model(HipModule):
         self.bwd_layers(tape, grads, len(self.model) - 1, 0)
         return None
 
-    # top-level layers after whose backward the weight gradients queued so far go to the side stream (runtime.wgrad_async)
-    _wgrad_flush_after = tuple(int(v) for v in __import__("os").environ.get("DSN_WGRAD_FLUSH_AFTER", "17,5").split(","))
-
     def bwd_begin(self, dy):
         """Gradient table of a backward pass: {top-level layer index: gradient of that layer's output}."""
         d_det, d_seg = dy
@@ -545,8 +542,6 @@ class Model(HipModule):
                 outs = m.bwd(tape, g, have, [h is not None for h in have])
                 for s, o in zip(srcs, outs):
                     grads[s] = o
-            if m.i in self._wgrad_flush_after:
-                tape.flush_wgrad_async()       # (no-op unless runtime.set_wgrad_async(True) / DSN_WGRAD_ASYNC=1)
 
     # ---- reference API ----------------------------------------------------------------------------------------------
     def fuse(self):

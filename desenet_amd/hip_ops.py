@@ -438,10 +438,8 @@ class WgradQueue:
         self.keep.append((x, dy, dw))
         self.n += 1
 
-    def flush(self, reset_arena: bool = True):
-        """Launch every queued job (three launches).  reset_arena=False (a group launched on a side stream while the backward
-        pass goes on): the slab arena keeps growing for the jobs still to come and the operands / slabs of this group are RETURNED
-        for the caller to hold until that stream has been joined."""
+    def flush(self):
+        """Launch every queued job (the grouped gather launches + the slab reduction)."""
         keep = self.keep
         if self.n:
             L = _lib.lib()
@@ -455,11 +453,6 @@ class WgradQueue:
                 ev.record()
                 self._pool()["events"][self.slot] = ev
             _lib.check(L.dsn_conv2d_wgrad_run(dev.data_ptr(), self.n, launch, stream_ptr()), "conv2d_wgrad_run")
-        if not reset_arena:
-            if self.n:
-                keep = list(keep) + [dev]
-            self.n, self.keep, self.host = 0, [], None
-            return keep
         if self.extra and not torch.cuda.is_current_stream_capturing():
             need = self.offset + self.extra      # everything is enqueued on this stream: safe to replace the arena now
             _retire(_wgrad_arena.get(self.device))     # (a captured graph keeps replaying into the arena it was captured with)

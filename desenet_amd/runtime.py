@@ -51,24 +51,6 @@ def set_wgrad_side_stream(on: bool):
     _use_side_stream = bool(on)
 
 
-# Queued weight gradients launched in several groups DURING the backward pass on a second stream (a parallel branch of the captured
-# graph): the dgrad / BatchNorm chain is a string of small latency-bound kernels that leaves most CUs idle, and nothing but the
-# optimizer waits for dW.  tools/graph_branches.py: two independent conv + BN chains captured as branches of one hipGraph replay in
-# 1344 us against 1974 us back to back (8 x 128 x 80 x 80), 760 against 877 us at 40 x 40 -- unlike chains of one-block kernels,
-# which get slower (999 vs 617 us: the branch bookkeeping costs more than the kernels).
-_wgrad_async = bool(int(_os.environ.get("DSN_WGRAD_ASYNC", "0")))
-_async_streams = {}
-
-
-def set_wgrad_async(on: bool):
-    global _wgrad_async
-    _wgrad_async = bool(on)
-
-
-def wgrad_async() -> bool:
-    return _wgrad_async and not _use_side_stream and not _no_queue
-
-
 def wgrad_stream(device):
     if not _use_side_stream:
         return None
@@ -260,23 +242,6 @@ class Tape:
             self.forked.add(side)
         return side
 
-    def flush_wgrad_async(self):
-        """Launch the weight-gradient jobs queued so far on the side stream (a branch of the captured graph) and keep walking
-        the backward chain on the current one.  Operands and slabs stay referenced until join()."""
-        q = getattr(self, "wq", None)
-        if q is None or q.n == 0 or not wgrad_async():
-            return
-        dev = q.device
-        side = _async_streams.get(dev)
-        if side is None:
-            side = _async_streams[dev] = torch.cuda.Stream(device=dev)
-        cur = torch.cuda.current_stream(dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            keep = q.flush(reset_arena=False)
-        self.__dict__.setdefault("_async_keep", []).append(keep)
-        self.forked.add(side)
-
     def join(self):
         """End of a backward pass: launch the queued weight gradients; the current stream waits for every side stream used
         since begin_backward()."""
@@ -286,7 +251,6 @@ class Tape:
         for side in getattr(self, "forked", ()):
             torch.cuda.current_stream(side.device).wait_stream(side)
         self.forked = set()
-        self.__dict__.pop("_async_keep", None)
 
     def pop(self):
         self.cursor -= 1
