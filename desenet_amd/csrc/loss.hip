@@ -417,21 +417,24 @@ constexpr int SCU_ROWS = 4;        // low-resolution rows a band of <= 8 output 
 // back through the separable interpolation weights as two GATHERS (first along x, then along y): no atomics inside the block,
 // a fixed summation order; only the hand-over of the (<= 4 x wl x C) band result to the global accumulator uses atomics, because
 // neighbouring bands share low-resolution rows.
+// NT threads per block: 512 halves the serial per-thread pixel loop (20 -> 10 pixels of exp / log each at 640 x 640); the grid is one
+// round of blocks either way (LDS allows three per CU)
+constexpr int SCU_NT = 512;
 template <typename T, int C>
-__global__ __launch_bounds__(256) void seg_ce_up_kernel(const T* __restrict__ lg, int64_t ld, int hl, int wl, int H, int W, int RB,
+__global__ __launch_bounds__(SCU_NT) void seg_ce_up_kernel(const T* __restrict__ lg, int64_t ld, int hl, int wl, int H, int W, int RB,
                                                         float sh, float sw, const int64_t* __restrict__ target, int ignore,
                                                         float* __restrict__ gacc, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     float* s_gh = s_dyn;                            // [RB][W][C]
     float* s_tx = s_gh + (size_t)RB * W * C;        // [RB][wl][C]
     float* s_lg = s_tx + (size_t)RB * wl * C;       // [SCU_ROWS][wl][C]
-    __shared__ float red[2][256];
+    __shared__ float red[2][SCU_NT];
     const int nb = (H + RB - 1) / RB;
     const int n = blockIdx.x / nb, band = blockIdx.x - n * nb;
     const int Y0 = band * RB;
     const int rows = (Y0 + RB <= H) ? RB : H - Y0;
     const int ylo0 = lerp_ac(Y0, sh, hl).i0;
-    for (int i = threadIdx.x; i < SCU_ROWS * wl * C; i += 256) {
+    for (int i = threadIdx.x; i < SCU_ROWS * wl * C; i += SCU_NT) {
         const int c = i % C, x = (i / C) % wl, r = i / (C * wl);
         const int yl = ylo0 + r;
         s_lg[i] = yl < hl ? to_f32<T>(lg[(((int64_t)n * hl + yl) * wl + x) * ld + c]) : 0.f;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256) void seg_ce_up_kernel(const T* __restrict__ lg
     __syncthreads();
     float s = 0.f, cnt = 0.f;
     const int64_t* tg = target + ((int64_t)n * H + Y0) * W;
-    for (int p = threadIdx.x; p < rows * W; p += 256) {
+    for (int p = threadIdx.x; p < rows * W; p += SCU_NT) {
         const int yr = p / W, X = p - yr * W;
         const int64_t t = tg[p];
         float gh[C];
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void seg_ce_up_kernel(const T* __restrict__ lg
     // stage 2a: along x.  Low-resolution column xl receives l0 from the pixels whose left neighbour it is and l1 from those whose
     // right neighbour it is: sw * X in [xl - 1, xl + 1)
     const float isw = 1.f / sw;
-    for (int i = threadIdx.x; i < rows * wl * C; i += 256) {
+    for (int i = threadIdx.x; i < rows * wl * C; i += SCU_NT) {
         const int c = i % C, xl = (i / C) % wl, yr = i / (C * wl);
         int xlo = (int)((float)(xl - 1) * isw) - 1, xhi = (int)((float)(xl + 1) * isw) + 1;
         xlo = xlo < 0 ? 0 : xlo;
@@ -487,13 +490,13 @@ __global__ __launch_bounds__(256) void seg_ce_up_kernel(const T* __restrict__ lg
         }
         s_tx[i] = acc;
     }
-    for (int t = 128; t > 0; t >>= 1) {
+    for (int t = SCU_NT / 2; t > 0; t >>= 1) {
         if ((int)threadIdx.x < t) { red[0][threadIdx.x] += red[0][threadIdx.x + t]; red[1][threadIdx.x] += red[1][threadIdx.x + t]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
     // stage 2b: along y, then the band's contribution to the (zero-initialised) global accumulator
-    for (int i = threadIdx.x; i < SCU_ROWS * wl * C; i += 256) {
+    for (int i = threadIdx.x; i < SCU_ROWS * wl * C; i += SCU_NT) {
         const int r = i / (C * wl), yl = ylo0 + r;
         if (yl >= hl) continue;
         float acc = 0.f;
@@ -650,7 +653,7 @@ extern "C" int dsn_seg_ce_up(const dsn_tensor* logits, const int64_t* target, in
             (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             attr_done = true;
         }
-        hipLaunchKernelGGL((seg_ce_up_kernel<T, 2>), dim3(nb), dim3(256), lds, st, (const T*)logits->ptr, logits->ldc, hl, wl, H, W, RB,
+        hipLaunchKernelGGL((seg_ce_up_kernel<T, 2>), dim3(nb), dim3(SCU_NT), lds, st, (const T*)logits->ptr, logits->ldc, hl, wl, H, W, RB,
                            sh, sw, target, ignore_index, gacc, partial);
         hipLaunchKernelGGL(seg_ce_up_finalize_kernel<T>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, partial, nb, gacc, npx, C,
                            (T*)dlogits->ptr, dlogits->ldc, gain, out);
