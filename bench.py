@@ -177,9 +177,15 @@ def roofline_from_profile(prof, steps, dtype):
                  "flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
                  # PMC bytes per launch (profiles/traffic.json, keyed by symbol family / dtype / tile: fwd and dgrad share a symbol)
                  "traffic": _traffic_table().get(name, _traffic_table().get(name.rsplit("/", 1)[0])),
-                 "timing": "HIP events around the same launches on eager steps right after the timed hipGraph replays "
-                           "(10-15 % above their duration under replay: profiles/*_kernel_stats.csv hold the rocprofv3 view)"})
+                 "timing": "HIP events around the same launches on eager steps right after the timed hipGraph replays, minus one "
+                           f"queue marker (half of what an EMPTY event pair measures on that stream: {_pair_overhead_us():.2f} us "
+                           "subtracted per launch); profiles/*_kernel_stats.csv hold the rocprofv3 view of the replayed step"})
     return roof, table
+
+
+def _pair_overhead_us():
+    from desenet_amd import hip_ops
+    return hip_ops.last_event_pair_overhead_us
 
 
 def roofline_by_layer(layers, steps, train):

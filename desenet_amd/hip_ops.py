@@ -1080,6 +1080,9 @@ def profile_enable(on: bool):
     _lib.check(_lib.lib().dsn_profile_enable(int(on)), "profile_enable")
 
 
+last_event_pair_overhead_us = 0.0
+
+
 def profile_collect(by_layer: bool = False):
     """{label: dict(launches, ms, flops, bytes)} for every kernel launched since profile_enable(True); label = rocprofv3 symbol
     family / dtype / tile / direction for the convolutions.  by_layer=True: (that dict, {(label, layer): dict(...)})."""
@@ -1092,8 +1095,12 @@ def profile_collect(by_layer: bool = False):
     if rc < 0:
         _lib.check(-rc, "profile_dump")
     out, layers = {}, {}
+    global last_event_pair_overhead_us
     for line in buf.value.decode().splitlines():
         label, layer, n, ms, fl, by = line.split("\t")
+        if label == "__event_pair_overhead":       # what the library subtracted from every record (one queue marker)
+            last_event_pair_overhead_us = float(ms) * 1e3
+            continue
         rec = dict(launches=int(float(n)), ms=float(ms), flops=float(fl), bytes=float(by))
         layers[(label, layer)] = rec
         a = out.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
