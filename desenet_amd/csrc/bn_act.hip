@@ -509,6 +509,11 @@ inline Strip make_strip(int64_t P, int C, int V, int max_blocks, int* nblocks, b
     if (!adaptive) u = UNROLL;      // reductions: every block ends with an LDS fold + 2C atomics -> fewer, fatter blocks
     int64_t per = (int64_t)TY * u;
     int64_t nb = (P + per - 1) / per;
+    // every block of the elementwise kernels folds the accumulators of ALL C channels in its prologue (16 loads + fp64 math per channel):
+    // past two blocks per CU more blocks only repeat that.  Measured (DSN_EW_MAXB, 0 = the launch's own cap): 256 -> 1933, 384 -> 1944,
+    // 512 -> 1972, 768 -> 1967, 1024 -> 1961, uncapped 1951 img/s on config 3; config 5 197.7 -> 200.9.
+    static const int maxb = [] { const char* e = getenv("DSN_EW_MAXB"); return e ? atoi(e) : 512; }();
+    if (adaptive && maxb > 0 && max_blocks > maxb) max_blocks = maxb;
     if (nb > max_blocks) {
         per = (P + max_blocks - 1) / max_blocks;
         per = (per + TY - 1) / TY * TY;
