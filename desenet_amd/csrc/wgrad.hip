@@ -978,10 +978,12 @@ inline int choose_split(const WGeom& g, bool alltaps = false, bool t128 = false)
     const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
     static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 320; }();
     static const int scap = [] { const char* e = getenv("DSN_WGRAD_SCAP"); return e ? atoi(e) : 256; }();
-    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 4096; }();
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_MINPX"); return e ? atoi(e) : 2048; }();
     // (re-measured with the grouped launches, MI355X: blocks 288..352 x minpx 4096..5120 is a plateau -- 0.54 ms gather + 0.06 ms
-    //  slab reduce; 256 / 1024 was 0.56 + 0.14: four times the slab traffic for parallelism the shared grids no longer need)
-    static const int target128 = [] { const char* e = getenv("DSN_WGRAD_BLOCKS128"); return e ? atoi(e) : 64; }();     // (sweep: 64..128 best on config 5, flat on config 3)
+    //  slab reduce; 256 / 1024 was 0.56 + 0.14: four times the slab traffic for parallelism the shared grids no longer need.
+    //  Round 3, with the 256-output slab reduction: minpx 2048 + 96 blocks per 128-wide job -1.2 % on the config-3 step (4.115 ->
+    //  4.065 ms), 1024 / 3072 / 8192 worse, config 5 flat)
+    static const int target128 = [] { const char* e = getenv("DSN_WGRAD_BLOCKS128"); return e ? atoi(e) : 96; }();     // (sweep: 64..128 best on config 5)
     const int tgt = alltaps ? target / 2 : (t128 ? target128 : target), cap = alltaps ? scap * 2 : scap;   // all-taps blocks are 9x heavier
     int64_t s = (tgt + base - 1) / base;
     const int64_t smax = (g.P + minpx - 1) / minpx;
