@@ -18,7 +18,7 @@ constexpr int THREADS = 256;
 // (Issuing the first batch above the prologue -- to overlap the accumulator fold with the operands' latency -- measured 2.6 %
 // SLOWER at equal occupancy, and 1 vector per batch 1.2 % slower than 2.)
 constexpr int UNROLL = 2;
-constexpr int MAX_RED_BLOCKS = 1024;
+constexpr int MAX_RED_BLOCKS = 512;   // (round 3: 256 / 512 / 1024 / 2048 -> 1985 / 1990 / 1984 / 1980 img/s on config 3)
 
 // V consecutive per-channel fp32 constants (c0 is a multiple of V, arrays are 32-byte aligned): 16-byte loads instead of V
 // scalar ones -- a thread used to issue up to 48 scalar loads of constants before touching its 2-8 data vectors.
