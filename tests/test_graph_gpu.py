@@ -366,5 +366,9 @@ print("LOSSES " + json.dumps(losses))
         curves[tag] = json.loads(line[0][7:])
     a, b = curves["default"], curves["conservative"]
     assert all(x == x for x in a + b) and a[-1] < a[0]
+    # Two runs of the SAME selection differ by up to 0.4 % at step 11 (fp64 atomics fold the BatchNorm partials in arrival order), the
+    # conservative selection by 1.5-2.2 % (tools/exp/traj.py, round 3): the bound on the whole curve is 4 %, and the first three steps
+    # -- where a wrong kernel shows, before the optimizer's feedback amplifies rounding -- must agree to 5e-3.
+    early = max(abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a[:3], b[:3]))
     worst = max(abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a, b))
-    assert worst < 2e-2, (worst, a, b)
+    assert early < 5e-3 and worst < 4e-2, (early, worst, a, b)
