@@ -65,3 +65,26 @@ def test_bnred_plan_refuses_what_the_kernels_cannot_take():
     rec["bnred_cov"] = []
     rec["y"] = rec["y"].float()
     assert conv_impl._bnred_plan(tape, buf, dx, None) == (None, ())          # dtype mismatch between y and dx
+
+
+def test_fused_pyramid_pooling_eligibility_is_a_host_decision():
+    """dsn_pp_stages_supported (pure host code): bf16, 16-byte channel vectors, at most 512 pixels per branch, and the branch's tiles
+    must fit the 160 KB of LDS of one CU -- DeSeNet-s (8 x 6 x 6 pixels, 128 -> 32) does, 64 pixels of 256 -> 64 do, 144 or 288 pixels
+    of 256 -> 64 do not; PyramidPooling._fusable refuses everything that is not a bf16 training step."""
+    import ctypes
+    from desenet_amd import _lib
+    L = _lib.lib()
+    bf16, f32 = _lib.DSN_BF16, _lib.DSN_F32
+    assert L.dsn_pp_stages_supported(288, 128, 32, bf16) == 1
+    assert L.dsn_pp_stages_supported(64, 256, 64, bf16) == 1
+    assert L.dsn_pp_stages_supported(144, 256, 64, bf16) == 0          # does not fit LDS
+    assert L.dsn_pp_stages_supported(288, 256, 64, bf16) == 0
+    assert L.dsn_pp_stages_supported(288, 128, 32, f32) == 0           # bf16 only
+    assert L.dsn_pp_stages_supported(288, 124, 32, bf16) == 0          # 16-byte channel vectors
+    assert L.dsn_pp_stages_supported(600, 32, 8, bf16) == 0            # more than 512 pixels per branch
+    from desenet_amd.core.models.common import PyramidPooling
+    pp = PyramidPooling(128).train()
+    x = torch.zeros(2, 128, 8, 8, dtype=torch.bfloat16)
+    assert pp._fusable(x, [1, 2, 3, 6], tape=None) is False             # no tape: not a training step of this package
+    assert pp.eval()._fusable(x, [1, 2, 3, 6], tape=object()) is False
+    assert pp.train()._fusable(x.float(), [1, 2, 3, 6], tape=object()) is False
