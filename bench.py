@@ -201,8 +201,11 @@ def roofline_by_layer(layers, steps, train):
             continue
         sym, dt, tile, direction = (label.split("/") + ["", "", "", ""])[:4]
         peak_tf = PEAK["mfma_bf16_TFs"] if dt == "bf16" else PEAK["mfma_f32_TFs"]
-        geom, chans = layer.split(" ")[0], layer.split(" ")[1]
-        ci, co = (int(v) for v in chans.split("->"))
+        try:
+            geom, chans = layer.split(" ")[0], layer.split(" ")[1]
+            ci, co = (int(v) for v in chans.split("->"))
+        except (IndexError, ValueError):
+            continue                     # (a labelled launch that is not a convolution layer)
         sec = r["ms"] * 1e-3
         row = {"kernel": label, "layer": layer, "launches_per_step": r["launches"] / steps,
                "avg_us": r["ms"] / r["launches"] * 1e3, "TFLOPs": r["flops"] / sec / 1e12, "GBs": r["bytes"] / sec / 1e9,

@@ -164,6 +164,8 @@ PROTOTYPES = {
     "dsn_detect_decode": (i32, [TP, vp, vp, i64, i64, i32, i32, f32, vp, vp]),
     "dsn_detect_raw_bwd": (i32, [vp, TP, i32, i32, i32, vp]),
     "dsn_detect_decode_multi": (i32, [vp, vp, i32, vp, i64, vp, i32, i32, vp, vp, vp]),
+    "dsn_detect_head_fwd_supported": (i32, [i32, i32, i32, i32]),
+    "dsn_detect_head_fwd_multi": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "dsn_detect_raw_bwd_multi": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp]),
     "dsn_nms_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "dsn_nms": (i32, [vp, i32, i32, i32, f32, f32, i32, i32, u64, i32, vp, vp, vp, i64, vp]),

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 from copy import deepcopy
 from pathlib import Path
 
@@ -22,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip_ops as ops
-from ...conv_impl import conv_block_bwd, conv_block_fwd
+from ...conv_impl import _lazy_operand, conv_block_bwd, conv_block_fwd, packed_fwd
 from ...hip_ops import ACT_NONE
 from ...runtime import run_module
 from ..utils.autoanchor import check_anchor_order
@@ -117,6 +118,15 @@ class SegMaskPSP(HipModule):
         return dxs
 
 
+# the three head convolutions + permute of a training forward as one launch (DSN_DET_FUSED=0: conv per level + one permute launch)
+_DET_FUSED = os.environ.get("DSN_DET_FUSED", "1") != "0"
+
+
+def _conv_is_not_plain_1x1(m) -> bool:
+    return not (isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
+                and m.dilation == (1, 1) and m.groups == 1)
+
+
 class Detect(HipModule):
     stride = None
     onnx_dynamic = False
@@ -150,6 +160,9 @@ class Detect(HipModule):
         total = sum(self.na * t.shape[2] * t.shape[3] for t in xs)
         pred = None if self.training else torch.empty((n, total, self.no), dtype=torch.float32, device=dev)
         raws, row = [], 0
+        if self.training and tape is not None and _DET_FUSED and self._fwd_fused(xs, tape, raws):
+            tape.push([(tuple(x.shape), x.dtype) for x in xs])
+            return raws
         anchors_px = self.anchor_grid.view(self.nl, self.na, 2).float().contiguous()
         ts, rows = [], []
         for i, x in enumerate(xs):               # the three head convs, then ONE decode launch for all levels
@@ -163,6 +176,30 @@ class Detect(HipModule):
         if tape is not None:
             tape.push([(tuple(x.shape), x.dtype) for x in xs])
         return raws if self.training else (pred, raws)
+
+    def _fwd_fused(self, xs, tape, raws) -> bool:
+        """Training forward of all levels as ONE launch (ops.detect_head_fwd: 1x1 conv + bias + permute); leaves on the tape the
+        records conv_block_fwd would have pushed, so bwd() is unchanged.  False (nothing done) when the kernel does not take it."""
+        dt = xs[0].dtype
+        if any(x.dtype != dt for x in xs) or any(_conv_is_not_plain_1x1(m) for m in self.m) \
+                or not ops.detect_head_fwd_supported(dt, self.na, self.no, [x.shape[1] for x in xs]):
+            return False
+        xm = []
+        for x in xs:
+            xi, lz, zx = _lazy_operand(tape, x, 1)
+            if lz is not None:                 # (consumer-side BatchNorm requested for this input: the per-level path handles it)
+                return False
+            xm.append(xi)
+        if not all(ops._vec16(x) for x in xm):
+            return False
+        n = xm[0].shape[0]
+        packed = [packed_fwd(m, dt, None, None) for m in self.m]
+        for x in xm:
+            raws.append(torch.empty((n, self.na, x.shape[2], x.shape[3], self.no), dtype=torch.float32, device=x.device))
+        ops.detect_head_fwd(xm, [w for w, _ in packed], [b for _, b in packed], raws, self.na, self.no)
+        for i, m in enumerate(self.m):
+            tape.push(dict(conv=m, bn=None, act=ACT_NONE, x=xm[i], x_in=xs[i], ci_pad=None, geom=(1, 1, 0, 1), plain=True, y=None))
+        return True
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         metas = tape.pop()

@@ -90,26 +90,28 @@ struct DetectLevels {
     int32_t nl, N, na, no;
 };
 
-template <typename T>
+// I: index type -- uint32_t whenever every level's element count fits (64-bit divisions cost ~4x as many instructions, and this
+// kernel runs five of them per element)
+template <typename T, typename I>
 __global__ __launch_bounds__(256) void detect_decode_multi_kernel(const DetectLevels L, float* __restrict__ pred, int64_t pred_rows,
                                                                   const float* __restrict__ anchors) {
     const int l = blockIdx.y;
     const int ny = L.ny[l], nx = L.nx[l], na = L.na, no = L.no, C = na * no;
     const T* __restrict__ t = (const T*)L.t[l];
     float* __restrict__ raw = L.raw[l];
-    const int64_t tld = L.tld[l], total = (int64_t)L.N * ny * nx * C;
+    const int64_t tld = L.tld[l];
+    const I total = (I)L.N * (I)(ny * nx) * (I)C, HW = (I)(ny * nx);
     const float stride = L.stride[l];
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(i % C);
-        int64_t p = i / C;
-        const int x = (int)(p % nx);
-        int64_t q = p / nx;
-        const int y = (int)(q % ny);
-        const int n = (int)(q / ny);
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
+        const I p = i / (I)C;
+        const int ch = (int)(i - p * (I)C);
+        const I n = p / HW;
+        const int cellp = (int)(p - n * HW);
+        const int y = cellp / nx, x = cellp - y * nx;
         const int a = ch / no, o = ch - a * no;
-        const float v = to_f32<T>(t[p * tld + ch]);
-        const int64_t cell = ((int64_t)a * ny + y) * nx + x;
-        raw[(((int64_t)n * na * ny * nx) + cell) * no + o] = v;
+        const float v = to_f32<T>(t[(int64_t)p * tld + ch]);
+        const int64_t cell = (int64_t)a * (int64_t)HW + cellp;
+        raw[(((int64_t)n * na * (int64_t)HW) + cell) * no + o] = v;
         if (pred) {
             const float s = 1.0f / (1.0f + expf(-v));
             float r;
@@ -132,27 +134,28 @@ __global__ __launch_bounds__(256) void detect_raw_bwd_multi_kernel(const DetectL
     const int ny = L.ny[l], nx = L.nx[l], na = L.na, no = L.no, C = na * no, Cw = L.cw[l];
     const float* __restrict__ draw = L.raw[l];
     T* __restrict__ dt = (T*)L.t[l];
-    const int64_t tld = L.tld[l], total = (int64_t)L.N * ny * nx * Cw;
+    const int64_t tld = L.tld[l];
     __shared__ float sh[64];
     if (threadIdx.x < 64) sh[threadIdx.x] = 0.f;
     __syncthreads();
-    const int64_t i0 = blockIdx.x * 256ll + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * 256 / Cw * Cw;          // whole pixels per sweep: the channel of a thread is fixed
-    const int ch = (int)(i0 % Cw);
+    // 32-bit index arithmetic, one division per element (the host checks N * ny * nx < 2^31): the 64-bit i / Cw, p % nx, q % ny,
+    // q / ny chain this loop used to run per element cost more than the memory traffic
+    const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+    const unsigned pstep = gridDim.x * 256u / (unsigned)Cw;           // whole pixels per sweep: the channel of a thread is fixed
+    const unsigned pfirst = i0 / (unsigned)Cw;
+    const int ch = (int)(i0 - pfirst * (unsigned)Cw);
     const int a = ch / no, o = ch - a * no;
+    const unsigned HW = (unsigned)(ny * nx), P = (unsigned)L.N * HW;
     float s = 0.f;
-    for (int64_t i = i0; i < total && i0 < step; i += step) {
-        const int64_t p = i / Cw;
-        const int x = (int)(p % nx);
-        const int64_t q = p / nx;
-        const int y = (int)(q % ny);
-        const int n = (int)(q / ny);
-        const float v = ch < C ? draw[((((int64_t)n * na + a) * ny + y) * nx + x) * no + o] : 0.f;
-        dt[p * tld + ch] = from_f32<T>(v);
-        s += v;
-    }
+    if (pfirst < pstep)
+        for (unsigned p = pfirst; p < P; p += pstep) {
+            const unsigned n = p / HW, q = p - n * HW;
+            const float v = ch < C ? draw[(((int64_t)n * na + a) * HW + q) * no + o] : 0.f;
+            dt[(int64_t)p * tld + ch] = from_f32<T>(v);
+            s += v;
+        }
     if (L.part[l]) {
-        if (ch < C && i0 < step) atomicAdd(&sh[ch], s);
+        if (ch < C && pfirst < pstep) atomicAdd(&sh[ch], s);
         __syncthreads();
         if ((int)threadIdx.x < C) L.part[l][(int64_t)blockIdx.x * C + threadIdx.x] = sh[threadIdx.x];
     }
@@ -654,9 +657,15 @@ extern "C" int dsn_detect_decode_multi(const dsn_tensor* ts, float* const* raws,
         const int64_t tot = npix(&ts[l]) * ts[l].c;
         most = tot > most ? tot : most;
     }
-    DSN_DISPATCH_DTYPE(ts[0].dtype, T,
-                       hipLaunchKernelGGL(detect_decode_multi_kernel<T>, dim3(ew_grid(most), nl), dim3(256), 0, (hipStream_t)stream, L,
-                                          pred, pred_rows, anchors_px));
+    if (most + 256ll * ew_grid(most) < (1ll << 32)) {
+        DSN_DISPATCH_DTYPE(ts[0].dtype, T,
+                           hipLaunchKernelGGL((detect_decode_multi_kernel<T, uint32_t>), dim3(ew_grid(most), nl), dim3(256), 0,
+                                              (hipStream_t)stream, L, pred, pred_rows, anchors_px));
+    } else {
+        DSN_DISPATCH_DTYPE(ts[0].dtype, T,
+                           hipLaunchKernelGGL((detect_decode_multi_kernel<T, int64_t>), dim3(ew_grid(most), nl), dim3(256), 0,
+                                              (hipStream_t)stream, L, pred, pred_rows, anchors_px));
+    }
     DSN_LAUNCH_CHECK("detect_decode_multi");
     return DSN_OK;
 }
@@ -684,6 +693,7 @@ extern "C" int dsn_detect_raw_bwd_multi(const float* const* draws, const dsn_ten
         L.part[l] = bias_grads ? (float*)workspace + (int64_t)l * MAXB * C : nullptr;
         L.bias_grad[l] = bias_grads ? bias_grads[l] : nullptr;
         if (bias_grads) DSN_CHECK_ARG(bias_grads[l], "detect_raw_bwd_multi: null bias gradient for level %d", l);
+        DSN_CHECK_ARG(npix(&dts[l]) < (1ll << 31), "detect_raw_bwd_multi: level %d has 2^31 or more pixels", l);
         const int64_t tot = npix(&dts[l]) * L.cw[l];
         most = tot > most ? tot : most;
     }
@@ -694,6 +704,181 @@ extern "C" int dsn_detect_raw_bwd_multi(const float* const* draws, const dsn_ten
                        hipLaunchKernelGGL(detect_raw_bwd_multi_kernel<T>, dim3((unsigned)blocks, nl), dim3(256), 0, st, L));
     if (bias_grads) hipLaunchKernelGGL(detect_bias_finalize_kernel, dim3(C, nl), dim3(64), 0, st, L, (int)blocks);
     DSN_LAUNCH_CHECK("detect_raw_bwd_multi");
+    return DSN_OK;
+}
+
+// ---- the three head convolutions + permute of a TRAINING forward as one launch (round 3) -------------------------------------------
+// yolo.py:258-276 runs, per level, a biased 1x1 convolution to na*no channels and a view/permute to [N][na][ny][nx][no].  As
+// separate launches that was 3 implicit-GEMM kernels (7-11 us each: 33 output channels leave every tile 3/4 empty) + the permute
+// launch (14 us) = 39 us of a 4 ms step for 0.76 GFLOP.  Here a block owns 64 pixels x all head channels (<= 64): the operands are
+// read straight from global memory in MFMA fragment order (16-byte loads; the weights, <= 64 KB per level, stay in L2), the
+// result goes through the SAME bf16 rounding the convolution's output had and lands in raw[] permuted.
+struct DetHeadLevels {
+    const void* x[DET_MAXL];
+    const void* w[DET_MAXL];       // [na*no][K] bf16 (dsn_pack_weight_fwd)
+    const float* bias[DET_MAXL];   // may be NULL
+    float* raw[DET_MAXL];
+    int64_t xld[DET_MAXL];
+    int32_t ny[DET_MAXL], nx[DET_MAXL], K[DET_MAXL];
+    int32_t blk0[DET_MAXL + 1];
+    int32_t nl, N, na, no;
+    uint32_t no_magic;             // floor(2^32 / no) + 1: __umulhi(v, no_magic) == v / no for v < 2^16
+};
+constexpr int DH_MI = 4;                    // 16-pixel fragments per block (64 pixels)
+constexpr int DH_PX = 16 * DH_MI;
+constexpr int DH_PITCH = DH_PX + 4;         // floats per channel row of the partial sums: 4 * 68 = 16 (mod 64) keeps the 4 k-groups in 4 bank quarters
+
+// A block owns 64 pixels x all head channels; its 4 waves split the K axis (wave w takes the 32-wide k-steps w, w + 4, ...), so
+// the 80 x 80 level (K = 128, most of the pixels) is ONE step per wave = one round trip, with few enough registers and LDS that
+// (nearly) every block of the launch is resident at once -- the launch is bound by the latency chain of a block times the number
+// of block rounds, not by bytes or flops (measured: 12 us for that level alone with 32-pixel blocks at 3 blocks per CU).  The
+// four partial tiles are folded through LDS in a fixed order ((w0 + w2) + (w1 + w3)) and written [anchor][pixel][no]-major:
+// consecutive threads, consecutive addresses.  No hardware divisions per element (they alone cost 17 us in the first version).
+template <int NI>
+__global__ __launch_bounds__(256) void detect_head_fwd_kernel(const DetHeadLevels L) {
+    __shared__ float sP[2][NI * 16 * DH_PITCH];
+    __shared__ float sB[NI * 16];
+    int l = 0;
+    while (l + 1 < L.nl && (int)blockIdx.x >= L.blk0[l + 1]) ++l;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int HW = L.ny[l] * L.nx[l], K = L.K[l], no = L.no, C = L.na * no;
+    const int M = L.N * HW;                                   // (the host checks N * ny * nx < 2^31)
+    const int p0 = ((int)blockIdx.x - L.blk0[l]) * DH_PX;
+    const bf16_t* __restrict__ x = (const bf16_t*)L.x[l];
+    const bf16_t* __restrict__ w = (const bf16_t*)L.w[l];
+    // (the bias goes through LDS: a global load per output element made the epilogue a chain of L2 round trips)
+    if ((int)threadIdx.x < NI * 16) sB[threadIdx.x] = (L.bias[l] && (int)threadIdx.x < C) ? L.bias[l][threadIdx.x] : 0.f;
+    const bf16_t* xp[DH_MI];
+    const bf16_t* wp[NI];
+    bool wv[NI];
+#pragma unroll
+    for (int mi = 0; mi < DH_MI; ++mi) {
+        int p = p0 + mi * 16 + r;
+        p = p < M ? p : M - 1;                       // (rows past the end compute a duplicate that is never stored)
+        xp[mi] = x + (int64_t)p * L.xld[l];
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int c = ni * 16 + r;
+        wv[ni] = c < C;
+        wp[ni] = w + (int64_t)(wv[ni] ? c : C - 1) * K;
+    }
+    f32x4 acc[NI][DH_MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < DH_MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = wave * 32; kb < K; kb += 128) {
+        const int k = kb + kg * 8;                            // (K % 8 == 0: a lane's 8 values are all inside or all outside)
+        const bool kv = k < K;
+        const int ko = kv ? k : 0;
+        u32x4 xa[DH_MI], wa[NI];
+#pragma unroll
+        for (int mi = 0; mi < DH_MI; ++mi) {
+            xa[mi] = *reinterpret_cast<const u32x4*>(xp[mi] + ko);
+            if (!kv) xa[mi] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            wa[ni] = *reinterpret_cast<const u32x4*>(wp[ni] + ko);
+            if (!wv[ni]) wa[ni] = u32x4{0u, 0u, 0u, 0u};
+        }
+        // D[channel][pixel] += W[channel][k] * X[pixel][k]: a lane ends up with 4 consecutive channels of one pixel
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < DH_MI; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[ni]), __builtin_bit_cast(bf16x8, xa[mi]),
+                                                                      acc[ni][mi], 0, 0, 0);
+    }
+    float* sMine = sP[wave & 1];
+    if (wave < 2) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < DH_MI; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sMine[(ni * 16 + kg * 4 + i) * DH_PITCH + mi * 16 + r] = acc[ni][mi][i];
+    }
+    __syncthreads();
+    if (wave >= 2) {                                           // (each lane adds into the very elements its counterpart wrote)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < DH_MI; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sMine[(ni * 16 + kg * 4 + i) * DH_PITCH + mi * 16 + r] += acc[ni][mi][i];
+    }
+    __syncthreads();
+    float* __restrict__ raw = L.raw[l];
+    const int per_a = DH_PX * no, total = L.na * per_a;
+    const int n0 = p0 / HW, q0 = p0 - n0 * HW;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int a = (int)__umulhi((unsigned)(e / DH_PX), L.no_magic), rem = e - a * per_a;       // e / (DH_PX * no)
+        const int pix = (int)__umulhi((unsigned)rem, L.no_magic), o = rem - pix * no;              // rem / no, exact for rem < 2^16
+        if (p0 + pix >= M) continue;
+        int n = n0, q = q0 + pix;
+        while (q >= HW) { q -= HW; ++n; }
+        const int c = a * no + o;
+        const int at = c * DH_PITCH + pix;
+        const float v = (sP[0][at] + sP[1][at]) + sB[c];
+        raw[(((int64_t)n * L.na + a) * HW + q) * no + o] = to_f32<bf16_t>(from_f32<bf16_t>(v));
+    }
+}
+
+extern "C" int dsn_detect_head_fwd_supported(int32_t dtype, int32_t na, int32_t no, int32_t k_min_multiple) {
+    return dtype == DSN_BF16 && na > 0 && no >= 2 && na * no <= 64 && k_min_multiple > 0 && k_min_multiple % 8 == 0;
+}
+
+// xs[l]: bf16 head inputs (channels % 8 == 0, 16-byte rows), ws[l]: packed forward weights [na*no][K], biases[l]: fp32 or NULL,
+// raws[l]: fp32 [N][na][ny][nx][no].  DSN_EUNSUPPORTED (nothing launched) outside dsn_detect_head_fwd_supported.
+extern "C" int dsn_detect_head_fwd_multi(const dsn_tensor* xs, const void* const* ws, const float* const* biases, float* const* raws,
+                                         int32_t nl, int32_t na, int32_t no, void* stream) {
+    DSN_CHECK_ARG(xs && ws && raws && nl >= 1 && nl <= DET_MAXL && na > 0 && no > 0, "detect_head_fwd_multi: invalid arguments");
+    const int C = na * no;
+    DetHeadLevels L{};
+    L.nl = nl; L.N = xs[0].n; L.na = na; L.no = no;
+    L.no_magic = (uint32_t)((1ull << 32) / (uint64_t)no) + 1u;
+    int blk = 0;
+    double flops = 0, bytes = 0;
+    for (int l = 0; l < nl; ++l) {
+        DSN_CHECK_ARG(tensor_ok(&xs[l]) && ws[l] && raws[l] && xs[l].n == L.N && npix(&xs[l]) < (1ll << 31) - DH_PX,
+                      "detect_head_fwd_multi: level %d is malformed", l);
+        if (!dsn_detect_head_fwd_supported(xs[l].dtype, na, no, xs[l].c) || xs[l].ldc % 8 != 0 ||
+            ((uintptr_t)xs[l].ptr | (uintptr_t)ws[l]) % 16 != 0)
+            return DSN_EUNSUPPORTED;
+        flops += 2.0 * npix(&xs[l]) * C * xs[l].c;
+        bytes += (double)npix(&xs[l]) * (xs[l].c * 2.0 + C * 4.0) + (double)C * xs[l].c * 2.0;
+    }
+    // block ranges by DECREASING K: a block of the deepest level walks the most k-steps one after the other, so those start first
+    // and the short-chain blocks of the large maps fill the tail of the launch
+    int order[DET_MAXL];
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    for (int i = 1; i < nl; ++i)
+        for (int j = i; j > 0 && xs[order[j]].c > xs[order[j - 1]].c; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int s = 0; s < nl; ++s) {
+        const int l = order[s];
+        L.x[s] = xs[l].ptr; L.w[s] = ws[l]; L.bias[s] = biases ? biases[l] : nullptr; L.raw[s] = raws[l];
+        L.xld[s] = xs[l].ldc; L.ny[s] = xs[l].h; L.nx[s] = xs[l].w; L.K[s] = xs[l].c;
+        L.blk0[s] = blk;
+        blk += (int)((npix(&xs[l]) + DH_PX - 1) / DH_PX);
+    }
+    L.blk0[nl] = blk;
+    hipStream_t st = (hipStream_t)stream;
+    char layer[64] = "";
+    if (dsn_prof_on()) {
+        int ksum = 0;
+        for (int l = 0; l < nl; ++l) ksum += xs[l].c;
+        snprintf(layer, sizeof layer, "k1s1 %d->%d detect-heads x%d n%d", ksum, C, nl, L.N);
+    }
+    ProfScope prof("detect_head_fwd_kernel/bf16/64x64/fwd", layer, flops, bytes, st);
+    if (C <= 16) hipLaunchKernelGGL(detect_head_fwd_kernel<1>, dim3(blk), dim3(256), 0, st, L);
+    else if (C <= 32) hipLaunchKernelGGL(detect_head_fwd_kernel<2>, dim3(blk), dim3(256), 0, st, L);
+    else if (C <= 48) hipLaunchKernelGGL(detect_head_fwd_kernel<3>, dim3(blk), dim3(256), 0, st, L);
+    else hipLaunchKernelGGL(detect_head_fwd_kernel<4>, dim3(blk), dim3(256), 0, st, L);
+    DSN_LAUNCH_CHECK("detect_head_fwd_multi");
     return DSN_OK;
 }
 

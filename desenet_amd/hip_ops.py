@@ -980,6 +980,25 @@ def detect_decode_multi(ts, raws, pred, row_offsets, na, no, strides, anchors_px
                "detect_decode_multi")
 
 
+def detect_head_fwd_supported(dtype, na, no, channels) -> bool:
+    """Can the three head convolutions + permute of a training forward run as ONE launch (detect_head_fwd)?"""
+    import math
+    k = 0
+    for c in channels:
+        k = math.gcd(k, int(c))
+    return bool(_lib.lib().dsn_detect_head_fwd_supported(_DT[dtype], na, no, k))
+
+
+def detect_head_fwd(xs, ws, biases, raws, na, no):
+    """raws[l] = permute(conv1x1(xs[l], ws[l]) + biases[l]) for every Detect level, one launch (training forward)."""
+    nl = len(xs)
+    arr = (dsn_tensor * nl)(*[desc(x) for x in xs])
+    wp = (C.c_void_p * nl)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * nl)(*[(b.data_ptr() if b is not None else None) for b in biases])
+    rp = (C.c_void_p * nl)(*[r.data_ptr() for r in raws])
+    _lib.check(_lib.lib().dsn_detect_head_fwd_multi(arr, wp, bp, rp, nl, na, no, stream_ptr()), "detect_head_fwd_multi")
+
+
 _det_ws = {}
 
 

@@ -394,6 +394,15 @@ int dsn_detect_raw_bwd(const float* draw, const dsn_tensor* dt, int32_t na, int3
 int dsn_detect_decode_multi(const dsn_tensor* ts, float* const* raws, int32_t nl, float* pred, int64_t pred_rows,
                             const int64_t* row_offs, int32_t na, int32_t no, const float* strides, const float* anchors_px,
                             void* stream);
+/* Training forward of ALL Detect heads in one launch (yolo.py:258-276: per level a biased 1x1 convolution to na*no channels,
+ * then view + permute to [N][na][ny][nx][no]): xs[l] bf16 head inputs (channels % 8 == 0), ws[l] packed forward weights
+ * [na*no][K] (dsn_pack_weight_fwd), biases[l] fp32 [na*no] (the array or an entry may be NULL), raws[l] fp32 outputs.  The result
+ * is rounded to bf16 on the way, as the head convolution's own output is.  na*no <= 64, bf16 only: DSN_EUNSUPPORTED (nothing
+ * launched) otherwise -- callers then run dsn_conv2d_fwd per level + dsn_detect_decode_multi.  _supported: the same predicate for
+ * host-side planning (k_min_multiple: any common divisor of the levels' input channel counts). */
+int dsn_detect_head_fwd_supported(int32_t dtype, int32_t na, int32_t no, int32_t k_min_multiple);
+int dsn_detect_head_fwd_multi(const dsn_tensor* xs, const void* const* ws, const float* const* biases, float* const* raws,
+                              int32_t nl, int32_t na, int32_t no, void* stream);
 int dsn_detect_raw_bwd_multi(const float* const* draws, const dsn_tensor* dts, int32_t nl, int32_t na, int32_t no,
                              const int32_t* zero_pad_to, float* const* bias_grads, void* workspace, int64_t workspace_bytes,
                              void* stream);

@@ -254,6 +254,59 @@ def test_pyramid_pooling_fused_branches_match_the_per_branch_path(shape, monkeyp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,hw,ch,nc", [(8, (80, 40, 20), (128, 256, 512), 6), (3, (13, 7, 4), (24, 40, 72), 1),
+                                        (2, (20, 10, 5), (64, 128, 256), 16)])
+def test_detect_fused_head_forward_matches_the_per_level_path(n, hw, ch, nc, monkeypatch):
+    """The training forward of all Detect heads as ONE launch (dsn_detect_head_fwd_multi: 1x1 conv + bias + permute, yolo.py:258-276)
+    against (a) a plain fp32 torch reference on the bf16-rounded operands and (b) the per-level conv + permute launches, and the
+    backward that follows it (unchanged kernels reading the fused path's tape records): input and parameter gradients."""
+    import copy
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    from desenet_amd.core.models import yolo
+    desenet_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(11)
+        ref = yolo.Detect(nc, ANCHORS, ch=ch)
+        ref.stride = torch.tensor([8.0, 16.0, 32.0])
+        for m in ref.m:
+            with torch.no_grad():
+                m.weight.normal_(0, 0.05); m.bias.uniform_(-1, 1)
+        ref = ref.cuda().train()
+        fused = copy.deepcopy(ref)
+        xs = [torch.randn(n, c, s, s, device="cuda").bfloat16().float() for c, s in zip(ch, hw)]
+        gys = [torch.randn(n, 3, s, s, nc + 5, device="cuda") for s in hw]
+        calls = {"n": 0}
+        real = ops.detect_head_fwd
+        monkeypatch.setattr(ops, "detect_head_fwd", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), real(*a, **k))[1])
+        outs = {}
+        for name, mod, flag in (("ref", ref, False), ("fused", fused, True)):
+            monkeypatch.setattr(yolo, "_DET_FUSED", flag)
+            xin = [x.clone().requires_grad_(True) for x in xs]
+            ys = mod(xin)
+            torch.autograd.backward(list(ys), gys)
+            torch.cuda.synchronize()
+            outs[name] = ([y.detach().clone() for y in ys], [x.grad.float().clone() for x in xin],
+                          {k: p.grad.float().clone() for k, p in mod.named_parameters()})
+        assert calls["n"] == 1, calls
+        for l, (a, b) in enumerate(zip(outs["ref"][0], outs["fused"][0])):
+            assert a.shape == b.shape and b.dtype == torch.float32
+            m = ref.m[l]
+            want = torch.nn.functional.conv2d(xs[l], m.weight.detach().bfloat16().float(), m.bias.detach().float())
+            want = want.view(n, 3, nc + 5, hw[l], hw[l]).permute(0, 1, 3, 4, 2)
+            scale = float(want.abs().max())
+            assert float((b - want).abs().max()) <= 8e-3 * scale, ("torch", l, float((b - want).abs().max()) / scale)    # one bf16 rounding
+            assert float((a - b).abs().max()) <= 8e-3 * scale, ("per-level", l, float((a - b).abs().max()) / scale)
+            assert torch.equal(b, b.bfloat16().float())          # bf16-representable, as the head convolution's output is
+        for l, (a, b) in enumerate(zip(outs["ref"][1], outs["fused"][1])):
+            assert torch.equal(a, b), ("input gradient", l)      # same kernels, same operands
+        for k, g in outs["ref"][2].items():
+            assert torch.equal(g, outs["fused"][2][k]), k
+    finally:
+        desenet_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
 def test_ffm_attention_fused_small_convs_match_the_layer_path(monkeypatch):
     """FFM's channel attention (two bias-free 1x1 convs on the pooled [n, c, 1, 1] vector, SiLU / Sigmoid: common.py:222-242) through
     the one-block kernels of csrc/pp_fused.hip against the conv + activation launches: output, input and weight gradients."""
