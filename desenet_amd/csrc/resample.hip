@@ -713,8 +713,17 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nchw_rows_kernel(const float
 }
 
 // ---- adaptive average pool: bin o covers [floor(o*H/k), ceil((o+1)*H/k)) ------------------------------------------------
-__device__ __forceinline__ int bin_lo(int o, int in, int k) { return (o * in) / k; }
-__device__ __forceinline__ int bin_hi(int o, int in, int k) { return ((o + 1) * in + k - 1) / k; }
+// a / b for small non-negative operands through the float reciprocal (+-1 correction: exact below 2^22): ~8 instructions against
+// ~30 for the integer division sequence -- the bin arithmetic below runs a few dozen of these per wave before any memory access
+__device__ __forceinline__ int div_small(int a, int b) {
+    if ((unsigned)(a | b) >> 22) return a / b;
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    q -= (q * b > a) ? 1 : 0;
+    q += ((q + 1) * b <= a) ? 1 : 0;
+    return q;
+}
+__device__ __forceinline__ int bin_lo(int o, int in, int k) { return div_small(o * in, k); }
+__device__ __forceinline__ int bin_hi(int o, int in, int k) { return div_small((o + 1) * in + k - 1, k); }
 
 template <typename T>
 __global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, int64_t yld, T* __restrict__ dx, int64_t xld,
@@ -804,16 +813,29 @@ __global__ void adaptive_avgpool_bwd_multi_kernel(const PoolSrcs srcs, T* __rest
 // adaptive bins overlap by one row when H is not a multiple of the grid) are block-uniform, and the bins of every column are
 // tabulated once per block in LDS -- the element loop is left with loads, multiplies by a reciprocal bin area and adds.  (The form
 // above spends ~100 integer divisions per 16-byte vector on bin arithmetic: 37 us for PyramidPooling's 8 x 128 x 80 x 80 dx.)
-template <typename T, int V>
+// NS: number of sources (compile time).  Averaging is separable, so the block first folds, per source, the (at most two) pooled
+// rows that contain h into ONE fp32 row  rv[b][ow][c] = sum_a dy_b[n][oh_a][ow][c] / height_a  in LDS (a few KB: the pooled maps
+// are 1 .. 6 wide); the element loop then touches global memory for dx only and reads its (at most two per source) column bins
+// from LDS.  Reading the bins from global memory per element -- up to 16 loads of the same few KB per 16-byte vector, from every
+// block of the launch -- took 26 us for PyramidPooling's 13 MB dx whichever way the loads were arranged.
+// blockIdx.y: segment of wseg columns.
+template <typename T, int V, int NS>
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_rows_kernel(const PoolSrcs srcs, T* __restrict__ dx, int64_t xld, int H,
-                                                                        int W, int C, int accumulate) {
-    extern __shared__ int ctab[];                      // [4 sources][W][4]: ow0, ow1 (or -1), 1/width bits of each
+                                                                        int W, int C, int accumulate, int wseg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+    int koff[NS + 1];
+    koff[0] = 0;
+#pragma unroll
+    for (int b = 0; b < NS; ++b) koff[b + 1] = koff[b] + srcs.KW[b];
+    float* rv = reinterpret_cast<float*>(pool_smem);                                   // [sum KW][C]
+    int* ctab = reinterpret_cast<int*>(pool_smem + (size_t)koff[NS] * C * 4);          // [NS][wseg][4]: ow0, ow1 (or -1), 1/width bits
     const int h = blockIdx.x % H, n = blockIdx.x / H;
     const int ncv = C / V;
-    for (int it = threadIdx.x; it < srcs.n * W; it += 256) {
-        const int b = it / W, w = it - b * W;
+    const int w_lo = blockIdx.y * wseg, w_n = (W - w_lo) < wseg ? (W - w_lo) : wseg;
+    for (int it = threadIdx.x; it < NS * w_n; it += 256) {
+        const int b = div_small(it, w_n), wl = it - b * w_n, w = w_lo + wl;
         const int KW = srcs.KW[b];
-        const int ow0 = (w * KW) / W;
+        const int ow0 = div_small(w * KW, W);
         int cand[3] = {ow0 - 1, ow0, ow0 + 1}, got = 0;
         int o[2] = {-1, -1};
         float inv[2] = {0.f, 0.f};
@@ -826,19 +848,18 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_rows_kernel(const Po
             inv[got] = 1.f / (float)(w1 - w0);
             ++got;
         }
-        int* e = ctab + (b * W + w) * 4;
+        int* e = ctab + (b * wseg + wl) * 4;
         e[0] = o[0]; e[1] = o[1]; e[2] = __float_as_int(inv[0]); e[3] = __float_as_int(inv[1]);
     }
     // rows: block-uniform (scalar) arithmetic
-    int oh[4][2];
-    float ih[4][2];
+    int oh[NS][2];
+    float ih[NS][2];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NS; ++b) {
         oh[b][0] = oh[b][1] = -1;
         ih[b][0] = ih[b][1] = 0.f;
-        if (b >= srcs.n) continue;
         const int KH = srcs.KH[b];
-        const int oh0 = (h * KH) / H;
+        const int oh0 = div_small(h * KH, H);
         bool first = true;
 #pragma unroll
         for (int j = -1; j <= 1; ++j) {
@@ -850,39 +871,50 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_rows_kernel(const Po
             else { oh[b][1] = c; ih[b][1] = 1.f / (float)(h1 - h0); }
         }
     }
+    // the row-combined pooled vectors (both candidate rows loaded unconditionally: a missing one reads row 0 with weight 0)
+    for (int it = threadIdx.x; it < koff[NS] * ncv; it += 256) {
+        const int col = div_small(it, ncv), cv = it - col * ncv;
+        int b = 0;
+#pragma unroll
+        for (int j = 1; j < NS; ++j) b += col >= koff[j] ? 1 : 0;
+        int r0 = 0, r1 = 0, k0 = 0, KH = 1, KW = 1;
+        float f0 = 0.f, f1 = 0.f;
+        const T* dy = nullptr;
+        int64_t ld = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (b == j) {
+                r0 = oh[j][0] >= 0 ? oh[j][0] : 0; f0 = oh[j][0] >= 0 ? ih[j][0] : 0.f;
+                r1 = oh[j][1] >= 0 ? oh[j][1] : 0; f1 = oh[j][1] >= 0 ? ih[j][1] : 0.f;
+                k0 = koff[j]; KH = srcs.KH[j]; KW = srcs.KW[j]; dy = (const T*)srcs.dy[j]; ld = srcs.ld[j];
+            }
+        const int ow = col - k0;
+        float v0[V], v1[V];
+        VecIO<T, V>::load(dy + (((int64_t)n * KH + r0) * KW + ow) * ld + cv * V, v0);
+        VecIO<T, V>::load(dy + (((int64_t)n * KH + r1) * KW + ow) * ld + cv * V, v1);
+#pragma unroll
+        for (int k = 0; k < V; ++k) rv[col * C + cv * V + k] = v0[k] * f0 + v1[k] * f1;
+    }
     __syncthreads();
-    for (int it = threadIdx.x; it < W * ncv; it += 256) {
-        const int w = it / ncv, cv = it - w * ncv;
+    for (int it = threadIdx.x; it < w_n * ncv; it += 256) {
+        const int wl = it / ncv, cv = it - wl * ncv, w = w_lo + wl;
+        T* o = dx + (((int64_t)n * H + h) * W + w) * xld + cv * V;
         float s[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) s[k] = 0.f;
+        if (accumulate) VecIO<T, V>::load(o, s);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= srcs.n) continue;
-            const T* dy = (const T*)srcs.dy[b];
-            const int* e = ctab + (b * W + w) * 4;
-            const int KW = srcs.KW[b];
+        for (int b = 0; b < NS; ++b) {
+            const int4 ev = *reinterpret_cast<const int4*>(ctab + (b * wseg + wl) * 4);
+            const float f0 = ev.x >= 0 ? __int_as_float(ev.z) : 0.f, f1 = ev.y >= 0 ? __int_as_float(ev.w) : 0.f;
+            const float* p0 = rv + (koff[b] + (ev.x >= 0 ? ev.x : 0)) * C + cv * V;
+            const float* p1 = rv + (koff[b] + (ev.y >= 0 ? ev.y : 0)) * C + cv * V;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                if (oh[b][a] < 0) continue;
+            for (int k = 0; k < V; k += 4) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + k), a1 = *reinterpret_cast<const f32x4*>(p1 + k);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int ow = e[c];
-                    if (ow < 0) continue;
-                    const float f = ih[b][a] * __int_as_float(e[2 + c]);
-                    float v[V];
-                    VecIO<T, V>::load(dy + (((int64_t)n * srcs.KH[b] + oh[b][a]) * KW + ow) * srcs.ld[b] + cv * V, v);
-#pragma unroll
-                    for (int k = 0; k < V; ++k) s[k] += v[k] * f;
-                }
+                for (int e = 0; e < 4; ++e) s[k + e] += a0[e] * f0 + a1[e] * f1;
             }
-        }
-        T* o = dx + (((int64_t)n * H + h) * W + w) * xld + cv * V;
-        if (accumulate) {
-            float old[V];
-            VecIO<T, V>::load(o, old);
-#pragma unroll
-            for (int k = 0; k < V; ++k) s[k] += old[k];
         }
         VecIO<T, V>::store(o, s);
     }
@@ -1696,17 +1728,36 @@ extern "C" int dsn_adaptive_avgpool_bwd_multi(const dsn_tensor* dys, int32_t n_s
             srcs.dy[i] = dys[i].ptr; srcs.ld[i] = dys[i].ldc; srcs.KH[i] = dys[i].h; srcs.KW[i] = dys[i].w;
         }
         const int V = dx->dtype == DSN_F32 ? 4 : 8;
-        bool rows = (int64_t)n_src * dx->w * 16 <= 48 * 1024 && dx->n * dx->h >= 64;
+        int64_t sum_kw = 0;
+        for (int i = 0; i < n_src; ++i) sum_kw += dys[i].w;
+        // LDS: the row-combined pooled vectors (fp32 [sum KW][C]) + the column table
+        bool rows = sum_kw * dx->c * 4 + (int64_t)n_src * dx->w * 16 <= 60 * 1024 && dx->n * dx->h >= 64;
         for (int i = 0; i < n_src; ++i) rows = rows && dys[i].h <= dx->h && dys[i].w <= dx->w;     // (bins: at most two per row / column)
         if (rows) {
-            const size_t lds = (size_t)n_src * dx->w * 16;
-            const dim3 grid((unsigned)(dx->n * dx->h));
-            if (dx->dtype == DSN_F32)
-                hipLaunchKernelGGL((adaptive_avgpool_bwd_rows_kernel<float, 4>), grid, dim3(256), lds, st, srcs, (float*)dx->ptr,
-                                   dx->ldc, dx->h, dx->w, dx->c, accumulate);
-            else
-                hipLaunchKernelGGL((adaptive_avgpool_bwd_rows_kernel<bf16_t, 8>), grid, dim3(256), lds, st, srcs, (bf16_t*)dx->ptr,
-                                   dx->ldc, dx->h, dx->w, dx->c, accumulate);
+            static const int seg_items = [] { const char* e = getenv("DSN_POOLBWD_ITEMS"); return e ? atoi(e) : 512; }();
+            int wseg = seg_items / (dx->c / V);               // columns per block
+            wseg = wseg < 1 ? 1 : (wseg > dx->w ? dx->w : wseg);
+            const size_t lds = (size_t)sum_kw * dx->c * 4 + (size_t)n_src * wseg * 16;
+            const dim3 grid((unsigned)(dx->n * dx->h), (unsigned)((dx->w + wseg - 1) / wseg));
+#define DSN_POOL_ROWS(T_, V_, NS_)                                                                                                \
+    hipLaunchKernelGGL((adaptive_avgpool_bwd_rows_kernel<T_, V_, NS_>), grid, dim3(256), lds, st, srcs, (T_*)dx->ptr, dx->ldc, dx->h, \
+                       dx->w, dx->c, accumulate, wseg)
+            if (dx->dtype == DSN_F32) {
+                switch (n_src) {
+                    case 1: DSN_POOL_ROWS(float, 4, 1); break;
+                    case 2: DSN_POOL_ROWS(float, 4, 2); break;
+                    case 3: DSN_POOL_ROWS(float, 4, 3); break;
+                    default: DSN_POOL_ROWS(float, 4, 4); break;
+                }
+            } else {
+                switch (n_src) {
+                    case 1: DSN_POOL_ROWS(bf16_t, 8, 1); break;
+                    case 2: DSN_POOL_ROWS(bf16_t, 8, 2); break;
+                    case 3: DSN_POOL_ROWS(bf16_t, 8, 3); break;
+                    default: DSN_POOL_ROWS(bf16_t, 8, 4); break;
+                }
+            }
+#undef DSN_POOL_ROWS
             DSN_LAUNCH_CHECK("adaptive_avgpool_bwd (rows)");
             return DSN_OK;
         }
