@@ -768,7 +768,10 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     }
     if (tiles64 >= 1536 && g.Ktot >= 1024 && g.Cd >= 128)
         return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 128x128
-    if (tiles64 < 256 || (tiles64 <= 400 && g.Ktot <= 512))      // (short-K layers on 40x40 / 20x20 maps: measured 5.0 vs 5.6 us)
+    // (256 .. 400 tiles: 32x64 measured 5.0 vs 5.6 us per launch on short-K layers standalone, but inside the step the 64x64 tile is
+    // ahead -- 3.938 vs 3.947 ms, DSN_IGEMM_SMALLK = 0 vs 512 = largest K that still takes the small tile there)
+    static const int smallk = [] { const char* e = getenv("DSN_IGEMM_SMALLK"); return e ? atoi(e) : 0; }();
+    if (tiles64 < 256 || (tiles64 <= 400 && g.Ktot <= smallk))
         return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 32x64
     return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);          // 64x64
 }
