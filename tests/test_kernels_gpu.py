@@ -427,21 +427,27 @@ def test_adaptive_avgpool(ops, k, dtype):
     assert_close(dx.float().cpu(), xq.grad, TOL[dtype], "adaptive pool bwd")
 
 
+@pytest.mark.parametrize("c", [16, 10, 24])          # 16 / 24: 16-byte channel vectors; 10: the scalar form (no vector width divides it)
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_ffm_scale(ops, dtype):
-    f, a = rnd((2, 16, 8, 6), 31), rnd((2, 16, 1, 1), 32, 0, 1)
+def test_ffm_scale(ops, dtype, c):
+    f, a = rnd((3, c, 8, 6), 31), rnd((3, c, 1, 1), 32, 0, 1)
     fq, aq = q(f, dtype).requires_grad_(True), q(a, dtype).requires_grad_(True)
     ref = fq * aq + fq
-    g = rnd((2, 16, 8, 6), 33)
+    g = rnd((3, c, 8, 6), 33)
     ref.backward(q(g, dtype))
     fd, ad = to_dev(ops, f, dtype), to_dev(ops, a, dtype)
-    out = ops.new_act(2, 16, 8, 6, dtype, "cuda")
+    out = ops.new_act(3, c, 8, 6, dtype, "cuda")
     ops.ffm_scale(fd, ad, out)
     assert_close(out.float().cpu(), ref.detach(), TOL[dtype], "ffm_scale")
-    df, da = ops.new_act(2, 16, 8, 6, dtype, "cuda"), ops.new_act(2, 16, 1, 1, dtype, "cuda")
+    df, da = ops.new_act(3, c, 8, 6, dtype, "cuda"), ops.new_act(3, c, 1, 1, dtype, "cuda")
     ops.ffm_scale_bwd(to_dev(ops, g, dtype), fd, ad, df, da)
     assert_close(df.float().cpu(), fq.grad, TOL[dtype], "ffm dfeat")
     assert_close(da.float().cpu(), aq.grad, TOL[dtype], "ffm datt")
+    # accumulate: dfeat += (the attention branch's gradient arrives in a buffer that already holds the other consumer's)
+    base = rnd((3, c, 8, 6), 34)
+    df2 = to_dev(ops, base, dtype)
+    ops.ffm_scale_bwd(to_dev(ops, g, dtype), fd, ad, df2, da, accumulate=True)
+    assert_close(df2.float().cpu(), fq.grad + q(base, dtype), 2 * TOL[dtype], "ffm dfeat (accumulate)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -466,6 +472,48 @@ def test_detect_decode(ops, dtype):
     dt = ops.new_act(n, na * no, ny, nx, dtype, "cuda")
     ops.detect_raw_bwd(raw, dt, na, no)
     assert torch.equal(dt.float().cpu(), tq)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detect_multi_level_launches(ops, dtype):
+    """All Detect levels per launch (dsn_detect_decode_multi / dsn_detect_raw_bwd_multi, 32-bit index arithmetic) on ragged maps:
+    raw is the exact permutation, pred the decode of yolo.py:262-275 at each level's row offset, the backward restores the head
+    outputs into row-padded tensors (padding zero-filled) and adds the per-channel sums into the bias gradients."""
+    from oracle import desenet_ref as R
+    na, no, n = 3, 7, 3
+    shapes, strides = [(13, 11), (7, 5), (4, 3)], [8.0, 16.0, 32.0]
+    anchors = torch.tensor([[[10., 13.], [16., 30.], [33., 23.]], [[30., 61.], [62., 45.], [59., 119.]],
+                            [[116., 90.], [156., 198.], [373., 326.]]])
+    ts = [rnd((n, na * no, ny, nx), 60 + l, -3, 3) for l, (ny, nx) in enumerate(shapes)]
+    rows, row = [], 2
+    for ny, nx in shapes:
+        rows.append(row)
+        row += na * ny * nx
+    raws = [torch.empty((n, na, ny, nx, no), device="cuda") for ny, nx in shapes]
+    pred = torch.zeros((n, row + 3, no), device="cuda")
+    ops.detect_decode_multi([to_dev(ops, t, dtype) for t in ts], raws, pred, rows, na, no, strides, anchors.cuda().contiguous())
+    for l, (ny, nx) in enumerate(shapes):
+        y = q(ts[l], dtype).view(n, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+        assert torch.equal(raws[l].cpu(), y), f"level {l}: raw is a pure permutation"
+        sg = y.sigmoid()
+        xy = (sg[..., 0:2] * 2.0 - 0.5 + R.make_grid(nx, ny)) * strides[l]
+        wh = (sg[..., 2:4] * 2) ** 2 * anchors[l].view(1, na, 1, 1, 2)
+        ref = torch.cat((xy, wh, sg[..., 4:]), -1).view(n, -1, no)
+        assert_close(pred[:, rows[l]:rows[l] + na * ny * nx].cpu(), ref, 1e-5, f"decode level {l}")
+    assert float(pred[:, :2].abs().max()) == 0 and float(pred[:, row:].abs().max()) == 0
+    vec = 4 if dtype == torch.float32 else 8
+    draws = [torch.randn(n, na, ny, nx, no, device="cuda") for ny, nx in shapes]
+    dts = [ops.new_act(n, na * no, ny, nx, dtype, "cuda", ldc_align=vec) for ny, nx in shapes]
+    for d in dts:
+        ops.padded_view(d).fill_(7.0)                                  # stale contents, padding lanes included
+    bias = [torch.full((na * no,), 0.5, device="cuda") for _ in shapes]
+    ops.detect_raw_bwd_multi(draws, dts, na, no, bias)
+    for l, (ny, nx) in enumerate(shapes):
+        want = draws[l].permute(0, 1, 4, 2, 3).reshape(n, na * no, ny, nx)
+        assert torch.equal(dts[l].float(), want.to(dtype).float()), f"level {l}: dt"
+        pv = ops.padded_view(dts[l])
+        assert float(pv[:, na * no:].float().abs().max()) == 0, f"level {l}: row padding must be zero"
+        assert_close(bias[l].cpu(), 0.5 + want.sum(dim=(0, 2, 3)).cpu(), 1e-5, f"level {l}: bias gradient")
 
 
 NMS_CASES = ["default", "val_multilabel", "agnostic", "classes", "ties", "maxdet", "empty", "over30000", "iou_edge"]
