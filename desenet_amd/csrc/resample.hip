@@ -402,19 +402,9 @@ __global__ void bilinear_kernel(const T* __restrict__ x, int64_t xld, void* __re
     const int64_t total = (int64_t)N * Ho * Wo * C;
     GRID_STRIDE(i, total) {
         int c, w, h, n;
-        if (NCHW_OUT) {  // i enumerates NCHW so the fp32 stores coalesce along w
-            w = (int)(i % Wo);
-            int64_t t = i / Wo;
-            h = (int)(t % Ho); t /= Ho;
-            c = (int)(t % C);
-            n = (int)(t / C);
-        } else {
-            c = (int)(i % C);
-            int64_t t = i / C;
-            w = (int)(t % Wo); t /= Wo;
-            h = (int)(t % Ho);
-            n = (int)(t / Ho);
-        }
+        int64_t pq;
+        if (NCHW_OUT) split_nhwc(i, Wo, Ho, C, pq, w, h, c, n);     // i enumerates NCHW so the fp32 stores coalesce along w
+        else split_nhwc(i, C, Wo, Ho, pq, c, w, h, n);
         const Lerp a = lerp_coord(h, sh, Hi), b = lerp_coord(w, sw, Wi);
         const T* base = x + (int64_t)n * Hi * Wi * xld + c;
         const float v00 = to_f32<T>(base[((int64_t)a.i0 * Wi + b.i0) * xld]);
