@@ -726,7 +726,7 @@ template <typename T, int MODE>
 int launch_1x1_ws_cfg(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* d, const WGeom& g, const BnAcc& fin,
                       int is_dgrad, hipStream_t st, int ns, const WsX& ex) {
     if (ns > 4) {      // 5 .. 8 slabs (K <= 512 bf16): 32 x 64 tiles, 64 KB of weights + a 2-stage ring, one block per CU; no extras
-        if constexpr (MODE != 2 && sizeof(T) == 2) {
+        if constexpr (MODE != 2) {
             switch (ns) {
                 case 5: return launch_1x1_ws<T, 1, 2, 2, 2, 5, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
                 case 6: return launch_1x1_ws<T, 1, 2, 2, 2, 6, MODE>(s, w, bias, d, g, fin, is_dgrad, st, ex);
@@ -1711,7 +1711,8 @@ int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
     // GEMM fetched those 64 KB once per 32 / 64 pixels (DSN_WS_LONGK=0: off; DSN_WS_LONGK_MINPX: smallest map taken)
     static const int longk = [] { const char* e = getenv("DSN_WS_LONGK"); return e ? atoi(e) : 1; }();
     static const int longk_minpx = [] { const char* e = getenv("DSN_WS_LONGK_MINPX"); return e ? atoi(e) : 2048; }();
-    const int ns_max = (longk && !extras && s->dtype == DSN_BF16 && npix(d) >= longk_minpx) ? 8 : 4;
+    static const int longk_f32 = [] { const char* e = getenv("DSN_WS_LONGK_F32"); return e ? atoi(e) : 1; }();
+    const int ns_max = (longk && !extras && (s->dtype == DSN_BF16 || longk_f32) && npix(d) >= longk_minpx) ? 8 : 4;
     if (s->c % vec != 0 || ns > ns_max || d->c % vec != 0 || s->ldc % vec != 0 || d->ldc % vec != 0) return 1;
     if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
     const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * es, wb = (int64_t)d->c * s->c * es;

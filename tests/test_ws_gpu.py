@@ -38,7 +38,8 @@ CASES_1X1 = [
     (2, 64, 47, 45, 64),       # ragged last pixel tile, one slab
     (2, 32, 64, 64, 32),       # half a slab (32 bf16 channels), 128 x 32 tile
     (2, 96, 40, 56, 40),       # one and a half slabs, ragged channel tile (40 of 64)
-    (1, 256, 48, 48, 200),     # four slabs (32 x 64 tiles), ragged last channel tile
+    (1, 256, 48, 48, 200),     # four slabs (32 x 64 tiles; eight in fp32: the long-K form), ragged last channel tile
+    (2, 160, 40, 40, 96),      # five fp32 slabs / two and a half bf16 slabs
     (3, 40, 31, 33, 72),       # nothing aligned to a tile
     (4, 128, 40, 40, 128),
     (8, 512, 20, 20, 256),     # eight slabs (bf16 only): 64 KB of resident weights, 2-stage ring, one block per CU
@@ -52,8 +53,8 @@ CASES_1X1 = [
 @pytest.mark.parametrize("act", ["silu", "none"])
 def test_conv1x1_ws_forward(ops, case, dtype, act):
     n, ci, h, w, co = case
-    if dtype == torch.float32 and ci > 128:
-        pytest.skip("more than four fp32 slabs: not a weights-stationary launch")
+    if dtype == torch.float32 and (ci > 256 or (ci > 128 and n * h * w < 2048)):
+        pytest.skip("more than eight fp32 slabs (or a long-K launch on a tiny map): not a weights-stationary launch")
     x, wt, b = rnd((n, ci, h, w), 11), rnd((co, ci, 1, 1), 12, -0.3, 0.3), rnd((co,), 13)
     ref = F.conv2d(q(x, dtype), q(wt, dtype), b)
     if act == "silu":
@@ -70,8 +71,8 @@ def test_conv1x1_ws_forward(ops, case, dtype, act):
 @pytest.mark.parametrize("case", CASES_1X1)
 def test_conv1x1_ws_dgrad(ops, case, dtype):
     n, ci, h, w, co = case
-    if dtype == torch.float32 and co > 128:
-        pytest.skip("more than four fp32 slabs: not a weights-stationary launch")
+    if dtype == torch.float32 and (co > 256 or (co > 128 and n * h * w < 2048)):
+        pytest.skip("more than eight fp32 slabs (or a long-K launch on a tiny map): not a weights-stationary launch")
     if ci > 256 and co < 64:
         pytest.skip("fewer than 64 source channels with a long destination: fine, but not a case worth its time")
     dy, wt = rnd((n, co, h, w), 21), rnd((co, ci, 1, 1), 22, -0.3, 0.3)
