@@ -65,13 +65,20 @@ template <typename T, int V> struct VecIO {   // generic / scalar
         for (int i = 0; i < V; ++i) p[i] = from_f32<T>(o[i]);
     }
 };
+// store(): non-temporal by default (resampling / copy kernels); a translation unit that defines DSN_VECIO_PLAIN before including
+// this header gets ordinary stores (bn_act.hip does: its outputs are re-read by the next kernel, and on the 50-200 MB tensors of
+// the 1280^2 configuration that is worth 0.9 % of the step)
 template <> struct VecIO<float, 4> {
     __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(p);
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
     }
     __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
+#ifdef DSN_VECIO_PLAIN
+        *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+#else
         __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(p));
+#endif
     }
 };
 template <> struct VecIO<bf16_t, 8> {
@@ -84,7 +91,11 @@ template <> struct VecIO<bf16_t, 8> {
         bf16x8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+#ifdef DSN_VECIO_PLAIN
+        *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, v);
+#else
         __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+#endif
     }
 };
 template <typename T> struct VW { static constexpr int N = 16 / sizeof(T); };
