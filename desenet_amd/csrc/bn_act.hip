@@ -11,6 +11,9 @@
 // Ordinary (not non-temporal) output stores in this file's kernels: measured with two libraries alternated in one call, DeSeNet-m at
 // 1280^2 19.38-19.41 vs 19.57-19.58 ms per step, config 3 3.942 vs 3.940 ms (common.h: VecIO::store)
 #define DSN_VECIO_PLAIN 1
+// ... and non-temporal LOADS: every input of these kernels is read exactly once (five alternated pairs on config 3: 3.930 vs 3.940 ms;
+// DeSeNet-m at 1280^2 19.24-19.28 vs 19.27-19.31 ms)
+#define DSN_VECIO_NTLOAD 1
 #include "common.h"
 
 namespace {

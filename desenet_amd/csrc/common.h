@@ -67,10 +67,15 @@ template <typename T, int V> struct VecIO {   // generic / scalar
 };
 // store(): non-temporal by default (resampling / copy kernels); a translation unit that defines DSN_VECIO_PLAIN before including
 // this header gets ordinary stores (bn_act.hip does: its outputs are re-read by the next kernel, and on the 50-200 MB tensors of
-// the 1280^2 configuration that is worth 0.9 % of the step)
+// the 1280^2 configuration that is worth 0.9 % of the step).  DSN_VECIO_NTLOAD likewise turns load() into a non-temporal load (inputs
+// that are read exactly once).
 template <> struct VecIO<float, 4> {
     __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
+#ifdef DSN_VECIO_NTLOAD
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
         const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#endif
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
     }
     __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
@@ -83,7 +88,11 @@ template <> struct VecIO<float, 4> {
 };
 template <> struct VecIO<bf16_t, 8> {
     __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+#ifdef DSN_VECIO_NTLOAD
+        const bf16x8 v = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+#else
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
     }
