@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-layers", default="", help="write the per-(kernel label, layer) table of the profiled eager steps to this file")
+    ap.add_argument("--dump-json", default="", help="write the full result (per-kernel and per-layer tables, the `also` children's tables) "
+                    "to this file; stdout carries only the compact line.  Default: gpurun_out/bench_detail_<config>.json")
     ap.add_argument("--no-ema", action="store_true", help="train: leave out the rank-0 ModelEMA update (train.py:374)")
     ap.add_argument("--eager", action="store_true", help="train: launch every kernel from Python instead of hipGraph replay")
     ap.add_argument("--accumulate", type=int, default=1, help="train: micro-batches per optimizer step (train.py:146; 1 = step every batch)")
@@ -227,7 +229,85 @@ def roofline_by_layer(layers, steps, train):
             "summary": summary, "layers": rows}
 
 
-def also_sections():
+LINE_LIMIT = 4000      # the driver parses the LAST ~8 KB of stdout; round 3's 46 KB line came back as "parsed": null
+
+
+def _round(v, nd=4):
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}") if abs(v) < 1 else round(v, 3)
+    return v
+
+
+def compact_roofline(r):
+    """The keys the task statement names for `roofline` (+ kernel label, launch time): no prose, no duplicate rates."""
+    if not r:
+        return None
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step", "flop_per_byte")
+    return {k: _round(r.get(k)) for k in keep if k in r}
+
+
+def compact_layer_classes(by_layer):
+    """roofline_by_layer.summary reduced to {class: {frac-of-its-roof, rate, ms}} -- the two north_star targets."""
+    if not by_layer or not by_layer.get("summary"):
+        return None
+    out = {}
+    for k, t in by_layer["summary"].items():
+        if k.startswith("c3_3x3"):
+            out[k] = {"bound": "mfma", "frac": _round(t["mfma_frac"]), "TFLOPs": _round(t["TFLOPs"]), "ms_per_step": _round(t["ms_per_step"])}
+        else:
+            out[k] = {"bound": "hbm", "frac": _round(t["hbm_frac"]), "GBs": _round(t["GBs"]), "mfma_frac": _round(t["mfma_frac"]),
+                      "ms_per_step": _round(t["ms_per_step"])}
+    return out
+
+
+def compact_line(out):
+    """ONE stdout JSON line below LINE_LIMIT bytes: the contract keys + `roofline` + `cpu_baseline` + per-class fractions + a
+    compact `also`.  Everything tabular (`kernels`, `roofline_by_layer.layers`, the children's tables) lives in the detail file."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+    line = {k: _round(out[k]) if not isinstance(out.get(k), dict) else out[k] for k in keys if k in out}
+    line["roofline"] = compact_roofline(out.get("roofline"))
+    cpu = out.get("cpu_baseline")
+    line["cpu_baseline"] = ({k: _round(v) for k, v in cpu.items()} if cpu else None)
+    line["layer_classes"] = compact_layer_classes(out.get("roofline_by_layer"))
+    if out.get("also"):
+        also = {}
+        for name, sec in out["also"].items():
+            if "error" in sec:
+                also[name] = {"error": str(sec["error"])[-160:]}
+                continue
+            r = sec.get("roofline") or {}
+            also[name] = {"value": _round(sec.get("value")), "unit": sec.get("unit"), "ms_per_step": _round(sec.get("ms_per_step")),
+                          "dtype": sec.get("dtype"), "steps": sec.get("steps"),
+                          "roofline": {k: _round(r.get(k)) for k in ("kernel", "bound", "frac") if k in r},
+                          "layer_classes": {k: v.get("frac") for k, v in (sec.get("layer_classes") or {}).items()}}
+        line["also"] = also
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > LINE_LIMIT:             # never let a long label cost the round its number again: shed optional parts
+        for victim in ("also", "layer_classes"):
+            if victim in line and len(txt) > LINE_LIMIT:
+                line[victim] = None
+                txt = json.dumps(line, separators=(",", ":"))
+        if len(txt) > LINE_LIMIT:
+            line["config"]["workload"] = line["config"]["workload"][:200]
+            if line.get("cpu_baseline"):
+                line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:160]
+            txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
+
+def default_detail_path(a):
+    """Where the tables go when --dump-json is not given: gpurun_out/ (merged back by gpurun), else nowhere."""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        return ""
+    tag = f"{a.mode}_{a.model}_{a.img}_b{a.batch or 0}_{a.dtype or 'def'}_g{a.gpus}"
+    return os.path.join(d, f"bench_detail_{tag}.json")
+
+
+def also_sections(detail_dir=""):
     """The other single-GPU configurations of BASELINE.json, measured by child runs of this script right after the headline
     (fresh processes: no shared caches with the timed region above): config 2 (fused fp32 inference + NMS, batch 16) and
     config 5's per-GPU shape (DeSeNet-m, 1280x1280, batch 4, bf16 training step)."""
@@ -238,6 +318,8 @@ def also_sections():
     out = {}
     for name, extra in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--also-only", *extra]
+        if detail_dir:
+            cmd += ["--dump-json", os.path.join(detail_dir, f"bench_detail_{name}.json")]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
@@ -248,8 +330,8 @@ def also_sections():
             j = json.loads(line[-1])
             out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
                          "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "workload": j["config"]["workload"],
-                         "roofline": j["roofline"], "roofline_by_layer": j.get("roofline_by_layer"),
-                         "kernels": j.get("kernels"), "wall_s": time.perf_counter() - t0}
+                         "roofline": j["roofline"], "layer_classes": j.get("layer_classes"),
+                         "wall_s": time.perf_counter() - t0}
         except Exception as e:      # never lose the headline line to a failing side section
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         log(f"also[{name}]: {out[name].get('value', out[name].get('error'))}")
@@ -266,6 +348,8 @@ def self_launch(a):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
+    # the task statement's environment note: the host driver supports dmabuf IPC only; without this RCCL's cross-process buffer
+    # registration fails with `hipIpcGetMemHandle: invalid argument`.  Already exported on the boxes; kept for a bare shell.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
@@ -441,6 +525,25 @@ def main():
         elapsed = float(t.item())
 
     log(f"timed region: {elapsed:.3f} s")
+    comm_info = {}
+    if world > 1:
+        # evidence that the collective really spans `world` ranks (outside the timed region): every rank contributes 1, and the
+        # flat gradient buffer's all-reduce -- the one exchange of the step -- is timed on its own
+        one = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(one)
+        comm_info = {"backend": dist.get_backend(), "rccl_ranks": int(round(float(one.item())))}
+        if train:
+            buf = torch.zeros_like(flat.flat)
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            comm_info["allreduce_us"] = round((time.perf_counter() - t1) / 10 * 1e6, 1)
+            comm_info["allreduce_MB"] = round(buf.numel() * buf.element_size() / 1e6, 1)
+        log(f"rank {rank}: {comm_info}")
     if rank == 0:
         roof, table = roofline_from_profile(prof, prof_steps, dtype)
         if roof is not None and not (train and a.model == "s" and batch == 8 and a.img == 640):
@@ -464,12 +567,21 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
             "data": "synthetic (seeded uniform images, seeded boxes/masks, hash-filled weights)",
-            "config": {"workload": workload, "batch_per_gpu": batch, "img": a.img, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "batch_per_gpu": batch, "img": a.img, "parallelism": f"dp{world}", **comm_info},
             "roofline": roof, "roofline_by_layer": by_layer, "cpu_baseline": cpu, "kernels": table,
         }
+        detail_path = a.dump_json or default_detail_path(a)
         if world == 1 and train and a.model == "s" and not a.no_also and not a.also_only:
-            out["also"] = also_sections()
-        print(json.dumps(out))
+            out["also"] = also_sections(os.path.dirname(detail_path) if detail_path else "")
+        if detail_path:                      # the per-kernel / per-layer tables: a side file, never the stdout line
+            try:
+                os.makedirs(os.path.dirname(detail_path) or ".", exist_ok=True)
+                with open(detail_path, "w") as f:
+                    json.dump(out, f, indent=1)
+                log("detail tables ->", detail_path)
+            except OSError as e:
+                log(f"could not write {detail_path}: {e}")
+        print(compact_line(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
