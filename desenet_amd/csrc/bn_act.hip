@@ -831,8 +831,9 @@ extern "C" int dsn_bn_finalize_multi(const dsn_bn_final* entries, int32_t n, voi
             t.e[i] = e;
             t.first[i] = blocks;
             blocks += (e.n + 255) / 256;
+            DSN_CHECK_ARG(blocks <= INT16_MAX, "bn_finalize_multi: %d blocks do not fit the table's 16-bit block index", blocks);
         }
-        t.first[t.n] = blocks;
+        t.first[t.n] = (int16_t)blocks;
         hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
         DSN_LAUNCH_CHECK("bn_finalize_multi");
     }

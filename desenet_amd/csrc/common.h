@@ -32,6 +32,15 @@ void dsn_set_error(const char* fmt, ...);
         if (e_ != hipSuccess) DSN_FAIL((int)e_, "%s: %s", what, hipGetErrorString(e_));    \
     } while (0)
 
+// Opt a kernel into more than 64 KB of dynamic LDS: once per (kernel, device ordinal), checked.  Returns DSN_OK or the HIP error
+// (message set): a launch site returns it instead of failing later with "invalid argument" at launch time.
+int dsn_lds_attr(const void* kern, int bytes);
+#define DSN_LDS_ATTR(kern, bytes)                                         \
+    do {                                                                  \
+        const int a_ = dsn_lds_attr((const void*)(kern), (bytes));        \
+        if (a_ != DSN_OK) return a_;                                      \
+    } while (0)
+
 // ---- tensor view as passed to kernels -------------------------------------------------------------------------
 struct TV {
     void*   p;

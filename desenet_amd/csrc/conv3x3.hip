@@ -402,11 +402,7 @@ int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const ds
     const size_t epi = (size_t)BM * (BN + CPAD) * 4 + 2 * 256 * 4;
     const size_t lds = loop > epi ? loop : epi;
     auto kern = conv3x3_halo_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, MULTI, LZ>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(kern, 150 * 1024);
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
     const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) +
                          9.0 * g.Cs * g.Cd;
@@ -662,11 +658,7 @@ int launch_1x1(const dsn_tensor* s, const void* w, const float* bias, const dsn_
     const size_t epi = (size_t)BM * (BN + CPAD) * 4 + 2 * 256 * 4;
     const size_t lds = loop > epi ? loop : epi;
     auto kern = conv1x1_dma_kernel<T, MI, NI, WGM, WGN, NS, LZ>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(kern, 150 * 1024);
     const int blocks = (int)((M + BM - 1) / BM) * g.tiles_n;
     const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) + (double)g.Cs * g.Cd;
     const ProfConv pc("conv1x1_dma_kernel", sizeof(T) == 2, BM, BN, is_dgrad != 0, 1, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);

@@ -694,12 +694,11 @@ int launch_1x1_ws(const dsn_tensor* s, const void* w, const float* bias, const d
     const size_t lds = (size_t)NS * (BN + D * BM) * ROWB + ((STATS || EX) ? (size_t)WGM * BN * 2 * 4 : 0);
     static const int max_bpc = [] { const char* e = getenv("DSN_WS_BPC"); return e ? atoi(e) : 4; }();
     const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, max_bpc);
+    // (the extras variant pins D = 3: with the 128 x 32 tile and four slabs that is 214 KB -- not this kernel's launch; the caller
+    // falls through to the one-trip / implicit-GEMM kernels)
+    if (lds > 160 * 1024) return 1;
     auto kern = conv1x1_ws_kernel<T, MI, NI, WGM, WGN, NS, STATS, D, EX>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(kern, 160 * 1024);
     double xch = (ex.res ? 1.0 : 0.0) + (ex.accumulate ? 1.0 : 0.0);
     for (int i = 0; i < ex.nseg; ++i) xch += (double)(ex.seg[i].c1 - ex.seg[i].c0) / g.Cd;
     const double elems = (double)M * (g.Cs + (double)g.Cd * (1.0 + xch)) + (double)g.Cs * g.Cd;
@@ -766,11 +765,7 @@ int launch_gather_ws(const dsn_tensor* s, const void* w, const dsn_tensor* d, WG
     const size_t lds = (size_t)WB1 + (size_t)D * TILEB + RED;
     const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 4);
     auto kern = conv1x1_ws_kernel<T, MI, NI, WGM, WGN, NS, STATS, D, EX, G>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(kern, 160 * 1024);
     double xch = 0.0;
     for (int i = 0; i < ex.nseg; ++i) xch += (double)(ex.seg[i].c1 - ex.seg[i].c0) / (G == 2 ? g.d2s_c : g.Cd);
     const double src_el = (double)g.N * g.gHs * g.gWs * g.gCt;
@@ -1190,11 +1185,7 @@ int launch_3x3_ws(const dsn_tensor* s, const void* w, const float* bias, const d
         const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 2);
         constexpr bool HP = TW == 8;          // hand-issued fragment reads: measured +10 % on 8 x 8 patches, -30 % on 8 x 16 ones
         auto kern = conv3x3_ws_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, NS, STATS, D, HP, EX>;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        DSN_LDS_ATTR(kern, 160 * 1024);
         double xch = (ex.res ? 1.0 : 0.0) + (ex.accumulate ? 1.0 : 0.0);
         for (int i = 0; i < ex.nseg; ++i) xch += (double)(ex.seg[i].c1 - ex.seg[i].c0) / g.Cd;
         const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1.0 + xch)) + 9.0 * g.Cs * g.Cd;
@@ -1644,11 +1635,7 @@ int launch_3x3_thin_f32(const dsn_tensor* s, const void* w, const float* bias, c
     const size_t lds = (size_t)WBYTES + (size_t)D * HSTAGE + (STATS ? (size_t)WGM * BN * 2 * 4 : 0);
     const WsPlan pl = ws_plan(g.tiles_m, g.tiles_n, lds, 4);
     auto kern = conv3x3_thin_f32_ws_kernel<MI, NI, WGN, STATS, D>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(kern, 150 * 1024);
     const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd) + 9.0 * g.Cs * g.Cd;
     const ProfConv pc("conv3x3_thin_f32_ws_kernel", false, BM, BN, false, 3, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
     ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * 4, st);

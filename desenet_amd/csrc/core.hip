@@ -11,6 +11,28 @@ void dsn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- dynamic-LDS opt-in, once per (kernel, device) ------------------------------------------------------------------------
+#include <mutex>
+#include <unordered_map>
+int dsn_lds_attr(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, uint64_t> done;        // kernel -> bit per device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    uint64_t& m = done[kern];
+    if (m & bit) return DSN_OK;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dsn_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", bytes, dev, hipGetErrorString(e));
+        return (int)e;
+    }
+    m |= bit;
+    return DSN_OK;
+}
+
 // ---- live profiler -------------------------------------------------------------------------------------------------
 #include <map>
 #include <string>

@@ -646,13 +646,7 @@ extern "C" int dsn_seg_ce_up(const dsn_tensor* logits, const int64_t* target, in
     const float sh = (float)(hl - 1) / (float)(H - 1), sw = (float)(wl - 1) / (float)(W - 1);
     const int64_t npx = (int64_t)n * hl * wl;
     DSN_DISPATCH_DTYPE(logits->dtype, T, {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            (void)hipFuncSetAttribute((const void*)seg_ce_up_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            attr_done = true;
-        }
+        DSN_LDS_ATTR((seg_ce_up_kernel<T, 2>), 96 * 1024);
         hipLaunchKernelGGL((seg_ce_up_kernel<T, 2>), dim3(nb), dim3(SCU_NT), lds, st, (const T*)logits->ptr, logits->ldc, hl, wl, H, W, RB,
                            sh, sw, target, ignore_index, gacc, partial);
         hipLaunchKernelGGL(seg_ce_up_finalize_kernel<T>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, partial, nb, gacc, npx, C,

@@ -306,11 +306,7 @@ extern "C" int dsn_pp_stages_fwd(const dsn_pp_args* a, void* stream) {
     size_t lds = 0;
     const int rc = pp_check(a, false, &lds);
     if (rc) return rc;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)pp_stages_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(pp_stages_fwd_kernel, 160 * 1024);
     hipLaunchKernelGGL(pp_stages_fwd_kernel, dim3(a->nstage), dim3(PP_THREADS), lds, (hipStream_t)stream, *a);
     DSN_LAUNCH_CHECK("pp_stages_fwd");
     return DSN_OK;
@@ -320,11 +316,7 @@ extern "C" int dsn_pp_stages_bwd(const dsn_pp_args* a, void* stream) {
     size_t lds = 0;
     const int rc = pp_check(a, true, &lds);
     if (rc) return rc;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)pp_stages_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    DSN_LDS_ATTR(pp_stages_bwd_kernel, 160 * 1024);
     hipLaunchKernelGGL(pp_stages_bwd_kernel, dim3(a->nstage), dim3(PP_THREADS), lds, (hipStream_t)stream, *a);
     DSN_LAUNCH_CHECK("pp_stages_bwd");
     return DSN_OK;

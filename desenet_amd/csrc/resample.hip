@@ -1320,12 +1320,7 @@ extern "C" int dsn_maxpool_s1_multi(const dsn_tensor* x, const dsn_tensor* ys, v
             hipLaunchKernelGGL((maxpool_cascade_kernel<float, 4, 512>), dim3(x->n * (x->c / 4)), dim3(512), l_full, st,
                                (const float*)x->ptr, x->ldc, out, x->h, x->w, x->c, ks[0] / 2);
         } else if (narrow) {
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void*)maxpool_cascade_kernel<bf16_t, 4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          150 * 1024);
-                attr = true;
-            }
+            DSN_LDS_ATTR((maxpool_cascade_kernel<bf16_t, 4, 1024>), 150 * 1024);
             hipLaunchKernelGGL((maxpool_cascade_kernel<bf16_t, 4, 1024>), dim3(x->n * (x->c / 4)), dim3(1024), l_half, st,
                                (const bf16_t*)x->ptr, x->ldc, out, x->h, x->w, x->c, ks[0] / 2);
         } else {

@@ -1095,16 +1095,11 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
 }
 
 constexpr size_t ALLTAPS_LDS = (size_t)2 * 32 * TB * 2 * (1 + 9);   // A + 9 shifted B tiles, double buffered: 80 KiB
-void alltaps_attr_once() {
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute((const void*)wgrad_alltaps_bf16_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ALLTAPS_LDS);
-    (void)hipFuncSetAttribute((const void*)wgrad_alltaps_grouped_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ALLTAPS_LDS);
-    (void)hipFuncSetAttribute((const void*)wgrad_alltaps_grouped_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ALLTAPS_LDS);
-    done = true;
+int alltaps_attr_once() {
+    DSN_LDS_ATTR(wgrad_alltaps_bf16_kernel<9>, (int)ALLTAPS_LDS);
+    DSN_LDS_ATTR(wgrad_alltaps_grouped_kernel<false>, (int)ALLTAPS_LDS);
+    DSN_LDS_ATTR(wgrad_alltaps_grouped_kernel<true>, (int)ALLTAPS_LDS);
+    return DSN_OK;
 }
 
 }  // namespace
@@ -1133,7 +1128,7 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
         } else if (job.kind == 3) {
             hipLaunchKernelGGL(wgrad128_kernel<32>, grid, block, 0, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
         } else if (job.kind == 1) {
-            alltaps_attr_once();
+            { const int a_ = alltaps_attr_once(); if (a_ != DSN_OK) return a_; }
             hipLaunchKernelGGL(wgrad_alltaps_bf16_kernel<9>, grid, block, ALLTAPS_LDS, st, (const bf16_t*)x->ptr,
                                (const bf16_t*)dy->ptr, out, g);
         } else if (x->dtype == DSN_F32) {
@@ -1289,7 +1284,7 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
         }
         if (g1 > 0) {
             DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: all-taps jobs are bf16 only");
-            alltaps_attr_once();
+            { const int a_ = alltaps_attr_once(); if (a_ != DSN_OK) return a_; }
             if (lazy) hipLaunchKernelGGL(wgrad_alltaps_grouped_kernel<true>, dim3(g1), dim3(256), ALLTAPS_LDS, st, jobs, n);
             else hipLaunchKernelGGL(wgrad_alltaps_grouped_kernel<false>, dim3(g1), dim3(256), ALLTAPS_LDS, st, jobs, n);
         }

@@ -72,6 +72,11 @@ class GraphedTrainStep:
             self._set_labels(det_targets, None)
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.split = self._pick_split(split_layer) if self.multi else 0
+        if self.split > 0 and any(m.__dict__.get("_dsn_sync") is not None for m in model.modules()):
+            # SyncBatchNorm's per-layer all-reduces are CAPTURED into the backward graphs; the overlapped gradient all-reduce is an
+            # eager collective on the same communicator.  One communicator must not carry a captured and an eager operation in
+            # flight at once (no device-side order between them): run the step unsplit, gradient all-reduce after the whole backward.
+            self.split = 0
 
         snap = self._snapshot() if restore_after_warmup else None
         side = torch.cuda.Stream(device=dev)
