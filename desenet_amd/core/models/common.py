@@ -441,6 +441,10 @@ class PyramidPooling(HipModule):
                 return False
             if bn.eps != bn0.eps or bn.momentum != bn0.momentum or act_code(cv.act) != act_code(convs[0].act):
                 return False
+            # a frozen / eval-mode BatchNorm inside a training model keeps its running statistics (conv_block_fwd's `frozen`
+            # record); the fused kernel always computes batch statistics and updates the running averages
+            if not (cv.training and bn.training) or bn.running_mean is None or bn.running_var is None:
+                return False
         n, c = x.shape[0], x.shape[1]
         return ops.pp_stages_supported(n * max(ks) ** 2, c, convs[0].conv.out_channels, x.dtype)
 

@@ -424,6 +424,11 @@ int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
 int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
 
+// conv_pp.hip: 256-pixel x 128 / 256-channel block tiles, two wave groups in ping-pong (bf16, 3x3 / stride 1 / dilation 1); tried
+// first (same return convention)
+int dsn_conv3x3_pp_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
+
 // the gather forms of the 1x1 kernel: 3x3 / stride 2 / pad 1 forward, and its data gradient (2x2 form, depth-to-space store)
 int dsn_conv3x3s2_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                          const dsn_conv_params* p, const BnAcc* finp, void* stream);

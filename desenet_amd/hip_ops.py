@@ -1154,6 +1154,8 @@ def pp_stages_fwd(xs, ws, bns, zs, ys, stats, act, momentum, eps):
     stages = []
     for x, w, bn, z, y, st in zip(xs, ws, bns, zs, ys, stats):
         _require_gpu(x)
+        if _nhwc_ldc(x) != c:
+            raise ValueError("pp_stages_fwd: the pooled maps are staged as dense [pixels][C] rows")
         stages.append(dict(x=x.data_ptr(), w=w.data_ptr(), z=z.data_ptr(), y=y.data_ptr(), stats=_p(st),
                            gamma=_p(bn.weight) if bn is not None else None, beta=_p(bn.bias) if bn is not None else None,
                            running_mean=_p(bn.running_mean) if bn is not None else None,
@@ -1168,6 +1170,8 @@ def pp_stages_bwd(xs, ws, zs, dys, dxs, stats, dgammas, dbetas, dws, act, accumu
     c, co = xs[0].shape[1], zs[0].shape[1]
     stages = []
     for x, w, z, dy, dx, st, dg, db, dw in zip(xs, ws, zs, dys, dxs, stats, dgammas, dbetas, dws):
+        if _nhwc_ldc(x) != c or _nhwc_ldc(dx) != c:
+            raise ValueError("pp_stages_bwd: x and dx are dense [pixels][C] rows")
         stages.append(dict(x=x.data_ptr(), w=w.data_ptr(), z=z.data_ptr(), dy=dy.data_ptr(), dx=dx.data_ptr(), stats=_p(st),
                            dgamma=_p(dg), dbeta=_p(db), dw=_p(dw), zld=_nhwc_ldc(z), dyld=_nhwc_ldc(dy),
                            P=x.shape[0] * x.shape[2] * x.shape[3], has_bn=int(st is not None)))

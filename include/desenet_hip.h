@@ -120,6 +120,11 @@ int dsn_conv2d_dgrad_s2_bnred(const dsn_tensor* dy, const void* w_s2, const dsn_
  * data-gradient extras variants, 3 = every eligible launch.  A negative argument leaves that mode unchanged.  Returns
  * 16 * mode_1x1 + mode_3x3 after the update.  Results do not depend on the mode beyond fp32 summation order. */
 int         dsn_ws_mode(int32_t mode_1x1, int32_t mode_3x3);
+/* The same for the big-tile ping-pong 3x3 kernel (csrc/conv_pp.hip: 256 output pixels x 128 / 256 channels per block, bf16, k3 /
+ * s1 / d1, input channels in whole 64-channel slabs): 0 = never, 1 = default (layers whose 16 x 16 patches cover >= 80 % of the map
+ * and give >= 160 blocks), 2 = every eligible layer, 3 = the same with 256-channel tiles wherever possible, 4 / 5 = every eligible layer on 128-channel tiles with two / one
+ * block(s) per CU (tests, A/B runs).  Negative: unchanged.  Returns the mode after the update. */
+int         dsn_pp_mode(int32_t mode);
 int         dsn_version(void);
 const char* dsn_last_error(void);
 

@@ -45,6 +45,18 @@ LAYERS_M = [  # DeSeNet-m (config 5): batch 4, 1280x1280 -- the layers that carr
 ]
 
 
+LAYERS_PP = [  # conv_pp.hip: the same 400-patch grid (4 x 160 x 160) with K = 576 .. 4608 -> time = a + b K; one-round grids
+    ("pp 64->128 k3 @160", 4, 64, 160, 160, 128, 3, 1),
+    ("pp 128->128 k3 @160", 4, 128, 160, 160, 128, 3, 1),
+    ("pp 256->128 k3 @160", 4, 256, 160, 160, 128, 3, 1),
+    ("pp 512->128 k3 @160", 4, 512, 160, 160, 128, 3, 1),
+    ("pp1 64->128 k3 @2x160", 2, 64, 160, 160, 128, 3, 1),
+    ("pp1 128->128 k3 @2x160", 2, 128, 160, 160, 128, 3, 1),
+    ("pp1 256->128 k3 @2x160", 2, 256, 160, 160, 128, 3, 1),
+    ("pp1 512->128 k3 @2x160", 2, 512, 160, 160, 128, 3, 1),
+    ("pp1 256->256 k3 @2x160", 2, 256, 160, 160, 256, 3, 1),
+]
+
 _STREAM = None
 
 
@@ -106,7 +118,7 @@ def main():
     if which == "bn":
         return bench_bn()
     import os
-    for name, n, ci, h, w, co, k, s in (LAYERS_M if os.environ.get("DSN_BENCH_SET") == "m" else LAYERS):
+    for name, n, ci, h, w, co, k, s in {"m": LAYERS_M, "pp": LAYERS_PP}.get(os.environ.get("DSN_BENCH_SET", ""), LAYERS):
         if only and only not in name:
             continue
         pad = k // 2
