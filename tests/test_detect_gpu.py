@@ -65,5 +65,13 @@ def test_detect_chain_vs_oracle(fused, conf, iou, max_det):
         # exact check above (same pred in, same boxes out, ties included) and by tests/test_kernels_gpu.py's golden NMS cases.
         assert (oseg != xseg).float().mean().item() < 1e-3
         assert len(odet) == len(xdet) or max(len(odet), len(xdet)) < max_det
+        if len(odet) == len(xdet) and len(xdet) > 0:
+            # equal counts: the two chains' boxes, each sorted by (class, confidence, x1, y1), agree within the fp32 tolerance
+            # (coordinates are rounded pixels: +-1) for all but the few rows a saturated-confidence tie may have swapped
+            key = lambda a: a[np.lexsort((a[:, 1], a[:, 0], a[:, 4], a[:, 5]))]
+            a, b = key(np.asarray(odet, np.float64)), key(np.asarray(xdet, np.float64))
+            same = (np.abs(a[:, :4] - b[:, :4]).max(1) <= 1.0 + 1e-3 * np.abs(b[:, :4]).max(1)) & \
+                   (np.abs(a[:, 4] - b[:, 4]) <= 1e-3) & (a[:, 5] == b[:, 5])
+            assert same.mean() >= 0.9, (same.mean(), len(a))
     if conf < 0.01:
         assert len(xdet) > 0, "the low-threshold case is expected to keep boxes (exercises scale_coords / round)"

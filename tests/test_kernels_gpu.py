@@ -89,6 +89,9 @@ def test_conv_fwd(ops, case, dtype):
     y = ops.new_act(n, co, ho, wo, dtype, "cuda")
     ops.conv2d_fwd(xd, wp, b.cuda(), rd, y, ops.conv_params(k, s, pad, dil, act=ops.ACT_SILU))
     assert_close(y.float().cpu(), ref, TOL[dtype], f"conv {case}")
+    if dtype == torch.float32:      # element-wise as well: |a-b| <= 1e-3 |b| + 1e-3 rms(b) for EVERY output (tests/util.py)
+        from tests.util import elem_err
+        assert elem_err(y.cpu(), ref) <= 1.0, (f"conv {case} element-wise", elem_err(y.cpu(), ref))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -300,6 +303,9 @@ def test_bn_train_fwd_bwd(ops, shape, dtype):
     z = ops.new_act(n, c, h, w, dtype, "cuda")
     ops.bn_act_fwd(yd, scale, shift, ops.ACT_SILU, to_dev(ops, res, dtype), z)
     assert_close(z.float().cpu(), z_ref.detach(), TOL[dtype], "bn_act_fwd")
+    if dtype == torch.float32:
+        from tests.util import elem_err
+        assert elem_err(z.cpu(), z_ref.detach()) <= 1.0, ("bn_act_fwd element-wise", elem_err(z.cpu(), z_ref.detach()))
     dy = ops.new_act(n, c, h, w, dtype, "cuda")
     dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
     ops.bn_act_bwd(to_dev(ops, gz, dtype), yd, scale, shift, mean, rstd, ops.ACT_SILU, dy, dg, db)

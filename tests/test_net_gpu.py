@@ -118,6 +118,44 @@ def test_eval_vs_oracle_fresh_input(net):
     assert_close(seg.cpu(), rseg, 1e-3, "seg")
 
 
+def test_config2_at_its_own_batch_fused_fp32_vs_oracle(net):
+    """BASELINE.json config 2 at ITS size: 16 x 3 x 640 x 640 fp32, Model.fuse()d, forward + Detect decode against the oracle's fused
+    forward on the same seeded batch (the goldens stop at batch 2, and the tile / kernel selection depends on M = N*H*W: batch 16
+    takes the thin fp32 Focus kernel, the 128 x 32 and long-K weights-stationary fp32 tiles that smaller batches never reach), then
+    non_max_suppression(0.25, 0.45, max_det 1000) on the HIP `pred` against oracle.nms_ref on that SAME pred: selection exact.
+    Tolerances: 1e-3 per tensor (max|a-b| / max|b|, BASELINE.json) on pred, the three raw heads and seg, AND element-wise
+    |a-b| <= 1e-3 |b| + 1e-3 rms(b) (tests/util.py: elem_err) on the raw heads and seg -- `pred` is excluded from the element-wise
+    form only because its w/h columns are (2 sigmoid)^2 * anchor of the raw logits already held element-wise."""
+    import copy
+    from oracle import desenet_ref as R
+    from oracle import nms_ref
+    from desenet_amd.core.utils.general import non_max_suppression
+    from tests.util import elem_err
+    _, m = net
+    cfg = load_cfg()
+    sd = R.fold_bn({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    mf = copy.deepcopy(m).eval().fuse()
+    x = synth_images(16, 640, 2)
+    with torch.no_grad():
+        (rpred, rraws), rseg, _ = R.forward(cfg, sd, x, fused=True)
+        (pred, raws), seg = mf(x.cuda())
+    assert tuple(pred.shape) == (16, 25200, 11) and tuple(seg.shape) == (16, 2, 640, 640)
+    assert_close(pred.cpu(), rpred, 1e-3, "pred")
+    assert_close(seg.cpu(), rseg, 1e-3, "seg")
+    assert elem_err(seg.cpu(), rseg) <= 1.0, ("seg element-wise", elem_err(seg.cpu(), rseg))
+    for i, (a, b) in enumerate(zip(raws, rraws)):
+        assert_close(a.cpu(), b, 1e-3, f"raw{i}")
+        assert elem_err(a.cpu(), b) <= 1.0, (f"raw{i} element-wise", elem_err(a.cpu(), b))
+    out = non_max_suppression(pred, 0.25, 0.45, max_det=1000)
+    want = nms_ref.non_max_suppression(pred.cpu().numpy(), 0.25, 0.45, max_det=1000)
+    assert len(out) == 16
+    kept = 0
+    for o, w in zip(out, want):
+        assert tuple(o.shape) == w.shape and np.array_equal(o.cpu().numpy(), w), (o.shape, w.shape)
+        kept += len(w)
+    assert kept > 0
+
+
 def _train_step(dsn, m, bs, size, seed, dtype):
     import copy
     from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses
@@ -516,14 +554,15 @@ def test_teacher_forced_layer_backward_at_640(net, dtype, tol):
     for the same isolated layer (torch.autograd.grad over oracle.desenet_ref.apply_layer in fp32 on the CPU).
     rel err = max|a-b| / max|b| per tensor <= 5e-3 in fp32 and <= 6e-2 in bf16; gradients whose oracle value is numerically zero
     (max|b| < 1e-12: the BatchNorm before a 1x1-map Conv, quirk Q1) must be zero or absent.
-    One documented exception in bf16: SPP (layer 8).  Its three max pools route each output's gradient to the FIRST maximum of a
-    5x5 / 9x9 / 13x13 window; on bf16-rounded activations the largest values of a window tie in a sizeable share of the windows,
-    and the first of the tied pixels is not the pixel whose fp32 value is largest -- the gradient mass moves to another pixel of
-    the window (exactly what ATen's own bf16 max_pool2d does), which the per-element comparison with the fp32 oracle sees as a
-    large error in dx and in cv1's gradients although every kernel is exact (the fp32 run of this test holds layer 8 to 5e-3, and
-    tests/test_resample_r3_gpu.py pins values and arg-max indices bit for bit, ties included).  Bound there: the gradient NORM
-    within 25 % (the bound of the whole-net bf16 tests)."""
+    SPP (layer 8) in bf16: its three max pools route each output's gradient to the FIRST maximum of a 5x5 / 9x9 / 13x13 window, and
+    on bf16-rounded activations the largest values of a window tie in a sizeable share of the windows -- the first of the tied
+    pixels is not the pixel whose fp32 value is largest (exactly what ATen's own bf16 max_pool2d does).  The oracle for that layer
+    is therefore TEACHER-FORCED with the pool input the kernels saw (cv1's bf16 output, straight-through for the gradient, as in
+    tests/test_modules_gpu.py::_spp_reference_with_the_kernels_pool_input), so both sides route through the same ties with the
+    same first-maximum rule and the layer is held to the same 6e-2 per tensor as every other one (round 3 bounded its gradient
+    NORM by 25 % instead, which bounds nothing per element)."""
     import copy
+    import torch.nn.functional as F
     from oracle import desenet_ref as R
     from oracle import loss_ref
     dsn, m = net
@@ -561,7 +600,18 @@ def test_teacher_forced_layer_backward_at_640(net, dtype, tol):
             # oracle, isolated layer (fresh running statistics: BatchNorm's train-mode forward updates them in place)
             sdl = {k: v.clone().requires_grad_(is_p(k)) for k, v in sd0.items()}
             oin = [t.detach().clone().requires_grad_(L.i != 0) for t in (raw if lst else [raw])]
-            oout = R.apply_layer(R.Ctx(sdl, training=True), L, oin if lst else oin[0])
+            if dtype == torch.bfloat16 and L.kind == "SPP":
+                # tie-aware reference: the oracle's pools see the pool input the KERNELS saw (cv1's bf16 output, straight-through
+                # for the gradient), so both sides route every window's gradient through the same first maximum
+                with torch.no_grad():
+                    z0_hip = copy.deepcopy(HL).train().cv1(oin[0].detach().cuda()).float().cpu()
+                cxl = R.Ctx(sdl, training=True)
+                z0 = R.conv_bn_act(cxl, oin[0], f"model.{L.i}.cv1", 1)
+                z0 = z0 + (z0_hip - z0).detach()
+                oout = R.conv_bn_act(cxl, torch.cat([z0] + [F.max_pool2d(z0, k, 1, k // 2) for k in L.args[2]], 1),
+                                     f"model.{L.i}.cv2", 1)
+            else:
+                oout = R.apply_layer(R.Ctx(sdl, training=True), L, oin if lst else oin[0])
             pk = [k for k in sdl if k.startswith(f"model.{L.i}.") and sdl[k].requires_grad]
             oo = list(oout) if isinstance(oout, (list, tuple)) else [oout]
             uu = ups[L.i] if isinstance(ups[L.i], list) else [ups[L.i]]
@@ -586,11 +636,6 @@ def test_teacher_forced_layer_backward_at_640(net, dtype, tol):
                 assert g is not None, (L.i, nme, "no HIP gradient")
                 e = rel_err(g.float().cpu(), o)
                 worst[(L.i, nme)] = e
-                if dtype == torch.bfloat16 and L.kind == "SPP" and not e <= tol:
-                    nerr = abs(float(g.float().norm()) - float(o.norm())) / float(o.norm())      # tie routing: see the docstring
-                    if not nerr <= 0.25:
-                        bad[(L.i, nme)] = ("norm", nerr)
-                    continue
                 if not e <= tol:
                     bad[(L.i, nme)] = e
     finally:

@@ -38,6 +38,20 @@ def rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
+def elem_err(a, b, rtol=1e-3):
+    """Element-wise companion of rel_err for fp32 results: the worst |a-b| / (rtol*|b| + rtol*rms(b)) over the tensor.  <= 1 means
+    every element is within rtol of its OWN magnitude plus rtol of the tensor's rms (the absolute floor keeps elements that are
+    zero by cancellation from demanding infinite relative accuracy).  Unlike max|a-b| / max|b| it does not let the large elements
+    of a tensor hide a wrong small one (seg logits near 0, raw w/h channels)."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    rms = b.pow(2).mean().sqrt()
+    return ((a - b).abs() / (rtol * b.abs() + rtol * rms + 1e-30)).max().item()
+
+
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
