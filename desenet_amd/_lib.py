@@ -177,9 +177,6 @@ PROTOTYPES = {
     "dsn_seg_ce_up_workspace_bytes": (i64, [i32, i32, i32, i32, i32]),
     "dsn_seg_ce_up": (i32, [TP, vp, i32, i32, i32, f32, vp, TP, vp, i64, vp]),
     "dsn_cast": (i32, [vp, vp, i32, i64, vp]),
-    "dsn_conv2d_fwd_lazy": (i32, [TP, vp, vp, vp, TP, TP, CP, vp, i64, vp]),
-    "dsn_conv2d_fwd_lazy_z": (i32, [TP, vp, TP, vp, vp, TP, TP, CP, vp, i64, vp]),
-    "dsn_conv2d_wgrad_plan_lazy": (i32, [TP, vp, TP, vp, i32, i32, CP, vp, i64, vp]),
     "dsn_bn_finalize_multi": (i32, [vp, i32, vp]),
     "dsn_lazy_materialize": (i32, [TP, vp, TP, vp, TP, vp]),
     "dsn_fill32": (i32, [vp, C.c_uint32, i64, vp]),

@@ -108,44 +108,13 @@ def _bn_sync(bn):
 
 
 import os as _os
-# Which consumers apply a deferred transform themselves.  The implicit-GEMM kernels re-stage every input element once per
-# filter tap and per output-channel tile, and SiLU costs ~38 VALU cycles per element per wave (v_exp_f32 + v_rcp_f32 are
-# quarter rate): measured on MI355X, a 3x3 consumer that transforms in its loader is VALU-bound and 2x slower (the 64x64 tile:
-# 16.7 -> 32.8 us), the all-taps weight gradient 4x.  1x1 consumers re-apply only once per output-channel tile: there the removed
-# BatchNorm pass was expected to outweigh the extra VALU work -- measured (profiles/r02c_*): it does not either; the 1x1 consumers
-# got 40 % slower and the queued 1x1 weight gradients 2x (x is re-staged once per output-channel tile), 5.01 -> 5.47 ms per step.
-# Default 0: nothing is deferred (every block materialises z with one elementwise launch, as before); DSN_LAZY_TAPS=1 / 9 turn the
-# 1x1 / every consumer on for experiments, and the kernels stay bit-exact against the materialised path (tests/test_lazy_gpu.py).
-_LAZY_MAX_TAPS = int(_os.environ.get("DSN_LAZY_TAPS", "0"))
-# Third form (DSN_LAZY_Z=1): the LDS-DMA kernels (conv3x3.hip) hold a block's whole input tile in LDS before the first MFMA, so the
-# transform can be applied ONCE per block there, with the materialised tile stored on the way (dsn_conv2d_fwd_lazy_z) -- no second
-# read of y and 29 fewer launches per DeSeNet-s step.  Measured (profiles/r02g_*): bit-exact, but slower as well, 4.77 -> 5.04 ms per
-# step: each block has to fold the fp64 accumulators of ALL its input channels before it can transform (16 L2 loads + an fp64
-# rsqrt per channel, queued behind the LDS-DMA), then runs the SiLU pass at two resident blocks per CU, once per output-channel
-# tile -- the one-trip 1x1 kernel with 256 input channels went from 10.7 to 33 us, more than the 7 us elementwise launch it replaced
-# (producer-side finalisation was measured in round 1: ~7 us of device-scope round trips at the kernel's tail).  Default 0.
-_LAZY_Z = int(_os.environ.get("DSN_LAZY_Z", "0"))
 
-
-def _lazy_operand(tape, x, taps=1):
-    """(x', lazy descriptor | None, z | None): x itself plus the descriptor of its deferred-BatchNorm segments when the convolution
-    can apply them while staging x -- with z, a fresh tensor that receives the materialised x on the way -- otherwise a
-    materialised copy of x, None and None."""
-    if tape is None:
-        return x, None, None
-    lz = tape.lazy_in(x)
-    if lz is None:
-        return x, None, None
-    if lz is False or not ops.lazy_input_ok(x):
-        return tape.materialize(x), None, None
-    z = tape.lazy_copy(x)
-    if z is not None:
-        return z, None, None
-    if taps <= max(_LAZY_MAX_TAPS, 1 if getattr(tape, "lazy_force", False) else 0):
-        return x, lz, None
-    if _LAZY_Z:
-        return x, lz, ops.new_act(*x.shape, x.dtype, x.device)
-    return tape.materialize(x), None, None
+# BatchNorm in training: the convolution's epilogue adds per-channel sums into fp64 accumulators, ONE elementwise launch
+# (dsn_lazy_materialize) folds them in its prologue and writes z = act(bn(y)) (+ shortcut), and the saved statistics / running
+# averages of all modules are written by one finalisation launch at the end of the forward pass (runtime.Tape.finalize_forward).
+# (Rounds 2-3 also carried CONSUMER-side forms -- act(bn(.)) applied in the next convolution's operand loader, or once per block
+#  inside the LDS-DMA kernels -- behind DSN_LAZY_TAPS / DSN_LAZY_Z.  Both measured slower, 5.01 -> 5.47 / 6.66 ms and 4.77 -> 5.04 ms
+#  per step, and were deleted in round 4 together with their kernel instantiations.)
 
 
 def _defer_ok(bn, out, co, bias, sync) -> bool:
@@ -154,11 +123,8 @@ def _defer_ok(bn, out, co, bias, sync) -> bool:
 
 
 def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, training: bool, tape=None, out=None,
-                   residual=None, q1: bool = False, ci_pad: Optional[int] = None, lazy_out: bool = False):
-    """x: NHWC-backed activation (channels may be zero-padded up to ci_pad).  Returns z (written into `out` if given).
-    lazy_out (training, with a tape): the caller guarantees that every consumer of the result is a convolution of this package
-    reading it through the same tape -- the block then writes the RAW conv output into `out`, tags it as deferred and skips the
-    BatchNorm + activation pass (runtime.LazyRec).  Without it the result is materialised as usual."""
+                   residual=None, q1: bool = False, ci_pad: Optional[int] = None):
+    """x: NHWC-backed activation (channels may be zero-padded up to ci_pad).  Returns z (written into `out` if given)."""
     k, s, p, d = _conv_geom(conv)
     n, co, ho, wo = out_shape(conv, x)
     dtype = x.dtype
@@ -175,60 +141,35 @@ def conv_block_fwd(x, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], act: int, t
     w, bias = packed_fwd(conv, dtype, ci_pad, None)
     plain = skip_bn and act == ACT_NONE and residual is None
     sync = _bn_sync(bn) if train_bn else None
-    x_in = x
-    x, lz, zx = _lazy_operand(tape, x, k * k)
-    # (zx: the convolution below also writes the materialised x there -- that is what the weight gradient reads)
-    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x if zx is None else zx, x_in=x_in, ci_pad=ci_pad,
-               geom=(k, s, p, d), plain=plain)
+    rec = dict(conv=conv, bn=None if skip_bn else bn, act=act, x=x, x_in=x, ci_pad=ci_pad, geom=(k, s, p, d), plain=plain)
     if train_bn and tape is not None and _defer_ok(bn, out, co, bias, sync):
-        # deferred path: conv (+ BatchNorm sums in its epilogue) and nothing else when the output may stay raw; otherwise ONE
-        # elementwise launch materialises z (+ shortcut).  Saved statistics / running averages: end-of-forward finalisation.
-        defer = lazy_out and residual is None and (_LAZY_MAX_TAPS > 0 or _LAZY_Z or lazy_out == "force")
-        y = out if defer else ops.new_act(n, co, ho, wo, dtype, x.device)
-        acc, _ = ops.conv2d_fwd_acc(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz, z_out=zx)
-        if zx is not None:
-            tape.lazy_register_copy(x, zx)
+        # conv (+ BatchNorm sums in its epilogue), then ONE elementwise launch writes z (+ shortcut).  Saved statistics / running
+        # averages: end-of-forward finalisation.
+        y = ops.new_act(n, co, ho, wo, dtype, x.device)
+        acc, _ = ops.conv2d_fwd_acc(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE))
         stats = torch.empty((4, co), dtype=torch.float32, device=x.device)
         count = n * ho * wo
-        if defer:
-            tape.lazy_tag(out, acc, co, 0, count, bn, act, stats)
-        else:
-            me = _self_lazy(acc, co, 0, 0, co, count, bn, act)
-            res, lres = residual, None
-            if residual is not None and tape.lazy_copy(residual) is not None:
-                res = tape.lazy_copy(residual)          # (an earlier consumer materialised it on the way)
-            elif residual is not None:
-                lres = tape.lazy_in(residual)
-                if lres is False or (lres is not None and not ops.lazy_input_ok(residual)):
-                    res, lres = tape.materialize(residual), None
-            ops.lazy_materialize(y, me, out, res, lres)
-            tape.lazy_pending_only(acc, co, 0, co, count, bn, stats)
+        ops.lazy_materialize(y, _self_lazy(acc, co, 0, 0, co, count, bn, act), out, residual, None)
+        tape.lazy_pending_only(acc, co, 0, co, count, bn, stats)
         if bn.num_batches_tracked is not None and not bn.__dict__.get("_dsn_shared_counter"):
             bn.num_batches_tracked.add_(1)    # (a Model increments all of its counters with one launch per step)
         rec.update(y=y, scale=stats[0], shift=stats[1], mean=stats[2], rstd=stats[3], frozen=False, sync=None)
         tape.push(rec)
         tape.bn_register(out, rec)
         return out
-    if residual is not None and tape is not None:
-        residual = tape.materialize(residual)
     y = out if plain else ops.new_act(n, co, ho, wo, dtype, x.device)
     rec["y"] = y
     stats = None
     if train_bn and bias is None and co <= 1024:
         # BatchNorm statistics come out of the conv epilogue (fp32 accumulators) and are folded in the prologue of the
         # BN + act kernel: conv -> BN -> act is two launches, y is read once
-        if lz is not None:
-            x, lz, zx = tape.materialize(x), None, None
-            rec["x"] = x
         stats = ops.conv2d_fwd_bnstats(x, w, y, ops.conv_params(k, s, p, d, ACT_NONE), bn.weight, bn.bias, bn.running_mean,
                                        bn.running_var, bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps,
                                        act, residual, out, sync=sync)
     else:
         if sync is not None:
             raise NotImplementedError("SyncBatchNorm after a biased or > 1024-channel convolution (not in DeSeNet)")
-        ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE), lazy=lz, z_out=zx)
-        if zx is not None:
-            tape.lazy_register_copy(x, zx)
+        ops.conv2d_fwd(x, w, bias, None, y, ops.conv_params(k, s, p, d, ACT_NONE))
     if plain:
         pass
     elif skip_bn:
@@ -295,10 +236,9 @@ def pair_ready(blk_a, blk_b, x, tape, dtype):
     return hit
 
 
-def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
-    """z[:, :coA] = blk_a(x), z[:, coA:] = blk_b(x) as ONE convolution (`out`: coA+coB channels).  lazy_out: both halves stay
-    raw in `out`, tagged as deferred (two BatchNorm modules over one accumulator); otherwise one elementwise launch
-    materialises them."""
+def pair_block_fwd(x, blk_a, blk_b, hit, tape, out):
+    """z[:, :coA] = blk_a(x), z[:, coA:] = blk_b(x) as ONE convolution (`out`: coA+coB channels) and ONE elementwise launch over two
+    BatchNorm modules that share an accumulator."""
     ca, cb, ba, bb = blk_a.conv, blk_b.conv, blk_a.bn, blk_b.bn
     _, _, wf, _ = hit
     n, _, h, w = x.shape
@@ -307,28 +247,17 @@ def pair_block_fwd(x, blk_a, blk_b, hit, tape, out, lazy_out: bool = False):
     act = act_code(blk_a.act)
     sync = _bn_sync(ba)
     x_in = x
-    x, lz, zx = _lazy_operand(tape, x)
     if _defer_ok(ba, out, co, None, sync) and coa % 8 == 0:
-        lazy_out = bool(lazy_out) and (_LAZY_MAX_TAPS > 0 or _LAZY_Z or lazy_out == "force")
-        y = out if lazy_out else ops.new_act(n, co, h, w, x.dtype, x.device)
-        acc, _ = ops.conv2d_fwd_acc(x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE), lazy=lz, z_out=zx)
-        if zx is not None:
-            tape.lazy_register_copy(x, zx)
-            x = zx
+        y = ops.new_act(n, co, h, w, x.dtype, x.device)
+        acc, _ = ops.conv2d_fwd_acc(x, wf, y, ops.conv_params(1, 1, 0, 1, ACT_NONE))
         stats = torch.empty((4, co), dtype=torch.float32, device=x.device)
         count = n * h * w
-        if lazy_out:
-            tape.lazy_tag(out[:, :coa], acc, co, 0, count, ba, act, stats, o0=0)
-            tape.lazy_tag(out[:, coa:], acc, co, coa, count, bb, act, stats, o0=coa)
-        else:
-            ops.lazy_materialize(y, _self_lazy(acc, co, 0, 0, co, count, ba, act, second=(coa, bb)), out)
-            tape.lazy_pending_only(acc, co, 0, coa, count, ba, stats, o0=0)
-            tape.lazy_pending_only(acc, co, coa, co - coa, count, bb, stats, o0=coa)
+        ops.lazy_materialize(y, _self_lazy(acc, co, 0, 0, co, count, ba, act, second=(coa, bb)), out)
+        tape.lazy_pending_only(acc, co, 0, coa, count, ba, stats, o0=0)
+        tape.lazy_pending_only(acc, co, coa, co - coa, count, bb, stats, o0=coa)
         scale, shift, mean, rstd = stats[0], stats[1], stats[2], stats[3]
         sync = None
     else:
-        if lz is not None:
-            x, zx = tape.materialize(x), None
         y = ops.new_act(n, co, h, w, x.dtype, x.device)
         mom = ba.momentum if ba.momentum is not None else BN_MOMENTUM
         scale, shift, mean, rstd = ops.conv2d_fwd_bnstats(
@@ -441,15 +370,8 @@ def _dgrad_red(dy, w, dx, params, residual, red, marks, s2=False):
 
 
 def _wgrad(tape, x, dy, g, ci, params, queue):
-    """dW (+)= wgrad(x, dy) into the OIHW gradient g.  x may carry deferred-BatchNorm segments: the queued kernels apply them
-    while staging x (scale / shift arrays of the finalised forward pass); shapes they cannot take get a materialised x."""
-    lz = tape.lazy_in(x, backward=True)
-    if lz is not None and (lz is False or queue is None or not ops.lazy_input_ok(x)):
-        x, lz = tape.materialize(x, backward=True), None
-    try:
-        ops.conv2d_wgrad(x, dy, g, ci, params, oihw=True, queue=queue, lazy=lz)
-    except ops.LazyUnsupported:
-        ops.conv2d_wgrad(tape.materialize(x, backward=True), dy, g, ci, params, oihw=True, queue=queue)
+    """dW (+)= wgrad(x, dy) into the OIHW gradient g (queued: planned now, launched with every other layer's at the end of the pass)."""
+    ops.conv2d_wgrad(x, dy, g, ci, params, oihw=True, queue=queue)
 
 
 class _NullCtx:

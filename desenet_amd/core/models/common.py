@@ -68,13 +68,11 @@ class Conv(HipModule):
     def fused(self) -> bool:
         return not hasattr(self, "bn")
 
-    def fwd(self, x, tape=None, out=None, residual=None, ci_pad=None, lazy_out=False):
-        """lazy_out: leave the result as the raw conv output, tagged as deferred on the tape (conv_impl.conv_block_fwd) -- only a
-        caller that knows every consumer is a convolution of this package may ask for it."""
+    def fwd(self, x, tape=None, out=None, residual=None, ci_pad=None):
         x = _as_input(x)
         bn = None if self.fused else self.bn
         return conv_block_fwd(x, self.conv, bn, act_code(self.act), self.training, tape, out, residual,
-                              q1=not self.fused, ci_pad=ci_pad, lazy_out=lazy_out)
+                              q1=not self.fused, ci_pad=ci_pad)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, residual=None, fuse_up=False):
         """fuse_up: this call completes the gradient of the block's input (conv_impl.conv_block_bwd)."""
@@ -92,11 +90,11 @@ class Bottleneck(HipModule):
         self.cv2 = Conv(c_, c2, 3, 1, g=g)
         self.add = shortcut and c1 == c2
 
-    def fwd(self, x, tape=None, out=None, lazy_out=False):
+    def fwd(self, x, tape=None, out=None):
         x = _as_input(x)
-        t = self.cv1.fwd(x, tape, lazy_out=True)                 # consumed by cv2 only: BN + SiLU ride in its operand staging
-        # the shortcut is added by the pass that materialises z (a deferred x is transformed there as well)
-        return self.cv2.fwd(t, tape, out, residual=x if self.add else None, lazy_out=lazy_out and not self.add)
+        t = self.cv1.fwd(x, tape)
+        # the shortcut is added by the elementwise pass that writes z = act(bn(y))
+        return self.cv2.fwd(t, tape, out, residual=x if self.add else None)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
         dt = self.cv2.bwd(tape, dy, fuse_up=True)               # (cv1's output has no other consumer: dt is complete)
@@ -115,7 +113,7 @@ class C3(HipModule):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
-    def fwd(self, x, tape=None, out=None, lazy_out=False):
+    def fwd(self, x, tape=None, out=None):
         x = _as_input(x)
         c_ = self.cv1.conv.out_channels
         n, _, h, w = x.shape
@@ -128,19 +126,19 @@ class C3(HipModule):
             cat3 = ops.new_act(n, 3 * c_, h, w, x.dtype, x.device)
             # every consumer inside the block is a convolution (Bottleneck.cv1, cv3) or the materialising pass of a shortcut:
             # the pair and the chain's last output stay raw
-            pair_block_fwd(x, self.cv2, self.cv1, hit, tape, cat3[:, c_:], lazy_out=True)
+            pair_block_fwd(x, self.cv2, self.cv1, hit, tape, cat3[:, c_:])
             a = cat3[:, 2 * c_:]
             for i, b in enumerate(blocks):
-                a = b.fwd(a, tape, cat3[:, :c_] if i == len(blocks) - 1 else None, lazy_out=True)
-            z = self.cv3.fwd(cat3[:, :2 * c_], tape, out, lazy_out=lazy_out)
+                a = b.fwd(a, tape, cat3[:, :c_] if i == len(blocks) - 1 else None)
+            z = self.cv3.fwd(cat3[:, :2 * c_], tape, out)
             tape.push("c3-merged")
             return z
         cat = ops.new_act(n, 2 * c_, h, w, x.dtype, x.device)
-        a = self.cv1.fwd(x, tape, cat[:, :c_] if not blocks else None, lazy_out=True)
+        a = self.cv1.fwd(x, tape, cat[:, :c_] if not blocks else None)
         for i, b in enumerate(blocks):
-            a = b.fwd(a, tape, cat[:, :c_] if i == len(blocks) - 1 else None, lazy_out=True)
-        self.cv2.fwd(x, tape, cat[:, c_:], lazy_out=True)
-        z = self.cv3.fwd(cat, tape, out, lazy_out=lazy_out)
+            a = b.fwd(a, tape, cat[:, :c_] if i == len(blocks) - 1 else None)
+        self.cv2.fwd(x, tape, cat[:, c_:])
+        z = self.cv3.fwd(cat, tape, out)
         if tape is not None:
             tape.push("c3-plain")
         return z
@@ -177,7 +175,7 @@ class SPP(HipModule):
         self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
         self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
 
-    def fwd(self, x, tape=None, out=None, lazy_out=False):
+    def fwd(self, x, tape=None, out=None):
         x = _as_input(x)
         c_ = self.cv1.conv.out_channels
         n, _, h, w = x.shape
@@ -188,7 +186,7 @@ class SPP(HipModule):
                              [int(mp.kernel_size) for mp in self.m], idxs)          # one launch, x0 read once
         if tape is not None:
             tape.push(idxs)
-        return self.cv2.fwd(cat, tape, out, lazy_out=lazy_out)
+        return self.cv2.fwd(cat, tape, out)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
         c_ = self.cv1.conv.out_channels
@@ -207,7 +205,7 @@ class Focus(HipModule):
         super().__init__()
         self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
 
-    def fwd(self, x, tape=None, out=None, lazy_out=False):
+    def fwd(self, x, tape=None, out=None):
         if not x.is_cuda:
             raise RuntimeError("desenet_amd kernels run on an MI355X only: got a CPU tensor (there is no CPU fallback)")
         dt = compute_dtype()
@@ -216,7 +214,7 @@ class Focus(HipModule):
         cpad = (4 * c + vec - 1) // vec * vec          # 12 -> 12 (fp32) / 16 (bf16): 16-byte channel vectors
         s2d = ops.new_act(n, cpad, h // 2, w // 2, dt, x.device)
         ops.focus_s2d(x, s2d)
-        return self.conv.fwd(s2d, tape, out, ci_pad=cpad, lazy_out=lazy_out)
+        return self.conv.fwd(s2d, tape, out, ci_pad=cpad)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True):
         if need_dx:
@@ -317,8 +315,8 @@ class _ConvBnAct(nn.Sequential):
     def forward(self, x):
         return run_module(self, x)
 
-    def fwd(self, x, tape=None, out=None, lazy_out=False):
-        return conv_block_fwd(_as_input(x), self[0], self[1], ACT_SILU, self.training, tape, out, lazy_out=lazy_out)
+    def fwd(self, x, tape=None, out=None):
+        return conv_block_fwd(_as_input(x), self[0], self[1], ACT_SILU, self.training, tape, out)
 
     def bwd(self, tape, dy, dx=None, acc=False, need_dx=True, fuse_up=False):
         return conv_block_bwd(tape, dy, dx, acc, need_dx, fuse_up=fuse_up)
@@ -342,7 +340,7 @@ class RFB2(HipModule):
         self.branch3 = nn.Sequential(Conv(in_planes, inter, k=1, s=1))
         self.ConvLinear = Conv(4 * inter, out_planes, k=1, s=1)
 
-    def fwd(self, x, tape=None, out=None, lazy_out=False):
+    def fwd(self, x, tape=None, out=None):
         x = _as_input(x)
         i = self.branch1[0].in_channels
         n, _, h, w = x.shape
@@ -352,16 +350,16 @@ class RFB2(HipModule):
             # [x3 | t] into the tail of a 5i-wide buffer [x0 | x1 | x2 | x3 | t]; ConvLinear reads the first four fifths
             cat = ops.new_act(n, 5 * i, h, w, x.dtype, x.device)
             # every intermediate of the block feeds convolutions only (branch chain, ConvLinear): all of them stay raw
-            pair_block_fwd(x, self.branch3[0], self.branch0[0], hit, tape, cat[:, 3 * i:], lazy_out=True)
+            pair_block_fwd(x, self.branch3[0], self.branch0[0], hit, tape, cat[:, 3 * i:])
             t = cat[:, 4 * i:]
         else:
             cat = ops.new_act(n, 4 * i, h, w, x.dtype, x.device)     # [x0 | x1 | x2 | x3]
-            self.branch3[0].fwd(x, tape, cat[:, 3 * i:], lazy_out=True)
-            t = self.branch0[0].fwd(x, tape, lazy_out=True)
-        x0 = self.branch0[1].fwd(t, tape, cat[:, :i], lazy_out=True)
-        x1 = self.branch1.fwd(x0, tape, cat[:, i:2 * i], lazy_out=True)
-        self.branch2.fwd(x1, tape, cat[:, 2 * i:3 * i], lazy_out=True)
-        z = self.ConvLinear.fwd(cat[:, :4 * i], tape, out, lazy_out=lazy_out)
+            self.branch3[0].fwd(x, tape, cat[:, 3 * i:])
+            t = self.branch0[0].fwd(x, tape)
+        x0 = self.branch0[1].fwd(t, tape, cat[:, :i])
+        x1 = self.branch1.fwd(x0, tape, cat[:, i:2 * i])
+        self.branch2.fwd(x1, tape, cat[:, 2 * i:3 * i])
+        z = self.ConvLinear.fwd(cat[:, :4 * i], tape, out)
         if tape is not None:
             tape.push("rfb-merged" if hit is not None else "rfb-plain")
         return z

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip_ops as ops
-from ...conv_impl import _lazy_operand, conv_block_bwd, conv_block_fwd, packed_fwd
+from ...conv_impl import conv_block_bwd, conv_block_fwd, packed_fwd
 from ...hip_ops import ACT_NONE
 from ...runtime import run_module
 from ..utils.autoanchor import check_anchor_order
@@ -66,7 +66,7 @@ class SegMaskPSP(HipModule):
         n, _, h, w = x8.shape
         dt, dev = x8.dtype, x8.device
         cat = ops.new_act(n, 3 * c, h, w, dt, dev)                      # [m8 | up2(m16) | up4(m32)]
-        self.m8[0].fwd(x8, tape, cat[:, :c], lazy_out=True)              # read by RFB2's 1x1 convs only: stays raw
+        self.m8[0].fwd(x8, tape, cat[:, :c])
         f16 = self.m16[0].fwd(x16, tape)
         ops.bilinear_ac(f16, cat[:, c:2 * c])
         f32 = self.m32[0].fwd(x32, tape)
@@ -184,12 +184,7 @@ class Detect(HipModule):
         if any(x.dtype != dt for x in xs) or any(_conv_is_not_plain_1x1(m) for m in self.m) \
                 or not ops.detect_head_fwd_supported(dt, self.na, self.no, [x.shape[1] for x in xs]):
             return False
-        xm = []
-        for x in xs:
-            xi, lz, zx = _lazy_operand(tape, x, 1)
-            if lz is not None:                 # (consumer-side BatchNorm requested for this input: the per-level path handles it)
-                return False
-            xm.append(xi)
+        xm = list(xs)
         if not all(ops._vec16(x) for x in xm):
             return False
         n = xm[0].shape[0]
@@ -387,9 +382,8 @@ class Model(HipModule):
         self._plan_deferred()
 
     def _plan_deferred(self):
-        """Which top-level layers may leave their output as a raw, deferred-BatchNorm tensor (runtime.LazyRec): layers of a type
-        that can (Conv, Focus, C3, SPP) whose EVERY consumer in the graph applies the transform itself -- convolution-fronted
-        layers (Conv, C3, SPP, Detect, SegMaskPSP) directly, or through Concat layers, which only build views."""
+        """The consumer graph of the top-level layers and, from it, which layer's backward completes the gradient of its input
+        layer (BatchNorm backward sums in that launch's epilogue)."""
         consumers = {m.i: [] for m in self.model}
         for m in self.model:
             srcs = [m.i - 1] if m.f == -1 else ([m.f] if isinstance(m.f, int) else [m.i + j if j < 0 else j for j in m.f])
@@ -397,16 +391,6 @@ class Model(HipModule):
                 if 0 <= s_ < m.i:
                     consumers[s_].append(m)
 
-        def accepts(m, seen=()):
-            if isinstance(m, (Conv, C3, SPP, Detect, SegMaskPSP)):
-                return True
-            if isinstance(m, Concat) and m.i not in seen:
-                cs = consumers[m.i]
-                return bool(cs) and all(accepts(c, seen + (m.i,)) for c in cs)
-            return False
-
-        self._lazy_plan = {m.i: bool(consumers[m.i]) and isinstance(m, (Conv, Focus, C3, SPP))
-                           and all(accepts(c) for c in consumers[m.i]) for m in self.model}
         # layers whose backward writes the LAST contribution to the gradient of their (single) input layer -- the consumer with
         # the lowest index: the backward pass walks the layers downwards and every other consumer has already added its share to
         # the buffer this one accumulates into -- so that gradient is complete when they write it and its BatchNorm backward sums can
@@ -515,8 +499,7 @@ class Model(HipModule):
                 if buf is None:
                     buf = cats[cat_i] = ops.new_act(n, ctot, h, w, self._dtype_of(x), self._device_of(x))
                 dst = buf[:, c0:c0 + c]
-            kw = {"lazy_out": True} if (tape is not None and self._lazy_plan.get(m.i)) else {}
-            x = m.fwd(x, tape, dst, **kw) if dst is not None else m.fwd(x, tape, **kw)
+            x = m.fwd(x, tape, dst) if dst is not None else m.fwd(x, tape)
             y.append(x if m.i in self.save else None)
         if tape is not None:
             tape.finalize_forward()       # ONE launch: saved statistics + running averages of every BatchNorm of this pass

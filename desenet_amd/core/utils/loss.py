@@ -103,7 +103,7 @@ class SegmentationLosses(nn.CrossEntropyLoss):
         if up is not None:
             try:
                 return ops.seg_ce_up(pred, target, up, self.ignore_index, gain=gain)
-            except ops.LazyUnsupported:
+            except ops.KernelUnsupported:
                 n, c, h, w = pred.shape
                 seg = torch.empty((n, c, int(up[0]), int(up[1])), dtype=torch.float32, device=pred.device)
                 ops.bilinear_ac(pred, seg, out_nchw=True)

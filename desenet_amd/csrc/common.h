@@ -204,11 +204,11 @@ __device__ __forceinline__ void bn_acc_fold(const BnAcc& f, int c, double& s, do
 }
 #endif
 
-// ---- deferred BatchNorm + activation ("lazy" inputs) ------------------------------------------------------------------------
-// A training-mode Conv block may leave its output as the RAW convolution result y (plus the per-channel fp64 sums in its BnAcc)
-// instead of running the BN + act pass: every consumer that is a convolution applies z = act(y * scale + shift) while it stages
-// its input operand (igemm: registers -> LDS; wgrad: the x operand), so z never travels through HBM.  A consumer's input may be a
-// concat of several such tensors (and of ordinary, already materialised ones): up to DSN_LAZY_MAXSEG channel segments.
+// ---- BatchNorm + activation from accumulators (dsn_lazy_materialize's operand descriptor) -----------------------------------------
+// A training-mode Conv block leaves its RAW convolution result y plus the per-channel fp64 sums in its BnAcc; ONE elementwise launch
+// folds the accumulators in its prologue and writes z = act(y * scale + shift) (+ shortcut).  A tensor may be a concat of several
+// producers: up to DSN_LAZY_MAXSEG channel segments.  (Rounds 2-3 also applied the transform inside the CONSUMING convolution's
+// operand loader; measured slower and deleted in round 4 -- DESIGN.md 8.)
 //   acc != NULL : forward, before the producer's statistics have been finalised -- the consumer folds the accumulators itself
 //                 (every block, redundantly, exactly as ew_prologue does: identical scale / shift bits)
 //   acc == NULL : scale / shift arrays (written by dsn_bn_finalize_multi at the end of the forward pass) -- backward (wgrad)
@@ -257,31 +257,6 @@ __device__ __forceinline__ void lazy_table(const LazyIn& lz, int C, float* sc, f
         sh[c] = b;
         if ((c & 7) == 0) act8[c >> 3] = (unsigned char)act;
     }
-}
-// z = act(y * sc + sh) on one 16-byte vector of T (8 bf16 / 4 fp32); `valid` false -> zeros (padding taps stay zero AFTER the
-// activation).  The fp32 arithmetic and the final rounding are those of the elementwise BN + act kernel (bn_act.hip: FwdF).
-template <typename T> __device__ __forceinline__ u32x4 lazy_apply(u32x4 v, const float* sc, const float* sh, int act, bool valid);
-template <> __device__ __forceinline__ u32x4 lazy_apply<float>(u32x4 v, const float* sc, const float* sh, int act, bool valid) {
-    const f32x4 y = __builtin_bit_cast(f32x4, v);
-    f32x4 z;
-    float u[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = y[k] * sc[k] + sh[k];
-    apply_act_vec<4>(u, act);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) z[k] = valid ? u[k] : 0.f;
-    return __builtin_bit_cast(u32x4, z);
-}
-template <> __device__ __forceinline__ u32x4 lazy_apply<bf16_t>(u32x4 v, const float* sc, const float* sh, int act, bool valid) {
-    const bf16x8 y = __builtin_bit_cast(bf16x8, v);
-    bf16x8 z;
-    float u[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) u[k] = (float)y[k] * sc[k] + sh[k];
-    apply_act_vec<8>(u, act);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) z[k] = valid ? (bf16_t)u[k] : (bf16_t)0.f;
-    return __builtin_bit_cast(u32x4, z);
 }
 #endif
 
@@ -407,15 +382,11 @@ static inline void dsn_fill_u32(void* p, uint32_t v, int64_t n_words, hipStream_
 // conv3x3.hip: the halo-tile kernel for 3x3 / stride-1 convolutions (forward and data gradient).  Returns 1 when the layer is not
 // one it takes (nothing launched), 0 when it ran, another status on failure.  finp: BatchNorm accumulators for the epilogue or NULL.
 struct BnAcc;
-// lz + z (forward only): s carries deferred-BatchNorm segments; the kernel applies them once per block in LDS and stores the
-// materialised activation to z.
 int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
-                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
-                         const dsn_tensor* z = nullptr, const dsn_bnred* br = nullptr);
+                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
 
 int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
-                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_lazy_in* lz = nullptr,
-                        const dsn_tensor* z = nullptr, const dsn_bnred* br = nullptr);
+                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
 
 // conv_ws.hip: weights-stationary persistent kernels, tried before the one-trip kernels above (same return convention)
 int dsn_conv1x1_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,

@@ -36,7 +36,6 @@ struct HGeom {
     int32_t nslab;
     int32_t HH, HW, NP;       // halo rows / columns / pixels
     int32_t halo_stride;      // bytes between the two halo buffers (0: single buffer)
-    uint32_t z_bytes;         // deferred-BatchNorm launches: buffer range of the materialised activation
 };
 
 template <typename T> struct HMma;
@@ -78,16 +77,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // IH: LDS-DMA instructions per wave that bring in one halo slab (32 pixels each over the 4 waves): covers up to IH * 32 pixels
 // MULTI: more than one channel slab -- the next slab's patch is prefetched into a second halo buffer at tap 0 (with a single slab
 // there is no second buffer and nothing is prefetched; the counted waits differ accordingly).
-// LZ: the source holds RAW pre-BatchNorm values for the channel segments of `lz` (common.h: deferred BatchNorm + act).  Unlike the
-// implicit-GEMM kernel, which would have to transform every element once per TAP while staging it (measured: VALU-bound, 2x
-// slower), here the patch sits in LDS before the first MFMA: each thread transforms IN PLACE exactly the vectors it fetched --
-// once per block -- and, for the blocks of the first output-channel tile, also stores the patch interior to `zout`, so that the
-// materialised activation exists for everything else that needs it (weight gradient, other consumers) without a pass of its own.
-template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, bool MULTI, bool LZ = false>
+template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, bool MULTI>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                            const float* __restrict__ bias, const T* __restrict__ res,
-                                                           T* __restrict__ dst, const BnAcc fin, const HGeom g, const LazyIn lz,
-                                                           T* __restrict__ zout, int64_t zld, const BnRed br) {
+                                                           T* __restrict__ dst, const BnAcc fin, const HGeom g, const BnRed br) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static_assert(BM == TH * TW, "the M tile is the TH x TW patch");
@@ -100,10 +93,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     // [weight ring: NBR x BN rows][halo buffer 0][halo buffer 1]; the epilogue's fp32 staging tile reuses the front
     unsigned char* sB = smem;
     unsigned char* sH = smem + NBR * BN * ROWB;
-    // LZ: (scale, shift, act) table behind the halo buffers
-    float* t_sc = reinterpret_cast<float*>(sH + (size_t)IH * 32 * ROWB * (MULTI ? 2 : 1));
-    float* t_sh = t_sc + (LZ ? g.Cs : 0);
-    unsigned char* t_act = reinterpret_cast<unsigned char*>(t_sh + (LZ ? g.Cs : 0));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -122,10 +111,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 
     // ---- halo fetch plan: instruction j of this wave covers halo pixels 32*j + 8*wave .. +8, lane -> pixel p, physical slot lane & 7
     uint32_t hoff[IH];
-    uint32_t zoff[LZ ? IH : 1];                // LZ: byte offset of the vector inside zout (patch interior, first N tile) or OOB
-    int hls[LZ ? IH : 1];                      // LZ: logical slot of the vector
-    u32x4 zv[LZ ? IH : 1];                     // LZ: the transformed vectors of the current slab (stored after the iteration's DMA)
-    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)zout, 0, LZ ? g.z_bytes : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < IH; ++j) {
         const int p = 32 * j + 8 * wave + (lane >> 3);
@@ -134,35 +119,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
         const bool ok = p < g.NP && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
         const int ls = hslot(lane & 7, hx);                                 // logical slot this lane fetches (hslot is an involution)
         hoff[j] = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + ls * VEC) * (uint32_t)sizeof(T) : OOB;
-        if constexpr (LZ) {
-            const bool interior = ok && tn == 0 && hy >= g.d && hy < g.d + TH && hx >= g.d && hx < g.d + TW;
-            zoff[j] = interior ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * zld + ls * VEC) * (uint32_t)sizeof(T) : OOB;
-            hls[j] = ls;
-        }
     }
-    // LZ: in-place transform of the halo slab `slab` in buffer hbuf (every thread: the vectors it fetched itself)
-    auto transform = [&](int slab, int hbuf) {
-        if constexpr (LZ) {
-#pragma unroll
-            for (int j = 0; j < IH; ++j) {
-                unsigned char* ptr = sH + hbuf * g.halo_stride + ((size_t)(32 * j + 8 * wave) * ROWB) + lane * 16;
-                const int ch = slab * KC + hls[j] * VEC;
-                u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
-                v = lazy_apply<T>(v, t_sc + ch, t_sh + ch, t_act[ch >> 3], hoff[j] != OOB);
-                *reinterpret_cast<u32x4*>(ptr) = v;
-                zv[j] = v;
-            }
-        }
-    };
-    // every wave issues exactly IH store instructions (lanes outside the patch interior carry an out-of-range offset and are
-    // dropped by the buffer unit), so that the counted vmcnt waits below stay exact
-    auto store_z = [&](int slab) {
-        if constexpr (LZ) {
-#pragma unroll
-            for (int j = 0; j < IH; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(zv[j], zrsrc, zoff[j] == OOB ? OOB : zoff[j] + (uint32_t)slab * ROWB, 0, 0);
-        }
-    };
     auto load_halo = [&](int slab, int hbuf) {
         const uint32_t add = slab < g.nslab ? (uint32_t)slab * ROWB : OOB;    // (past the last slab: every lane out of range)
 #pragma unroll
@@ -236,18 +193,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     load_halo(0, 0);
     load_w(0, 0);
     load_w(1, 1);
-    if constexpr (LZ) {
-        lazy_table(lz, g.Cs, t_sc, t_sh, t_act, 256);        // (its loads queue behind the LDS-DMA: one round trip)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // table writes retired before the first barrier publishes them
-    }
     int wbuf = 0, lbuf = 2;
     for (int s = 0; s < g.nslab; ++s) {
         const unsigned char* hb = sH + (s & 1) * g.halo_stride;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // outstanding vector-memory operations a wave may leave behind the ones it needs (issue order of iteration (s, 0):
-            // W(f + 2), [MULTI: halo(s + 1)], [LZ: IH stores of z]; W(f + 2) alone in the other iterations)
-            constexpr int EX = (MULTI ? IH : 0) + (LZ ? IH : 0);
+            // W(f + 2), [MULTI: halo(s + 1)]; W(f + 2) alone in the other iterations)
+            constexpr int EX = MULTI ? IH : 0;
             // lgkmcnt(0): the compiler may sink the MFMAs of the previous tap -- and with them the wait for their fragment reads --
             // BELOW this barrier (registers only: the "memory" clobbers do not hold them), which would leave ds_reads of ring stage
             // `lbuf` merely issued when another wave's LDS-DMA starts overwriting it after the barrier.  Observed: sporadic wrong
@@ -259,15 +212,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (LZ && t == 0) {                  // the slab's patch has landed (and the table is complete): transform it once
-                transform(s, s & 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
             load_w(s * 9 + t + 2, lbuf);
             if (MULTI && t == 0) load_halo(s + 1, (s + 1) & 1);      // (past the last slab: zeros into the buffer slab s - 1 used)
-            if (LZ && t == 0) store_z(s);
             const int ky = t / 3, kx = t - ky * 3;
             const int oy = (g.flip ? 2 - ky : ky) * g.d, ox = (g.flip ? 2 - kx : kx) * g.d;
             compute(hb, oy, ox, wbuf);
@@ -380,16 +326,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
     }
 }
 
-struct LzArgs {                    // deferred-BatchNorm input of a launch: segments + where the materialised activation goes
-    const LazyIn* lz;
-    void* zout;
-    int64_t zld;
-    const BnRed* br;               // dgrad: BatchNorm backward sums of the block(s) whose dz this launch completes (or NULL)
-};
-
-template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, bool MULTI, bool LZ>
+template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH, bool MULTI>
 int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, HGeom g,
-                const BnAcc& fin, hipStream_t st, const LzArgs& la) {
+                const BnAcc& fin, hipStream_t st, const BnRed* brp) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     g.tiles_y = (g.H + TH - 1) / TH;
     g.tiles_x = (g.W + TW - 1) / TW;
@@ -398,18 +337,18 @@ int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const ds
     if (g.NP > IH * 32) return 1;                                              // dilation too large for this instantiation
     const size_t halo_bytes = (size_t)IH * 32 * ROWB;
     g.halo_stride = g.nslab > 1 ? (int32_t)halo_bytes : 0;
-    const size_t loop = (size_t)NBR * BN * ROWB + halo_bytes * (g.nslab > 1 ? 2 : 1) + (LZ ? (size_t)g.Cs * 8 + g.Cs / 8 + 16 : 0);
+    const size_t loop = (size_t)NBR * BN * ROWB + halo_bytes * (g.nslab > 1 ? 2 : 1);
     const size_t epi = (size_t)BM * (BN + CPAD) * 4 + 2 * 256 * 4;
     const size_t lds = loop > epi ? loop : epi;
-    auto kern = conv3x3_halo_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, MULTI, LZ>;
+    auto kern = conv3x3_halo_kernel<T, TH, TW, MI, NI, WGM, WGN, IH, MULTI>;
     DSN_LDS_ATTR(kern, 150 * 1024);
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
-    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) +
+    const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(brp)) +
                          9.0 * g.Cs * g.Cd;
     const ProfConv pc("conv3x3_halo_kernel", sizeof(T) == 2, BM, BN, g.flip != 0, 3, 1, g.d, g.Cs, g.Cd, g.N, g.H, g.W);
     ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,
-                       (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld, la.br ? *la.br : BnRed{});
+                       (T*)d->ptr, fin, g, brp ? *brp : BnRed{});
     DSN_LAUNCH_CHECK("conv3x3 (halo tile)");
     return DSN_OK;
 }
@@ -421,14 +360,10 @@ int launch_halo1(const dsn_tensor* s, const void* w, const float* bias, const ds
 // NS x 8 MFMAs per wave, then the epilogue -- against prologue address arithmetic, three register stages and a barrier per chunk in
 // the implicit-GEMM kernel.  NS = number of 128-byte channel slabs (1 .. 4), a template parameter so that the counted waits are
 // immediates.
-// LZ: as in the halo kernel -- the input tile holds raw pre-BatchNorm values; once everything has landed each thread transforms the
-// vectors it fetched in place (once per block, not once per MFMA fragment) and the blocks of the first output-channel tile store
-// the materialised tile to `zout`.
-template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool LZ = false>
+template <typename T, int MI, int NI, int WGM, int WGN, int NS>
 __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                           const float* __restrict__ bias, const T* __restrict__ res,
-                                                          T* __restrict__ dst, const BnAcc fin, const HGeom g, const LazyIn lz,
-                                                          T* __restrict__ zout, int64_t zld, const BnRed br) {
+                                                          T* __restrict__ dst, const BnAcc fin, const HGeom g, const BnRed br) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static_assert(BM % 32 == 0 && BN % 32 == 0, "stages are filled 32 rows per pass");
@@ -482,31 +417,6 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
         }
     };
     fetch_all();
-    if constexpr (LZ) {
-        float* t_sc = reinterpret_cast<float*>(smem + NS * (BM + BN) * ROWB);
-        float* t_sh = t_sc + g.Cs;
-        unsigned char* t_act = reinterpret_cast<unsigned char*>(t_sh + g.Cs);
-        lazy_table(lz, g.Cs, t_sc, t_sh, t_act, 256);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)zout, 0, g.z_bytes, 0x00020000);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                unsigned char* ptr = sA + ((size_t)(s * BM + 32 * i + 8 * wave) * ROWB) + lane * 16;
-                const int ch = s * (ROWB / (int)sizeof(T)) + ls * VEC;
-                u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
-                v = lazy_apply<T>(v, t_sc + ch, t_sh + ch, t_act[ch >> 3], aoff[i] != OOB);
-                *reinterpret_cast<u32x4*>(ptr) = v;
-                const int64_t m = m0 + r0 + 32 * i;
-                if (tn == 0 && aoff[i] != OOB)
-                    __builtin_amdgcn_raw_buffer_store_b128(v, zrsrc, (uint32_t)(m * zld + ls * VEC) * (uint32_t)sizeof(T) + (uint32_t)(s * ROWB), 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the barrier of slab 0 publishes the transformed tile)
-    }
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -536,18 +446,10 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
         }
     };
     // (the waits are immediates: one statement per slab; slab s may leave the LDS-DMA of the NS - 1 - s younger slabs in flight)
-    // (LZ: every LDS-DMA has landed already; the stores of z stay in flight)
-    if constexpr (LZ) {
-        if constexpr (NS > 0) slab(0);
-        if constexpr (NS > 1) slab(1);
-        if constexpr (NS > 2) slab(2);
-        if constexpr (NS > 3) slab(3);
-    } else {
-        if constexpr (NS > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPC) : "memory"); slab(0); }
-        if constexpr (NS > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPC) : "memory"); slab(1); }
-        if constexpr (NS > 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * LPC) : "memory"); slab(2); }
-        if constexpr (NS > 3) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 4) * LPC) : "memory"); slab(3); }
-    }
+    if constexpr (NS > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPC) : "memory"); slab(0); }
+    if constexpr (NS > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPC) : "memory"); slab(1); }
+    if constexpr (NS > 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * LPC) : "memory"); slab(2); }
+    if constexpr (NS > 3) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 4) * LPC) : "memory"); slab(3); }
     __syncthreads();
     // ---- epilogue (as igemm.hip): act(acc + bias) staged as fp32, BatchNorm partial sums, 16-byte stores ------------------------
     constexpr int VPR = BN / VEC;
@@ -648,74 +550,52 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
     }
 }
 
-template <typename T, int MI, int NI, int WGM, int WGN, int NS, bool LZ>
+template <typename T, int MI, int NI, int WGM, int WGN, int NS>
 int launch_1x1(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, HGeom g,
-               const BnAcc& fin, int is_dgrad, hipStream_t st, const LzArgs& la) {
+               const BnAcc& fin, int is_dgrad, hipStream_t st, const BnRed* brp) {
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     const int64_t M = (int64_t)g.N * g.H * g.W;
     g.tiles_n = (g.Cd + BN - 1) / BN;
-    const size_t loop = (size_t)NS * (BM + BN) * ROWB + (LZ ? (size_t)g.Cs * 8 + g.Cs / 8 + 16 : 0);
+    const size_t loop = (size_t)NS * (BM + BN) * ROWB;
     const size_t epi = (size_t)BM * (BN + CPAD) * 4 + 2 * 256 * 4;
     const size_t lds = loop > epi ? loop : epi;
-    auto kern = conv1x1_dma_kernel<T, MI, NI, WGM, WGN, NS, LZ>;
+    auto kern = conv1x1_dma_kernel<T, MI, NI, WGM, WGN, NS>;
     DSN_LDS_ATTR(kern, 150 * 1024);
     const int blocks = (int)((M + BM - 1) / BM) * g.tiles_n;
-    const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(la.br)) + (double)g.Cs * g.Cd;
+    const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(brp)) + (double)g.Cs * g.Cd;
     const ProfConv pc("conv1x1_dma_kernel", sizeof(T) == 2, BM, BN, is_dgrad != 0, 1, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
     ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * sizeof(T), st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const T*)s->ptr, (const T*)w, bias, r ? (const T*)r->ptr : nullptr,
-                       (T*)d->ptr, fin, g, LZ ? *la.lz : LazyIn{}, (T*)la.zout, la.zld, la.br ? *la.br : BnRed{});
+                       (T*)d->ptr, fin, g, brp ? *brp : BnRed{});
     DSN_LAUNCH_CHECK("conv1x1 (one-trip LDS-DMA)");
     return DSN_OK;
 }
 
 template <typename T, int MI, int NI, int WGM, int WGN>
 int launch_1x1_ns(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, const HGeom& g,
-                  const BnAcc& fin, int is_dgrad, hipStream_t st, const LzArgs& la) {
-    if (la.lz) {
-        switch (g.nslab) {
-            case 1: return launch_1x1<T, MI, NI, WGM, WGN, 1, true>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-            case 2: return launch_1x1<T, MI, NI, WGM, WGN, 2, true>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-            case 3: return launch_1x1<T, MI, NI, WGM, WGN, 3, true>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-            case 4: return launch_1x1<T, MI, NI, WGM, WGN, 4, true>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-            default: return 1;
-        }
-    }
+                  const BnAcc& fin, int is_dgrad, hipStream_t st, const BnRed* brp) {
     switch (g.nslab) {
-        case 1: return launch_1x1<T, MI, NI, WGM, WGN, 1, false>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-        case 2: return launch_1x1<T, MI, NI, WGM, WGN, 2, false>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-        case 3: return launch_1x1<T, MI, NI, WGM, WGN, 3, false>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
-        case 4: return launch_1x1<T, MI, NI, WGM, WGN, 4, false>(s, w, bias, r, d, g, fin, is_dgrad, st, la);
+        case 1: return launch_1x1<T, MI, NI, WGM, WGN, 1>(s, w, bias, r, d, g, fin, is_dgrad, st, brp);
+        case 2: return launch_1x1<T, MI, NI, WGM, WGN, 2>(s, w, bias, r, d, g, fin, is_dgrad, st, brp);
+        case 3: return launch_1x1<T, MI, NI, WGM, WGN, 3>(s, w, bias, r, d, g, fin, is_dgrad, st, brp);
+        case 4: return launch_1x1<T, MI, NI, WGM, WGN, 4>(s, w, bias, r, d, g, fin, is_dgrad, st, brp);
         default: return 1;
     }
 }
 
 template <typename T, int TH, int TW, int MI, int NI, int WGM, int WGN, int IH>
 int launch_halo(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, HGeom g,
-                const BnAcc& fin, hipStream_t st, const LzArgs& la) {
-    if (la.lz) {
-        if (g.nslab > 1) return launch_halo1<T, TH, TW, MI, NI, WGM, WGN, IH, true, true>(s, w, bias, r, d, g, fin, st, la);
-        return launch_halo1<T, TH, TW, MI, NI, WGM, WGN, IH, false, true>(s, w, bias, r, d, g, fin, st, la);
-    }
-    if (g.nslab > 1) return launch_halo1<T, TH, TW, MI, NI, WGM, WGN, IH, true, false>(s, w, bias, r, d, g, fin, st, la);
-    return launch_halo1<T, TH, TW, MI, NI, WGM, WGN, IH, false, false>(s, w, bias, r, d, g, fin, st, la);
+                const BnAcc& fin, hipStream_t st, const BnRed* brp) {
+    if (g.nslab > 1) return launch_halo1<T, TH, TW, MI, NI, WGM, WGN, IH, true>(s, w, bias, r, d, g, fin, st, brp);
+    return launch_halo1<T, TH, TW, MI, NI, WGM, WGN, IH, false>(s, w, bias, r, d, g, fin, st, brp);
 }
 
 }  // namespace
 
 // Called by the convolution entry points of igemm.hip before they fall back to the implicit-GEMM kernel.  Returns 1 when the layer
 // is not one this kernel takes (then nothing was launched), 0 when it ran, < 0 / hipError on failure.
-// lz / z (forward only): s holds raw pre-BatchNorm values for the segments of lz; the kernel transforms them in LDS and writes the
-// materialised activation to z (same shape as s).
-static bool lz_ok(const dsn_tensor* s, const LazyIn* lz, const dsn_tensor* z, int vec, int es) {
-    if (!lz || lz->nseg <= 0) return true;
-    return z && z->ptr && z->dtype == s->dtype && z->n == s->n && z->h == s->h && z->w == s->w && z->c == s->c && z->ldc % vec == 0 &&
-           (uintptr_t)z->ptr % 16 == 0 && ((npix(z) - 1) * z->ldc + z->c) * es < (1ll << 31) && s->c <= 1024;
-}
-
 int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
-                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const LazyIn* lz,
-                         const dsn_tensor* z, const BnRed* br) {
+                         const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const BnRed* br) {
     static const int mode = [] { const char* e = getenv("DSN_HALO"); return e ? atoi(e) : 1; }();       // 0: never
     if (!mode) return 1;
     if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->dil < 1 || p->dil > 3) return 1;
@@ -736,10 +616,7 @@ int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, 
     g.sld = s->ldc; g.dld = d->ldc; g.rld = r ? r->ldc : 0;
     g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
     g.nslab = s->c / kc;
-    if (lz && lz->nseg <= 0) lz = nullptr;
-    if (lz && (is_dgrad || !lz_ok(s, lz, z, vec, es))) return 1;
-    const LzArgs la{lz, lz ? z->ptr : nullptr, lz ? z->ldc : 0, (br && br->nseg > 0) ? br : nullptr};
-    if (lz) g.z_bytes = (uint32_t)(((npix(z) - 1) * z->ldc + z->c) * es);
+    const BnRed* la = (br && br->nseg > 0) ? br : nullptr;
     BnAcc fin{};
     if (finp) fin = *finp;
     hipStream_t st = (hipStream_t)stream;
@@ -771,8 +648,7 @@ int dsn_conv3x3_halo_try(const dsn_tensor* s, const void* w, const float* bias, 
 
 // The same for 1x1 / stride-1 layers with at most four 128-byte channel slabs (conv1x1_dma_kernel).
 int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
-                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const LazyIn* lz,
-                        const dsn_tensor* z, const BnRed* br) {
+                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const BnRed* br) {
     static const int mode = [] { const char* e = getenv("DSN_DMA1X1"); return e ? atoi(e) : 1; }();       // 0: never
     if (!mode) return 1;
     if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0) return 1;
@@ -789,10 +665,7 @@ int dsn_conv1x1_dma_try(const dsn_tensor* s, const void* w, const float* bias, c
     g.sld = s->ldc; g.dld = d->ldc; g.rld = r ? r->ldc : 0;
     g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
     g.nslab = s->c / kc;
-    if (lz && lz->nseg <= 0) lz = nullptr;
-    if (lz && (is_dgrad || !lz_ok(s, lz, z, vec, es))) return 1;
-    const LzArgs la{lz, lz ? z->ptr : nullptr, lz ? z->ldc : 0, (br && br->nseg > 0) ? br : nullptr};
-    if (lz) g.z_bytes = (uint32_t)(((npix(z) - 1) * z->ldc + z->c) * es);
+    const BnRed* la = (br && br->nseg > 0) ? br : nullptr;
     BnAcc fin{};
     if (finp) fin = *finp;
     hipStream_t st = (hipStream_t)stream;

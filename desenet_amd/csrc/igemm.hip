@@ -92,31 +92,19 @@ template <int BM, int BN, int NBUF = 2> constexpr int smem_bytes() {
 // 2 = uniform tap: Cs is a multiple of the chunk, so the tap of a chunk is the same for the whole block -- tap stepping runs
 //     on the scalar unit, border handling is one bit test against a per-row tap mask built once, and an address is
 //     base + (uniform offset): ~4 VALU per load instead of ~35 (at 1.5 blocks per CU nothing hides the address arithmetic).
-// LAZY: the source tensor holds RAW pre-BatchNorm values for the channel segments of `lz` (common.h: deferred BN + act); the
-// block builds the per-channel (scale, shift, act) table once and applies z = act(y*scale + shift) to every A vector on its way
-// from the register stage into LDS (masked taps / rows stay zero AFTER the activation).
-constexpr int LAZY_MAXC = 1024;
 // GL > 0: LDS-DMA staging (buffer_load_dwordx4 ... lds) into a ring of GL LDS stages instead of register stages feeding two LDS
 // buffers: the loads of chunks i+1 .. i+GL-1 are in flight while chunk i is on the matrix cores at NO register cost (the
 // register-staged loop waits for the loads of the same or the next iteration: ~0.6 us per K chunk of pure load latency on
 // layers that live out of L2 / MALL).  An LDS-DMA wave-instruction writes 64 x 16 B LINEARLY (8 rows x 8 slots): the XOR swizzle
 // of the tile is applied on the SOURCE side -- thread (row, physical slot v) fetches logical slot v ^ swz(row).  One raw
 // s_barrier per chunk, counted s_waitcnt vmcnt (never 0 inside the loop), no ordinary global load inside the loop.
-template <typename T, int MI, int NI, int WGM, int WGN, int LD, bool PAR, bool LAZY = false, int NST = 3, int GL = 0>
+template <typename T, int MI, int NI, int WGM, int WGN, int LD, bool PAR, int NST = 3, int GL = 0>
 __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : MI * NI <= 8 ? 3 : 2)) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wpk,
                                                     const float* __restrict__ bias, const T* __restrict__ res,
                                                     T* __restrict__ dst, float* __restrict__ stats, const BnAcc fin, const Geom g,
-                                                    const LazyIn lz, const BnRed br) {
+                                                    const BnRed br) {
     static_assert(WGM * WGN == 4, "4 waves per block");
-    static_assert(!LAZY || (LD >= 1 && !PAR), "lazy inputs ride on the 16-byte staging paths");
-    static_assert(GL == 0 || (LD >= 1 && !PAR && !LAZY && GL >= 3), "LDS-DMA staging: vector paths, plain inputs, >= 3 stages");
-    // the table lives in DYNAMIC LDS sized by the layer (2 * Cs floats + Cs / 8 bytes): a static 8 KB array would take the
-    // 64x64 tile from four resident blocks per CU to three for every layer, however narrow
-    extern __shared__ __attribute__((aligned(16))) float s_lazy_dyn[];
-    float* s_lsc = s_lazy_dyn;
-    float* s_lsh = s_lazy_dyn + (LAZY ? g.Cs : 0);
-    unsigned char* s_lact = reinterpret_cast<unsigned char*>(s_lazy_dyn + (LAZY ? 2 * g.Cs : 0));
-    if constexpr (LAZY) lazy_table(lz, g.Cs, s_lsc, s_lsh, s_lact, 256);     // (visible after the first __syncthreads below)
+    static_assert(GL == 0 || (LD >= 1 && !PAR && GL >= 3), "LDS-DMA staging: vector paths, >= 3 stages");
     constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     constexpr int VEC = Mma<T>::VEC;
     constexpr bool VECLOAD = LD >= 1, UNI = LD == 2;
@@ -182,8 +170,6 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
     // three register stages: chunks i+1, i+2, i+3 are in flight while chunk i is on the matrix cores (the loads of a
     // chunk get two full iterations to land; one stage left every iteration waiting ~0.5 us for L2)
     u32x4 rga[NST][AR], rgb[NST][BR];      // NST register stages (6 was measured: slower everywhere -- the registers cost occupancy)
-    int st_cb[NST];                        // LAZY: source channel of this thread's vector in the staged chunk ...
-    uint32_t st_ok[NST];                   // ... and which of its AR rows hold real (in-range) data
 
     // source address of destination row i for tap (ky, kx); nullptr when the tap falls outside the map
     auto src_row = [&](int i, int ky, int kx) -> const T* {
@@ -257,18 +243,14 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
         else
             dstv = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
     };
-    auto load_chunk = [&](int ch, u32x4 (&ra)[AR], u32x4 (&rb)[BR], int& lcb, uint32_t& lok, int gbuf = 0) {
+    auto load_chunk = [&](int ch, u32x4 (&ra)[AR], u32x4 (&rb)[BR], int gbuf = 0) {
         const int k0 = ch * KC + v * VEC;
-        lok = 0;
-        lcb = 0;
         if (UNI) {
             constexpr uint32_t OOB = 0xFFFFFFF0u;
-            lcb = u_cc * KC + v * VEC;
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = u_tap < 32 && ((tapmask[i] >> (u_tap & 31)) & 1u);
                 const uint32_t off = ok ? voffA[i] + u_offA : OOB;
-                if (LAZY && ok) lok |= 1u << i;
                 fetchA(ra[i], i, off, gbuf);
             }
 #pragma unroll
@@ -298,7 +280,6 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
                 kc_c += KC;
                 kc_norm();
             }
-            lcb = c;
             const int kb = PAR ? tap * g.Cs + c : k0;           // position of this vector in the packed weight row
             // buffer loads: an offset beyond the descriptor's range returns zeros, so padding / masked taps / tile
             // overhang cost one v_cndmask on the OFFSET instead of a branch + four on the data
@@ -311,15 +292,13 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
                     const bool ok = kok && rowok[i] && (unsigned)(py[i] + dyo) < (unsigned)g.Hs &&
                                     (unsigned)(px[i] + dxo) < (unsigned)g.Ws;
                     const uint32_t off = ok ? (uint32_t)(base_off[i] + off_tap) * (uint32_t)sizeof(T) : OOB;
-                    if (LAZY && ok) lok |= 1u << i;
-                    fetchA(ra[i], i, off, gbuf);
+                        fetchA(ra[i], i, off, gbuf);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < AR; ++i) {
                     const T* p = kok ? src_row(i, ky, kx) : nullptr;
                     const uint32_t off = p ? (uint32_t)((p + c) - src) * (uint32_t)sizeof(T) : OOB;
-                    if (LAZY && p) lok |= 1u << i;
                     fetchA(ra[i], i, off, gbuf);
                 }
             }
@@ -359,26 +338,11 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
             }
         }
     };
-    auto store_chunk = [&](int buf, const u32x4 (&ra)[AR], const u32x4 (&rb)[BR], int lcb, uint32_t lok) {
-        float lsc[VEC], lsh[VEC];
-        int lact = 0;
-        if constexpr (LAZY) {
-            // (chunks past the end of K carry no valid row: any in-range table entry will do)
-            const int cbs = lcb <= g.Cs - VEC ? (lcb < 0 ? 0 : lcb) : g.Cs - VEC;
-#pragma unroll
-            for (int e = 0; e < VEC; e += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(s_lsc + cbs + e), b = *reinterpret_cast<const f32x4*>(s_lsh + cbs + e);
-                lsc[e] = a[0]; lsc[e + 1] = a[1]; lsc[e + 2] = a[2]; lsc[e + 3] = a[3];
-                lsh[e] = b[0]; lsh[e + 1] = b[1]; lsh[e + 2] = b[2]; lsh[e + 3] = b[3];
-            }
-            lact = s_lact[cbs >> 3];
-        }
+    auto store_chunk = [&](int buf, const u32x4 (&ra)[AR], const u32x4 (&rb)[BR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int r = r0 + 32 * i;
-            u32x4 val = ra[i];
-            if constexpr (LAZY) val = lazy_apply<T>(val, lsc, lsh, lact, (lok >> i) & 1u);
-            if (BM % 32 == 0 || r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = val;
+            if (BM % 32 == 0 || r < BM) *reinterpret_cast<u32x4*>(sA + (buf * BM + r) * ROWB + ((v ^ ((r >> 1) & 7)) << 4)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
@@ -431,7 +395,7 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
         constexpr int LPC = AR + BR;                       // LDS-DMA instructions per chunk per wave
         static_assert((GL - 2) * LPC < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
-        for (int s = 0; s < GL - 1; ++s) load_chunk(s, rga[0], rgb[0], st_cb[0], st_ok[0], s);
+        for (int s = 0; s < GL - 1; ++s) load_chunk(s, rga[0], rgb[0], s);
         int lbuf = GL - 1, cbuf = 0;                       // stage the next load goes to / stage of the chunk to compute
         for (int i = 0; i < nchunks; ++i) {
             // (lgkmcnt(0): this wave's fragment reads of chunk i - 1 have COMPLETED, not merely issued, before anyone may overwrite
@@ -440,7 +404,7 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
             __builtin_amdgcn_sched_barrier(0);             // (issue order pinned at the wait: nothing of chunk i - 1 is placed below it)
             __builtin_amdgcn_s_barrier();                  // everyone's have; and everyone is done reading stage lbuf (chunk i-1)
             asm volatile("" ::: "memory");
-            load_chunk(i + GL - 1, rga[0], rgb[0], st_cb[0], st_ok[0], lbuf);
+            load_chunk(i + GL - 1, rga[0], rgb[0], lbuf);
             compute(cbuf);
             lbuf = lbuf + 1 == GL ? 0 : lbuf + 1;
             cbuf = cbuf + 1 == GL ? 0 : cbuf + 1;
@@ -449,36 +413,34 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
         __syncthreads();
     } else if (nchunks >= g.longk) {
 #pragma unroll
-        for (int s = 0; s < NST; ++s) load_chunk(s, rga[s], rgb[s], st_cb[s], st_ok[s]);
-        if constexpr (LAZY) __syncthreads();          // the (scale, shift) table is complete
-        store_chunk(0, rga[0], rgb[0], st_cb[0], st_ok[0]);
+        for (int s = 0; s < NST; ++s) load_chunk(s, rga[s], rgb[s]);
+        store_chunk(0, rga[0], rgb[0]);
         __syncthreads();
         for (int it = 0; it < nchunks; it += NST) {
 #pragma unroll
             for (int s = 0; s < NST; ++s) {
                 const int i = it + s;
                 if (s > 0 && i >= nchunks) break;
-                load_chunk(i + NST, rga[s], rgb[s], st_cb[s], st_ok[s]);
+                load_chunk(i + NST, rga[s], rgb[s]);
                 compute(i & 1);
-                store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST], st_cb[(s + 1) % NST], st_ok[(s + 1) % NST]);
+                store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST]);
                 __syncthreads();
             }
         }
     } else {
 #pragma unroll
         for (int s = 0; s < NST; ++s)
-            if (nchunks > s) load_chunk(s, rga[s], rgb[s], st_cb[s], st_ok[s]);
-        if constexpr (LAZY) __syncthreads();          // the (scale, shift) table is complete
-        if (nchunks > 0) store_chunk(0, rga[0], rgb[0], st_cb[0], st_ok[0]);
+            if (nchunks > s) load_chunk(s, rga[s], rgb[s]);
+        if (nchunks > 0) store_chunk(0, rga[0], rgb[0]);
         __syncthreads();
         for (int it = 0; it < nchunks; it += NST) {
 #pragma unroll
             for (int s = 0; s < NST; ++s) {
                 const int i = it + s;
                 if (i < nchunks) {
-                    if (i + NST < nchunks) load_chunk(i + NST, rga[s], rgb[s], st_cb[s], st_ok[s]);
+                    if (i + NST < nchunks) load_chunk(i + NST, rga[s], rgb[s]);
                     compute(i & 1);
-                    if (i + 1 < nchunks) store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST], st_cb[(s + 1) % NST], st_ok[(s + 1) % NST]);
+                    if (i + 1 < nchunks) store_chunk((i + 1) & 1, rga[(s + 1) % NST], rgb[(s + 1) % NST]);
                     __syncthreads();
                 }
             }
@@ -638,7 +600,7 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
 
 template <typename T, int MI, int NI, int WGM, int WGN>
 int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst, float* stats, const BnAcc& fin, Geom g,
-               bool vec, hipStream_t st, int* tiles_m_out, const LazyIn* lzp = nullptr, const BnRed* brp = nullptr) {
+               bool vec, hipStream_t st, int* tiles_m_out, const BnRed* brp = nullptr) {
     const BnRed br = brp ? *brp : BnRed{};
     if (br.nseg > 0 && !(vec && g.Cd % Mma<T>::VEC == 0 && g.dld % Mma<T>::VEC == 0 && ((uintptr_t)dst) % 16 == 0 &&
                          (!res || (g.rld % Mma<T>::VEC == 0 && ((uintptr_t)res) % 16 == 0))))
@@ -691,8 +653,6 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     static const int longk = [] { const char* e = getenv("DSN_IGEMM_LONGK"); return e ? atoi(e) : 9; }();
     g.longk = longk;
     const bool uni = vec && !par && g.q == 1 && g.Cs % (ROWB / (int)sizeof(T)) == 0 && g.KH * g.KW <= 32 && !no_uni;
-    const bool lazy = lzp && lzp->nseg > 0;
-    const LazyIn lz = lazy ? *lzp : LazyIn{};
     // LDS-DMA ring (3 stages) instead of register staging.  Measured per layer (tools/bench_ops.py, MI355X): it wins where the
     // grid is small -- at most ~1.75 blocks of 64x64 per CU, so the larger LDS footprint costs no occupancy and the deeper
     // prefetch is all gain (3x3 on 20x20 / 40x40 maps: 16.8 -> 13.9, 23.7 -> 19.8, 14.8 -> 12.9 us; 1x1 512 -> 256 @20: 7.4 ->
@@ -704,37 +664,28 @@ int launch_cfg(const T* src, const T* w, const float* bias, const T* res, T* dst
     if constexpr (BM % 32 == 0 && BN % 32 == 0 && BM * BN <= 128 * 64) {
         const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n;
         const bool want = gl_env >= 0 ? gl_env == 3 : (blocks <= 448 && g.Ktot * (int)sizeof(T) >= 512);
-        if (!lazy && !par && vec && want) {
-            if (uni) hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
-            else hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
+        if (!par && vec && want) {
+            if (uni) hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, br);
+            else hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, 3, 3>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, br);
             DSN_LAUNCH_CHECK("igemm (LDS-DMA)");
             return DSN_OK;
         }
     }
-    if (lazy) {
-        if (!vec || par || g.Cs > LAZY_MAXC || g.Cs % 8 != 0)
-            DSN_FAIL(DSN_EUNSUPPORTED, "conv with a deferred-BatchNorm input: the layer cannot take the 16-byte staging paths "
-                                       "(channels %d, pixel stride %lld)", g.Cs, (long long)g.sld);
-        const size_t dyn = ((size_t)g.Cs * 8 + (size_t)g.Cs / 8 + 15) / 16 * 16;
-        if (uni)
-            hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false, true>), grid, block, dyn, st, src, w, bias, res, dst, stats, fin, g, lz, br);
-        else
-            hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false, true>), grid, block, dyn, st, src, w, bias, res, dst, stats, fin, g, lz, br);
-    } else if (par)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
+    if (par)
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, true>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, br);
     else if (uni)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 2, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, br);
     else if (vec)
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 1, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, br);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 0, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, lz, br);
+        hipLaunchKernelGGL((igemm_kernel<T, MI, NI, WGM, WGN, 0, false>), grid, block, 0, st, src, w, bias, res, dst, stats, fin, g, br);
     DSN_LAUNCH_CHECK("igemm");
     return DSN_OK;
 }
 
 template <typename T>
 int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, float* stats,
-           const BnAcc& fin, Geom g, hipStream_t st, int* tiles_m_out, const LazyIn* lz = nullptr, const BnRed* br = nullptr) {
+           const BnAcc& fin, Geom g, hipStream_t st, int* tiles_m_out, const BnRed* br = nullptr) {
     constexpr int VEC = Mma<T>::VEC;
     const T* src = (const T*)s->ptr;
     const T* res = r ? (const T*)r->ptr : nullptr;
@@ -747,33 +698,33 @@ int launch(const dsn_tensor* s, const void* w, const float* bias, const dsn_tens
     static const int force_s2 = [] { const char* e = getenv("DSN_IGEMM_S2_CFG"); return e ? atoi(e) : -1; }();    // tuning knob: stride-2 layers only
     const bool is_s2 = g.d2s_c > 0 || (g.a == 2 && g.KH == 3);
     switch (is_s2 && force_s2 >= 0 ? force_s2 : force) {
-        case 0: return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        case 1: return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        case 2: return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        case 3: return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        case 4: return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        case 5: return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        case 6: return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+        case 0: return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        case 1: return launch_cfg<T, 4, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        case 2: return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        case 3: return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        case 4: return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        case 5: return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        case 6: return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
         default: break;
     }
     // Tile choice, from tools/sweep_igemm.sh on the DeSeNet-s layer shapes (batch 8): these layers are latency-bound, not
     // MFMA-bound, so SMALL tiles win almost everywhere (more blocks per CU hide the load -> LDS -> MFMA round trips);
     // only the few large GEMMs (FFM 3x3: 1600 tiles x K 2304) amortise a 128x128 tile.
     const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.Cd + 63) / 64);
-    if (g.Cd <= 16) return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
+    if (g.Cd <= 16) return launch_cfg<T, 1, 1, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
     if (g.Cd <= 32) {
         if (g.M >= 400000)      // Focus conv / stem dgrad: 128 pixels x 32 channels
-            return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);
-        return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 64x32
+            return launch_cfg<T, 2, 2, 4, 1>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);
+        return launch_cfg<T, 2, 1, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);      // 64x32
     }
     if (tiles64 >= 1536 && g.Ktot >= 1024 && g.Cd >= 128)
-        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 128x128
+        return launch_cfg<T, 4, 4, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);      // 128x128
     // (256 .. 400 tiles: 32x64 measured 5.0 vs 5.6 us per launch on short-K layers standalone, but inside the step the 64x64 tile is
     // ahead -- 3.938 vs 3.947 ms, DSN_IGEMM_SMALLK = 0 vs 512 = largest K that still takes the small tile there)
     static const int smallk = [] { const char* e = getenv("DSN_IGEMM_SMALLK"); return e ? atoi(e) : 0; }();
     if (tiles64 < 256 || (tiles64 <= 400 && g.Ktot <= smallk))
-        return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);      // 32x64
-    return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, lz, br);          // 64x64
+        return launch_cfg<T, 1, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);      // 32x64
+    return launch_cfg<T, 2, 2, 2, 2>(src, (const T*)w, bias, res, dst, stats, fin, g, vec, st, tiles_m_out, br);          // 64x64
 }
 
 int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const dsn_conv_params* p) {
@@ -786,21 +737,9 @@ int check_common(const dsn_tensor* s, const void* w, const dsn_tensor* d, const 
 }
 
 int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const dsn_tensor* residual, const dsn_tensor* y,
-                  const dsn_conv_params* p, float* stats, int* tiles_m_out, void* stream, const BnAcc* finp = nullptr,
-                  const LazyIn* lz = nullptr, const dsn_tensor* z = nullptr) {
+                  const dsn_conv_params* p, float* stats, int* tiles_m_out, void* stream, const BnAcc* finp = nullptr) {
     int rc = check_common(x, w, y, p);
     if (rc) return rc;
-    if (z && lz && lz->nseg > 0 && !stats) {
-        // deferred input WITH a destination for the materialised activation: the LDS-DMA kernels transform the tile once per block
-        // in LDS and store z on the way; any other layer materialises z with the elementwise kernel and convolves that
-        rc = dsn_conv3x3_halo_try(x, w, bias, residual, y, p, 0, finp, stream, lz, z);
-        if (rc != 1) return rc;
-        rc = dsn_conv1x1_dma_try(x, w, bias, residual, y, p, 0, finp, stream, lz, z);
-        if (rc != 1) return rc;
-        rc = dsn_lazy_materialize(x, lz, nullptr, nullptr, z, stream);
-        if (rc) return rc;
-        return conv_fwd_impl(z, w, bias, residual, y, p, stats, tiles_m_out, stream, finp, nullptr, nullptr);
-    }
     const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     DSN_CHECK_ARG(ho == y->h && wo == y->w, "conv fwd: output is %dx%d, expected %dx%d", y->h, y->w, ho, wo);
@@ -808,7 +747,7 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
         DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == y->dtype && residual->n == y->n &&
                           residual->h == y->h && residual->w == y->w && residual->c == y->c,
                       "conv fwd: residual shape mismatch");
-    if (!stats && !(lz && lz->nseg > 0)) {      // 3x3 / stride 1 with whole 64-channel slabs: the halo-tile kernel (conv3x3.hip)
+    if (!stats) {      // 3x3 / stride 1 with whole 64-channel slabs: the halo-tile kernel (conv3x3.hip)
         rc = dsn_conv1x1_ws_try(x, w, bias, residual, y, p, 0, finp, stream);       // 1x1, weights-stationary persistent blocks
         if (rc != 1) return rc;
         rc = dsn_conv3x3_pp_try(x, w, bias, residual, y, p, 0, finp, stream);       // 3x3 / stride 1 on big tiles (conv_pp.hip)
@@ -831,8 +770,8 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
     g.sld = x->ldc; g.dld = y->ldc; g.rld = residual ? residual->ldc : 0;
     BnAcc fin{};
     if (finp) fin = *finp;
-    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, stats, fin, g, (hipStream_t)stream, tiles_m_out, lz);
-    return launch<bf16_t>(x, w, bias, residual, y, stats, fin, g, (hipStream_t)stream, tiles_m_out, lz);
+    if (x->dtype == DSN_F32) return launch<float>(x, w, bias, residual, y, stats, fin, g, (hipStream_t)stream, tiles_m_out);
+    return launch<bf16_t>(x, w, bias, residual, y, stats, fin, g, (hipStream_t)stream, tiles_m_out);
 }
 
 }  // namespace
@@ -865,50 +804,6 @@ extern "C" int dsn_conv2d_fwd_bnacc(const dsn_tensor* x, const void* w, const ds
     if (acc_bytes < bn_acc_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "conv2d_fwd_bnacc: accumulator buffer too small");
     BnAcc f{(double*)acc, y->c, (double)npix(y)};
     return conv_fwd_impl(x, w, nullptr, nullptr, y, p, nullptr, nullptr, stream, &f);
-}
-
-// Convolution whose input carries deferred BatchNorm + activation segments (include/desenet_hip.h: dsn_lazy_in).  acc != NULL:
-// also emit the BatchNorm sums of y (plain convolution only), as dsn_conv2d_fwd_bnacc does.
-static int conv2d_fwd_lazy_impl(const dsn_tensor* x, const dsn_lazy_in* lazy, const dsn_tensor* z, const void* w, const float* bias,
-                                const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc,
-                                int64_t acc_bytes, void* stream) {
-    DSN_CHECK_ARG(x && y && p, "conv2d_fwd_lazy: null argument");
-    if (z) DSN_CHECK_ARG(tensor_ok(z) && z->dtype == x->dtype && z->n == x->n && z->h == x->h && z->w == x->w && z->c == x->c,
-                         "conv2d_fwd_lazy_z: z must have the shape of x");
-    if (lazy) {
-        DSN_CHECK_ARG(lazy->nseg >= 0 && lazy->nseg <= DSN_LAZY_MAXSEG, "conv2d_fwd_lazy: %d segments", lazy->nseg);
-        for (int i = 0; i < lazy->nseg; ++i) {
-            const dsn_lazy_seg& s = lazy->seg[i];
-            DSN_CHECK_ARG(s.c0 >= 0 && s.c1 > s.c0 && s.c1 <= x->c, "conv2d_fwd_lazy: segment %d covers [%d, %d) of %d channels", i,
-                          s.c0, s.c1, x->c);
-            if (s.c0 % 8 || s.c1 % 8) DSN_FAIL(DSN_EUNSUPPORTED, "conv2d_fwd_lazy: segment bounds must be multiples of 8");
-            DSN_CHECK_ARG(!s.acc || (s.count > 0 && s.acc_c >= s.ch0 + (s.c1 - s.c0)), "conv2d_fwd_lazy: bad accumulator in segment %d", i);
-            DSN_CHECK_ARG((s.scale == nullptr) == (s.shift == nullptr), "conv2d_fwd_lazy: scale/shift must come in pairs");
-        }
-    }
-    if (acc) {
-        DSN_CHECK_ARG(p->act == DSN_ACT_NONE && !p->accumulate && !bias && !residual, "conv2d_fwd_lazy: BatchNorm sums need a plain convolution");
-        if (acc_bytes < bn_acc_bytes(y->c)) DSN_FAIL(DSN_EWORKSPACE, "conv2d_fwd_lazy: accumulator buffer too small");
-        BnAcc f{(double*)acc, y->c, (double)npix(y)};
-        return conv_fwd_impl(x, w, nullptr, nullptr, y, p, nullptr, nullptr, stream, &f, lazy, z);
-    }
-    return conv_fwd_impl(x, w, bias, residual, y, p, nullptr, nullptr, stream, nullptr, lazy, z);
-}
-
-extern "C" int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy, const void* w, const float* bias,
-                                   const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc,
-                                   int64_t acc_bytes, void* stream) {
-    return conv2d_fwd_lazy_impl(x, lazy, nullptr, w, bias, residual, y, p, acc, acc_bytes, stream);
-}
-
-// The same, and z = the materialised input (act(bn(x)) on the deferred segments, x elsewhere) is written as a side effect: by the
-// convolution kernel itself where it stages whole tiles through LDS (3x3 / stride 1 and 1x1 with 64-channel slabs), by one
-// elementwise launch ahead of the convolution otherwise.
-extern "C" int dsn_conv2d_fwd_lazy_z(const dsn_tensor* x, const dsn_lazy_in* lazy, const dsn_tensor* z, const void* w,
-                                     const float* bias, const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p,
-                                     void* acc, int64_t acc_bytes, void* stream) {
-    DSN_CHECK_ARG(z && lazy && lazy->nseg > 0, "conv2d_fwd_lazy_z: needs a deferred input and a destination for z");
-    return conv2d_fwd_lazy_impl(x, lazy, z, w, bias, residual, y, p, acc, acc_bytes, stream);
 }
 
 // Stride-2 3x3 (pad 1) input gradient as ONE stride-1 2x2 convolution over dy with 4*Ci output columns + depth-to-space store:
@@ -961,8 +856,8 @@ static int conv_dgrad_s2_impl(const dsn_tensor* dy, const void* w_s2, const dsn_
     rc = dsn_dgrad_s2_ws_try(dy, w_s2, dx, p, br, stream);                          // the large stems: weights-stationary, gathered K
     if (rc != 1) return rc;
     if (dy->dtype == DSN_F32)
-        return launch<float>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
-    return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
+        return launch<float>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, br);
+    return launch<bf16_t>(dy, w_s2, nullptr, nullptr, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, br);
 }
 
 extern "C" int dsn_conv2d_dgrad_s2(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p,
@@ -989,9 +884,9 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
     if (rc != 1) return rc;
     rc = dsn_conv3x3_ws_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, br);
     if (rc != 1) return rc;
-    rc = dsn_conv3x3_halo_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, nullptr, nullptr, br);
+    rc = dsn_conv3x3_halo_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, br);
     if (rc != 1) return rc;
-    rc = dsn_conv1x1_dma_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, nullptr, nullptr, br);
+    rc = dsn_conv1x1_dma_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, br);
     if (rc != 1) return rc;
     Geom g{};
     g.M = (int32_t)npix(dx); g.Hd = dx->h; g.Wd = dx->w;
@@ -1001,8 +896,8 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = residual ? residual->ldc : 0;
     if (dy->dtype == DSN_F32)
-        return launch<float>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
-    return launch<bf16_t>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, nullptr, br);
+        return launch<float>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, br);
+    return launch<bf16_t>(dy, w, nullptr, residual, dx, nullptr, BnAcc{}, g, (hipStream_t)stream, nullptr, br);
 }
 }  // namespace
 

@@ -41,30 +41,12 @@ template <> struct WTraits<bf16_t> {
 // the 32-byte column group with swz(row) spreads them over the four groups of the 256-byte bank row: conflict-free.
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-// Deferred BatchNorm + act on the x operand (common.h): a thread stages the SAME 16-byte channel vectors of every pixel row for
-// the whole kernel, so its (scale, shift, act) constants are fetched once into registers (backward: scale / shift arrays written by
-// dsn_bn_finalize_multi).  Returns false when channel c lies in no segment (identity).
-template <int VEC>
-__device__ __forceinline__ bool lazy_consts(const LazyIn& lz, int c, float (&sc)[VEC], float (&sh)[VEC], int& act) {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-    act = DSN_ACT_NONE;
-    for (int s = 0; s < lz.nseg; ++s)
-        if (c >= lz.seg[s].c0 && c < lz.seg[s].c1) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) lazy_fold(lz.seg[s], c + e - lz.seg[s].c0, sc[e], sh[e]);
-            act = lz.seg[s].act;
-            return true;
-        }
-    return false;
-}
-
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <typename T, bool VECLOAD, int PK, bool LAZY = false>
+template <typename T, bool VECLOAD, int PK>
 __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ out,
-                                           const WGeom& g, int bid, const LazyIn* lzp = nullptr) {
+                                           const WGeom& g, int bid) {
     constexpr int VEC = WTraits<T>::VEC, ROW = WTraits<T>::ROW;
     constexpr int VPR = TB / VEC;          // vectors per tile row
     constexpr int NV = VPR / 8;            // vectors per thread per row (8 threads per row)
@@ -89,19 +71,6 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
     const int srow = tid >> 3;      // staged pixel row 0..31
     const int sv = tid & 7;         // first vector of the row
     u32x4 ra[RG][NV], rb[RG][NV];
-    // deferred BatchNorm + act on x: constants of this thread's NV channel vectors, validity of the rows staged last
-    const bool lazy = LAZY && VECLOAD && lzp && lzp->nseg > 0;      // (LAZY: a separate instantiation -- the constants cost registers)
-    float lsc[NV][VEC], lsh[NV][VEC];
-    int lact[NV];
-    bool lhit[NV];
-    uint32_t lok = 0;               // bit rg*NV + i: rb[rg][i] holds in-range data
-    if (lazy) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = ci0 + (sv + 8 * i) * VEC;
-            lhit[i] = c < g.CiLoad && lazy_consts<VEC>(*lzp, c, lsc[i], lsh[i], lact[i]);
-        }
-    }
 
     // Vector path: raw buffer loads with 32-bit byte offsets (masked lanes get an out-of-range offset and read 0) and a
     // pixel cursor (p, ox, oy, n) per staged row that ADVANCES by PK per chunk instead of being re-derived with two integer
@@ -136,7 +105,6 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
         return *reinterpret_cast<u32x4*>(tmp);
     };
     auto load_chunk = [&](int ch) {      // called with ch = 0, 1, 2, ... in order (the cursor advances)
-        lok = 0;
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) {
             if constexpr (VECLOAD) {
@@ -151,7 +119,6 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
                     const int vc = (sv + 8 * i) * VEC;
                     ra[rg][i] = __builtin_amdgcn_raw_buffer_load_b128(yr, (pok && co0 + vc < g.Co) ? abase + vc * ES : OOB, 0, 0);
                     rb[rg][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (xok && ci0 + vc < g.CiLoad) ? bbase + vc * ES : OOB, 0, 0);
-                    if (LAZY && xok) lok |= 1u << (rg * NV + i);
                 }
                 aoff[rg] += astep;
                 boff[rg] += bstep;
@@ -192,12 +159,8 @@ __device__ __forceinline__ void wgrad_body(const T* __restrict__ x, const T* __r
             for (int i = 0; i < NV; ++i) {
                 int vc = (sv + 8 * i) * VEC;
                 if constexpr (sizeof(T) == 2) vc ^= swz(srow) << 4;
-                u32x4 xb = rb[rg][i];
-                if constexpr (VECLOAD && LAZY) {
-                    if (lazy && lhit[i]) xb = lazy_apply<T>(xb, lsc[i], lsh[i], lact[i], (lok >> (rg * NV + i)) & 1u);
-                }
                 *reinterpret_cast<u32x4*>(&sA[buf][(srow + 32 * rg) * ROW + vc]) = ra[rg][i];
-                *reinterpret_cast<u32x4*>(&sB[buf][(srow + 32 * rg) * ROW + vc]) = xb;
+                *reinterpret_cast<u32x4*>(&sB[buf][(srow + 32 * rg) * ROW + vc]) = rb[rg][i];
             }
     };
 
@@ -451,9 +414,9 @@ __device__ __forceinline__ void wgrad_body128(const bf16_t* __restrict__ x, cons
 // The per-tap kernel above re-reads dy once per tap (9x: 472 MB instead of 52 MB for the Focus conv -- it ran at the HBM
 // rate of the re-reads).  Here dy is staged once per chunk and shared by the nine taps, the nine shifted x gathers hit the
 // same cache lines, 10 16-byte loads are in flight per thread, and every barrier is followed by 36 MFMAs per wave.
-template <int NT, bool LAZY = false>
+template <int NT>
 __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                   float* __restrict__ out, const WGeom& g, int bid, const LazyIn* lzp = nullptr) {
+                                                   float* __restrict__ out, const WGeom& g, int bid) {
     constexpr int PKA = 32, ROW = TB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);                    // [2][PKA*ROW]
@@ -493,15 +456,9 @@ __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x,
     const uint32_t astep = (uint32_t)(PKA * (int)g.yld) * 2u, bstep = (uint32_t)(PKA * (int)g.xld) * 2u;
     const uint32_t brow = (uint32_t)(g.dil * g.Wi * (int)g.xld) * 2u, bcol = (uint32_t)(g.dil * (int)g.xld) * 2u;
     const bool aok = co0 + vc < g.Co, bok = ci0 + vc < g.CiLoad;
-    // deferred BatchNorm + act on x (see wgrad_body)
-    float lsc[8], lsh[8];
-    int lact = 0;
-    const bool lazy = LAZY && lzp && lzp->nseg > 0 && bok && lazy_consts<8>(*lzp, ci0 + vc, lsc, lsh, lact);
-    uint32_t lok = 0;                      // bit t: rb[t] holds in-range data
 
     auto load_chunk = [&](int) {           // called for chunk 0, 1, 2, ... in order
         const bool pok = cp < p_end;
-        lok = 0;
         ra = __builtin_amdgcn_raw_buffer_load_b128(yr, (pok && aok) ? aoff : OOB, 0, 0);
         const int iy0 = coy * g.stride - g.pad, ix0 = cox * g.stride - g.pad;
         const int nb = cn * g.Hi;
@@ -513,7 +470,6 @@ __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x,
             const uint32_t o = lin ? boff + (uint32_t)ky * brow + (uint32_t)kx * bcol
                                    : (uint32_t)(((nb + iy) * g.Wi + ix) * (int)g.xld + ci0 + vc) * 2u;
             rb[t] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? o : OOB, 0, 0);
-            if (LAZY && ok) lok |= 1u << t;
         }
         cp += PKA;
         aoff += astep;
@@ -529,9 +485,7 @@ __device__ __forceinline__ void wgrad_alltaps_body(const bf16_t* __restrict__ x,
         *reinterpret_cast<u32x4*>(&sA[(buf * PKA + srow) * ROW + vs]) = ra;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            u32x4 xb = rb[t];
-            if (LAZY && lazy) xb = lazy_apply<bf16_t>(xb, lsc, lsh, lact, (lok >> t) & 1u);
-            *reinterpret_cast<u32x4*>(&sB[((buf * NT + t) * PKA + srow) * ROW + vs]) = xb;
+            *reinterpret_cast<u32x4*>(&sB[((buf * NT + t) * PKA + srow) * ROW + vs]) = rb[t];
         }
     };
 
@@ -869,7 +823,6 @@ struct WJob {
     int32_t start[5];      // first block of this job in each launch
     int64_t n_out;
     double flops, bytes;
-    LazyIn lx;             // deferred BatchNorm + act segments of x (nseg == 0: plain)
 };
 // Blocks of one job that the hardware puts on the same XCD (consecutive block ids go round-robin over the eight XCDs) get
 // CONSECUTIVE work items: the (co, ci, tap) tiles of one pixel range then run on one XCD at about the same time and share its L2
@@ -887,19 +840,18 @@ __device__ __forceinline__ int find_job(const WJob* __restrict__ jobs, int n, in
     }
     return lo;
 }
-template <typename T, int PK, bool LAZY = false>
+template <typename T, int PK>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     const int l = find_job(jobs, n, blockIdx.x, 0);
     const WGeom g = jobs[l].g;
-    wgrad_body<T, true, PK, LAZY>((const T*)jobs[l].x, (const T*)jobs[l].dy, jobs[l].out, g,
-                            xcd_local(blockIdx.x - jobs[l].start[0], jobs[l].blocks[0]), &jobs[l].lx);
+    wgrad_body<T, true, PK>((const T*)jobs[l].x, (const T*)jobs[l].dy, jobs[l].out, g,
+                            xcd_local(blockIdx.x - jobs[l].start[0], jobs[l].blocks[0]));
 }
-template <bool LAZY>
 __global__ __launch_bounds__(256, 2) void wgrad_alltaps_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     const int l = find_job(jobs, n, blockIdx.x, 1);
     const WGeom g = jobs[l].g;
-    wgrad_alltaps_body<9, LAZY>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
-                          xcd_local(blockIdx.x - jobs[l].start[1], jobs[l].blocks[1]), &jobs[l].lx);
+    wgrad_alltaps_body<9>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
+                          xcd_local(blockIdx.x - jobs[l].start[1], jobs[l].blocks[1]));
 }
 template <int PK>
 __global__ __launch_bounds__(256, 2) void wgrad128_grouped_kernel(const WJob* __restrict__ jobs, int n) {
@@ -1097,8 +1049,7 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
 constexpr size_t ALLTAPS_LDS = (size_t)2 * 32 * TB * 2 * (1 + 9);   // A + 9 shifted B tiles, double buffered: 80 KiB
 int alltaps_attr_once() {
     DSN_LDS_ATTR(wgrad_alltaps_bf16_kernel<9>, (int)ALLTAPS_LDS);
-    DSN_LDS_ATTR(wgrad_alltaps_grouped_kernel<false>, (int)ALLTAPS_LDS);
-    DSN_LDS_ATTR(wgrad_alltaps_grouped_kernel<true>, (int)ALLTAPS_LDS);
+    DSN_LDS_ATTR(wgrad_alltaps_grouped_kernel, (int)ALLTAPS_LDS);
     return DSN_OK;
 }
 
@@ -1179,26 +1130,6 @@ extern "C" int dsn_conv2d_wgrad_plan(const dsn_tensor* x, const dsn_tensor* dy, 
     return DSN_OK;
 }
 
-// The same with a deferred-BatchNorm x operand (dsn_lazy_in with scale / shift arrays: backward runs after
-// dsn_bn_finalize_multi).  Only the grouped 16-byte paths apply the transform: DSN_EUNSUPPORTED otherwise (materialise x).
-extern "C" int dsn_conv2d_wgrad_plan_lazy(const dsn_tensor* x, const dsn_lazy_in* lx, const dsn_tensor* dy, float* dw,
-                                          int32_t ci_pad, int32_t oihw, const dsn_conv_params* p, void* workspace,
-                                          int64_t workspace_bytes, void* job_out) {
-    int rc = dsn_conv2d_wgrad_plan(x, dy, dw, ci_pad, oihw, p, workspace, workspace_bytes, job_out);
-    if (rc || !lx || lx->nseg == 0) return rc;
-    DSN_CHECK_ARG(lx->nseg > 0 && lx->nseg <= DSN_LAZY_MAXSEG, "conv wgrad plan: %d lazy segments", lx->nseg);
-    for (int i = 0; i < lx->nseg; ++i) {
-        const dsn_lazy_seg& s = lx->seg[i];
-        DSN_CHECK_ARG(s.c0 >= 0 && s.c1 > s.c0 && s.c1 <= x->c && !s.acc && s.scale && s.shift,
-                      "conv wgrad plan: lazy segment %d must carry scale / shift arrays over channels inside x", i);
-        if (s.c0 % 8 || s.c1 % 8) DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: lazy segment bounds must be multiples of 8");
-    }
-    if (((WJob*)job_out)->kind >= 3)
-        DSN_FAIL(DSN_EUNSUPPORTED, "conv wgrad plan: the 128 x 128-tile / halo-tile kernels do not apply deferred transforms (materialise x)");
-    ((WJob*)job_out)->lx = *lx;
-    return DSN_OK;
-}
-
 // jobs_host: n planned jobs, contiguous.  Assigns every job its first block in each of the three launches (in place) and
 // returns the grid sizes + totals in launch_out[10] = {grid per-tap, grid all-taps, grid reduce, dtype, flops, bytes,
 // reduce bytes, any deferred x, grid 128-tile, grid halo-tile} (doubles).  Upload the array AFTER this call.
@@ -1224,9 +1155,7 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
         DSN_CHECK_ARG(start[k] < (1ll << 31), "conv wgrad plan_finish: too many blocks");
     launch_out[0] = (double)start[0]; launch_out[1] = (double)start[1]; launch_out[2] = (double)start[2];
     launch_out[3] = (double)jobs[0].dtype; launch_out[4] = flops; launch_out[5] = bytes; launch_out[6] = rbytes;
-    int any_lazy = 0;
-    for (int i = 0; i < n; ++i) any_lazy |= jobs[i].lx.nseg > 0;
-    launch_out[7] = (double)any_lazy;       // some x operand carries deferred-BatchNorm segments: the LAZY instantiations run
+    launch_out[7] = 0.0;                    // (reserved: was "some x operand carries deferred-BatchNorm segments")
     launch_out[8] = (double)start[3];       // grid of the 128 x 128-tile launch
     launch_out[9] = (double)start[4];       // grid of the halo-tile all-taps launch
     static const bool dump = getenv("DSN_WGRAD_DUMP") && atoi(getenv("DSN_WGRAD_DUMP"));     // the plan, one line per job (stderr)
@@ -1256,17 +1185,12 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
     const WJob* jobs = (const WJob*)jobs_dev;
     const int g0 = (int)launch[0], g1 = (int)launch[1], g2 = (int)launch[2], dtype = (int)launch[3];
     const int g3 = (int)launch[8], g4 = (int)launch[9];
-    const bool lazy = launch[7] != 0.0;
     {
         ProfScope prof(KID_WGRAD + (dtype == DSN_BF16 ? 1 : 0), launch[4], launch[5], st);
         if (g0 > 0) {
             static const int gpk = [] { const char* e = getenv("DSN_WGRAD_GPK"); return (e && atoi(e) == 64) ? 64 : 32; }();
-            if (dtype == DSN_F32 && lazy)
-                hipLaunchKernelGGL((wgrad_grouped_kernel<float, 32, true>), dim3(g0), dim3(256), 0, st, jobs, n);
-            else if (dtype == DSN_F32)
+            if (dtype == DSN_F32)
                 hipLaunchKernelGGL((wgrad_grouped_kernel<float, 32>), dim3(g0), dim3(256), 0, st, jobs, n);
-            else if (lazy)
-                hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 32, true>), dim3(g0), dim3(256), 0, st, jobs, n);
             else if (gpk == 64)
                 hipLaunchKernelGGL((wgrad_grouped_kernel<bf16_t, 64>), dim3(g0), dim3(256), 0, st, jobs, n);
             else
@@ -1285,8 +1209,7 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
         if (g1 > 0) {
             DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: all-taps jobs are bf16 only");
             { const int a_ = alltaps_attr_once(); if (a_ != DSN_OK) return a_; }
-            if (lazy) hipLaunchKernelGGL(wgrad_alltaps_grouped_kernel<true>, dim3(g1), dim3(256), ALLTAPS_LDS, st, jobs, n);
-            else hipLaunchKernelGGL(wgrad_alltaps_grouped_kernel<false>, dim3(g1), dim3(256), ALLTAPS_LDS, st, jobs, n);
+            hipLaunchKernelGGL(wgrad_alltaps_grouped_kernel, dim3(g1), dim3(256), ALLTAPS_LDS, st, jobs, n);
         }
     }
     DSN_LAUNCH_CHECK("conv wgrad grouped");

@@ -79,37 +79,8 @@ def as_act(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-# ---- deferred BatchNorm guard ------------------------------------------------------------------------------------------------
-# A tensor tagged on a live Tape (runtime.Tape.lazy_tag) holds RAW pre-BN values: only the entry points that apply the deferred
-# transform themselves (conv forward x, weight-gradient x, lazy_materialize, the BN backward's y operand) may read it.  Every other
-# kernel wrapper goes through desc(), which refuses such memory loudly instead of computing on un-normalised activations.
-import weakref as _weakref
-
-_lazy_tapes = _weakref.WeakSet()
-
-
-def _lazy_guard_add(tape, sp):
-    _lazy_tapes.add(tape)
-
-
-def _lazy_guard(t):
-    if not _lazy_tapes:
-        return
-    sp = None
-    for tape in list(_lazy_tapes):
-        if not tape.lazy:
-            continue
-        if sp is None:
-            sp = t.untyped_storage().data_ptr()
-        if sp in tape.lazy and tape.lazy_lookup(t) is not None:
-            raise RuntimeError("a deferred-BatchNorm activation (raw convolution output awaiting act(bn(.))) reached a kernel that "
-                               "does not apply the transform: materialise it first (runtime.Tape.materialize)")
-
-
-def desc(t: torch.Tensor, raw: bool = False) -> dsn_tensor:
+def desc(t: torch.Tensor, raw: bool = False) -> dsn_tensor:      # (raw: kept for call sites that name a pre-BatchNorm operand)
     _require_gpu(t)
-    if not raw:
-        _lazy_guard(t)
     ldc = _nhwc_ldc(t)
     if ldc is None:
         raise ValueError(f"tensor with shape {tuple(t.shape)} strides {t.stride()} is not an NHWC view")
@@ -139,44 +110,23 @@ def conv_out_hw(h, w, k, stride, pad, dil):
     return ((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
 
 
-def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params, lazy=None, z_out=None):
-    """lazy: dsn_lazy_in describing deferred-BatchNorm segments of x (runtime.Tape.lazy_in) -- applied while x is staged.
-    z_out (with lazy): the materialised x is written there on the way (dsn_conv2d_fwd_lazy_z)."""
+def conv2d_fwd(x, w_packed, bias, residual, y, p: dsn_conv_params):
     L = _lib.lib()
-    dx, dy = desc(x, raw=lazy is not None), desc(y)
+    dx, dy = desc(x), desc(y)
     dr = desc(residual) if residual is not None else None
-    if lazy is not None and z_out is not None:
-        dz = desc(z_out)
-        _lib.check(L.dsn_conv2d_fwd_lazy_z(C.byref(dx), C.byref(lazy), C.byref(dz), w_packed.data_ptr(), _p(bias), _ref(dr),
-                                           C.byref(dy), C.byref(p), None, 0, stream_ptr()), "conv2d_fwd_lazy_z")
-        return y
-    if lazy is not None:
-        _lib.check(L.dsn_conv2d_fwd_lazy(C.byref(dx), C.byref(lazy), w_packed.data_ptr(), _p(bias), _ref(dr), C.byref(dy),
-                                         C.byref(p), None, 0, stream_ptr()), "conv2d_fwd_lazy")
-        return y
     _lib.check(L.dsn_conv2d_fwd(C.byref(dx), w_packed.data_ptr(), _p(bias), _ref(dr), C.byref(dy), C.byref(p),
                                 stream_ptr()), "conv2d_fwd")
     return y
 
 
-def lazy_input_ok(x) -> bool:
-    """Can a convolution apply a deferred transform to x while staging it?  (16-byte channel vectors, <= 1024 channels.)"""
-    return _vec16(x) and x.shape[1] % 8 == 0 and x.shape[1] <= 1024
-
-
-def conv2d_fwd_acc(x, w_packed, y, p: dsn_conv_params, lazy=None, z_out=None):
-    """Training forward of a BN'd convolution WITHOUT the BN + act pass: y = conv(x) (x may carry deferred segments) and the
-    per-channel fp64 sums of y in a fresh accumulator slot.  Returns (acc tensor, acc bytes).  z_out: see conv2d_fwd."""
+def conv2d_fwd_acc(x, w_packed, y, p: dsn_conv_params):
+    """Training forward of a BN'd convolution WITHOUT the BN + act pass: y = conv(x) and the per-channel fp64 sums of y in a fresh
+    accumulator slot (dsn_conv2d_fwd_bnacc).  Returns (acc tensor, acc bytes)."""
     L = _lib.lib()
-    dx, dy = desc(x, raw=lazy is not None), desc(y)
+    dx, dy = desc(x), desc(y)
     acc, nbytes = bn_acc(y.shape[1], y.device)
-    if lazy is not None and z_out is not None:
-        dz = desc(z_out)
-        _lib.check(L.dsn_conv2d_fwd_lazy_z(C.byref(dx), C.byref(lazy), C.byref(dz), w_packed.data_ptr(), None, None,
-                                           C.byref(dy), C.byref(p), acc.data_ptr(), nbytes, stream_ptr()), "conv2d_fwd_lazy_z")
-        return acc, nbytes
-    _lib.check(L.dsn_conv2d_fwd_lazy(C.byref(dx), C.byref(lazy) if lazy is not None else None, w_packed.data_ptr(), None, None,
-                                     C.byref(dy), C.byref(p), acc.data_ptr(), nbytes, stream_ptr()), "conv2d_fwd_lazy")
+    _lib.check(L.dsn_conv2d_fwd_bnacc(C.byref(dx), w_packed.data_ptr(), C.byref(dy), C.byref(p), acc.data_ptr(), nbytes,
+                                      stream_ptr()), "conv2d_fwd_bnacc")
     return acc, nbytes
 
 
@@ -329,28 +279,22 @@ def scratch(nbytes: int, device) -> torch.Tensor:
     return _note_capture(buf)
 
 
-def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False, queue: "Optional[WgradQueue]" = None, lazy=None):
+def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False, queue: "Optional[WgradQueue]" = None):
     """oihw=False: dw packed [Co][KH][KW][ci] (ci >= x channels).  oihw=True: dw is the OIHW fp32 gradient itself
     (ci = real input channels <= x channels); p.accumulate adds into it.
     queue: defer the launch -- the job is planned now and runs with every other queued layer at queue.flush()."""
     L = _lib.lib()
-    a, b = desc(x, raw=lazy is not None), desc(dy)
+    a, b = desc(x), desc(dy)
     nbytes = L.dsn_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(b), C.byref(p), ci)
     if queue is not None:
         slab = queue.slab(nbytes) if nbytes else None
-        if lazy is not None:
-            rc = L.dsn_conv2d_wgrad_plan_lazy(C.byref(a), C.byref(lazy), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p),
-                                              _p(slab), nbytes, queue.next_job_ptr())
-        else:
-            rc = L.dsn_conv2d_wgrad_plan(C.byref(a), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p), _p(slab), nbytes,
-                                         queue.next_job_ptr())
+        rc = L.dsn_conv2d_wgrad_plan(C.byref(a), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p), _p(slab), nbytes,
+                                     queue.next_job_ptr())
         if rc == 0:
             queue.commit(x, dy, dw, slab)
             return dw
         if rc != DSN_EUNSUPPORTED:
             _lib.check(rc, "conv2d_wgrad_plan")
-    if lazy is not None:
-        raise LazyUnsupported("weight gradient with a deferred-BatchNorm x operand needs the queued 16-byte paths")
     ws = scratch(nbytes, x.device) if nbytes else None
     _lib.check(L.dsn_conv2d_wgrad(C.byref(a), C.byref(b), dw.data_ptr(), ci, int(oihw), C.byref(p), _p(ws), nbytes,
                                   stream_ptr()), "conv2d_wgrad")
@@ -360,8 +304,8 @@ def conv2d_wgrad(x, dy, dw, ci, p: dsn_conv_params, oihw: bool = False, queue: "
 DSN_EUNSUPPORTED = -2
 
 
-class LazyUnsupported(RuntimeError):
-    """A kernel cannot apply a deferred transform for this shape: the caller materialises the operand and retries."""
+class KernelUnsupported(RuntimeError):
+    """A fused kernel does not take this shape: the caller runs the unfused launches instead."""
 
 
 _wgrad_arena = {}          # device -> persistent slab buffer (bump-allocated within a backward pass)
@@ -1231,7 +1175,7 @@ _seg_up_ws = {}
 def seg_ce_up(logits, target, out_hw, ignore_index=-1, gain=1.0):
     """Fused x-scale bilinear(align_corners=True) + CrossEntropyLoss on the LOW-resolution seg logits (an NHWC activation
     [N, C, h, w]): returns (out [2] = {mean CE, 1/valid}, dlogits: zero-padded NHWC activation of the logits' shape holding
-    gain * d loss / d logits).  Raises LazyUnsupported for shapes the fused kernel does not take."""
+    gain * d loss / d logits).  Raises KernelUnsupported for shapes the fused kernel does not take."""
     L = _lib.lib()
     tg = target if (target.dtype == torch.int64 and target.is_contiguous()) else target.long().contiguous()
     n, c, h, w = logits.shape
@@ -1249,7 +1193,7 @@ def seg_ce_up(logits, target, out_hw, ignore_index=-1, gain=1.0):
     rc = L.dsn_seg_ce_up(C.byref(a), tg.data_ptr(), H, W, int(ignore_index), float(gain), out.data_ptr(), C.byref(b),
                          ws.data_ptr(), nbytes, stream_ptr())
     if rc == DSN_EUNSUPPORTED:
-        raise LazyUnsupported(_lib.lib().dsn_last_error().decode(errors="replace"))
+        raise KernelUnsupported(_lib.lib().dsn_last_error().decode(errors="replace"))
     _lib.check(rc, "seg_ce_up")
     dl._dsn_zero_padded = True
     return out, dl

@@ -61,26 +61,23 @@ def wgrad_stream(device):
 
 
 class LazyRec:
-    """One BatchNorm module's DEFERRED affine + activation over channels [lo, hi) of an NHWC buffer's rows: the buffer holds the raw
-    convolution output y, `acc` the per-channel fp64 sums its epilogue produced; consumers that are convolutions apply
-    z = act(y*scale + shift) while staging their operand (include/desenet_hip.h: dsn_lazy_in).  `stats` ([4, n]: scale, shift,
-    mean, rstd) is filled by ONE dsn_bn_finalize_multi launch at the end of the forward pass, which also updates the running
-    statistics -- the backward pass and the weight-gradient kernels read the arrays."""
+    """One BatchNorm module whose saved statistics are still to be written: `acc` holds the per-channel fp64 sums the convolution's
+    epilogue produced (channels ch0 .. ch0 + hi of an acc_c-channel accumulator); `stats` ([4, n]: scale, shift, mean, rstd,
+    columns o0 ..) is filled by ONE dsn_bn_finalize_multi launch at the end of the forward pass, which also updates the running
+    statistics -- the backward pass reads the arrays."""
     __slots__ = ("sp", "lo", "hi", "acc", "acc_c", "ch0", "count", "bn", "act", "stats", "o0", "keep")
 
 
 class Tape:
     """LIFO of forward records with a replayable cursor (two backward() calls on one forward, train.py:366-367), plus the
-    registry of deferred-BatchNorm tensors of this forward pass (tags are keyed by MEMORY: storage + channel range, so channel
-    slices and zero-copy concats of tagged buffers resolve by themselves)."""
+    registry of BatchNorm-block outputs of this forward pass (keyed by MEMORY: storage + channel range, so channel slices and
+    zero-copy concats resolve by themselves) and the BatchNorm modules whose statistics the end-of-forward launch finalises."""
 
     def __init__(self):
         self.stack: List[object] = []
         self.cursor = 0
         self.grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
-        self.lazy: Dict[int, List[LazyRec]] = {}
         self.lazy_pending: List[LazyRec] = []
-        self.lazy_copies: Dict[tuple, torch.Tensor] = {}
         self.bn_out: Dict[int, list] = {}
 
     # ---- producers of BatchNorm outputs, by memory (conv_impl: backward sums in the consumer's dgrad epilogue) -----------------
@@ -107,7 +104,7 @@ class Tape:
                 out.append((a - lo, b - lo, rec, a - plo))
         return out or None
 
-    # ---- deferred BatchNorm registry ----------------------------------------------------------------------------------------
+    # ---- memory ranges / pending BatchNorm finalisation ----------------------------------------------------------------------------------------
     @staticmethod
     def _range(t):
         ops = _ops()
@@ -116,97 +113,14 @@ class Tape:
             return None
         return t.untyped_storage().data_ptr(), ldc, (t.storage_offset() % ldc if ldc else 0), t.shape[1]
 
-    def lazy_tag(self, y, acc, acc_c, ch0, count, bn, act, stats, o0=0):
-        """Mark the view `y` (raw conv output) as deferred: z = act(bn(y)) has NOT been applied.  stats: [4, C] tensor whose
-        columns o0.. receive this module's constants at finalize time."""
-        sp, ldc, lo, c = self._range(y)
-        r = LazyRec()
-        r.sp, r.lo, r.hi, r.acc, r.acc_c, r.ch0, r.count, r.bn, r.act, r.stats, r.o0, r.keep = \
-            sp, lo, lo + c, acc, acc_c, ch0, float(count), bn, act, stats, o0, y
-        self.lazy.setdefault(sp, []).append(r)
-        self.lazy_pending.append(r)
-        _ops()._lazy_guard_add(self, sp)
-        return r
-
     def lazy_pending_only(self, acc, acc_c, ch0, n, count, bn, stats, o0=0):
-        """A BatchNorm whose output WAS materialised in the forward pass (dsn_lazy_materialize): only its saved statistics and
-        running averages are still to be written by the end-of-forward finalisation."""
+        """A BatchNorm whose output was written by dsn_lazy_materialize: its saved statistics and running averages are still to be
+        written by the end-of-forward finalisation."""
         r = LazyRec()
         r.sp, r.lo, r.hi, r.acc, r.acc_c, r.ch0, r.count, r.bn, r.act, r.stats, r.o0, r.keep = \
             None, 0, n, acc, acc_c, ch0, float(count), bn, 0, stats, o0, None
         self.lazy_pending.append(r)
         return r
-
-    def lazy_lookup(self, x):
-        """[(c0, c1, rec, k0)]: channel ranges of `x` that are deferred (k0 = first channel of the range inside rec), or None."""
-        if not self.lazy or not torch.is_tensor(x) or x.dim() != 4:
-            return None
-        rng = self._range(x)
-        if rng is None:
-            return None
-        sp, ldc, lo, c = rng
-        recs = self.lazy.get(sp)
-        if not recs:
-            return None
-        out = []
-        for r in recs:
-            a, b = max(lo, r.lo), min(lo + c, r.hi)
-            if a < b:
-                out.append((a - lo, b - lo, r, a - r.lo))
-        return out or None
-
-    def lazy_in(self, x, backward=False):
-        """ctypes dsn_lazy_in for the tensor x (None when nothing in x is deferred).  forward: segments fold the accumulators;
-        backward: segments read the finalised scale / shift arrays."""
-        hits = self.lazy_lookup(x)
-        if hits is None:
-            return None
-        ops = _ops()
-        if len(hits) > ops._lib.LAZY_MAXSEG or any(c0 % 8 or c1 % 8 for c0, c1, _, _ in hits):
-            return False                   # cannot be expressed: the caller materialises
-        lz = ops._lib.dsn_lazy_in()
-        lz.nseg = len(hits)
-        for i, (c0, c1, r, k0) in enumerate(hits):
-            s = lz.seg[i]
-            s.c0, s.c1, s.act = c0, c1, r.act
-            s.count, s.eps = r.count, float(r.bn.eps)
-            if backward:
-                s.acc, s.acc_c, s.ch0 = None, 0, 0
-                s.p0 = r.o0 + k0
-                s.scale, s.shift = r.stats[0].data_ptr(), r.stats[1].data_ptr()
-            else:
-                s.acc, s.acc_c, s.ch0, s.p0 = r.acc.data_ptr(), r.acc_c, r.ch0 + k0, k0
-                s.gamma = r.bn.weight.data_ptr() if r.bn.weight is not None else None
-                s.beta = r.bn.bias.data_ptr() if r.bn.bias is not None else None
-        return lz
-
-    def materialize(self, x, backward=False):
-        """A plain tensor holding act(bn(x)) for a tensor with deferred segments (cached per view): the fallback for consumers
-        that cannot apply the transform themselves.  Returns x itself when nothing in it is deferred."""
-        hits = self.lazy_lookup(x)
-        if hits is None:
-            return x
-        ops = _ops()
-        key = (self._range(x), backward)
-        z = self.lazy_copies.get(key)
-        if z is None:
-            lz = self.lazy_in(x, backward)
-            if lz is False:
-                raise NotImplementedError("deferred-BatchNorm tensor with more than 6 segments or unaligned segment bounds")
-            z = ops.new_act(*x.shape, x.dtype, x.device)
-            ops.lazy_materialize(x, lz, z)
-            self.lazy_copies[key] = z
-        return z
-
-    def lazy_copy(self, x):
-        """The materialised copy of the deferred tensor x made earlier in this forward pass, or None."""
-        return self.lazy_copies.get((self._range(x), False))
-
-    def lazy_register_copy(self, x, z):
-        """z holds act(bn(x)) for the deferred view x (written by a convolution on the way: dsn_conv2d_fwd_lazy_z)."""
-        rng = self._range(x)
-        self.lazy_copies[(rng, False)] = z
-        self.lazy_copies[(rng, True)] = z
 
     def finalize_forward(self):
         """End of the forward pass: ONE launch (per 40 modules) writes every pending BatchNorm's saved statistics and updates its

@@ -52,15 +52,17 @@ typedef struct {
     int32_t accumulate;  /* 1: out += result (gradient fan-in)            */
 } dsn_conv_params;
 
-/* ---- deferred BatchNorm + activation ("lazy" input of a convolution) ------------------------------------------------
+/* ---- BatchNorm + activation from accumulators (operand descriptor of dsn_lazy_materialize) ---------------------------------
  * In training a Conv block computes z = act(bn(conv(x))) (common.py:53) with batch statistics: the statistics of the WHOLE
- * tensor must exist before a single z can be formed.  Instead of a separate BN + act pass over HBM, a block may leave its
- * RAW convolution output y in place (plus the per-channel fp64 sums its epilogue produced, dsn_conv2d_fwd_bnacc) and let every
- * CONSUMING convolution apply z = act(y*scale + shift) while it stages its input operand.  The consumer's input is described
- * as up to DSN_LAZY_MAXSEG channel segments (a concat of lazy tensors and ordinary ones -- common.py:145,185,545,693).
+ * tensor must exist before a single z can be formed.  The block leaves its RAW convolution output y plus the per-channel fp64
+ * sums its epilogue produced (dsn_conv2d_fwd_bnacc); ONE elementwise launch (dsn_lazy_materialize) folds the sums in its prologue
+ * and writes z (+ shortcut).  Its input is described as up to DSN_LAZY_MAXSEG channel segments (one per BatchNorm module whose
+ * output lies in the tensor -- a merged C3 cv2|cv1 pair has two):
  *   input channel c in [c0, c1): accumulator channel ch0 + (c - c0), parameter index p0 + (c - c0)
  *   acc != NULL : fold the sums here (count, eps, gamma, beta -- NULL gamma/beta = 1 / 0); else scale/shift arrays (both NULL:
- *   identity).  act = DSN_ACT_* applied after the affine map.  Channels outside every segment pass through unchanged. */
+ *   identity).  act = DSN_ACT_* applied after the affine map.  Channels outside every segment pass through unchanged.
+ * (Rounds 2-3 also let the CONSUMING convolution apply the transform in its operand loader -- dsn_conv2d_fwd_lazy[_z],
+ *  dsn_conv2d_wgrad_plan_lazy; measured slower on MI355X and removed in round 4.) */
 #define DSN_LAZY_MAXSEG 6
 typedef struct {
     int32_t       c0, c1;       /* channel range of the consumer's input */
@@ -487,12 +489,7 @@ int dsn_copy_multi(const dsn_copy_seg* segs_host, int32_t n, void* stream);
 /* p[i] += value for n int64 elements: BatchNorm's `num_batches_tracked += 1` for every layer in one launch. */
 int dsn_add_i64(void* p, int64_t n, int64_t value, void* stream);
 
-/* ---- convolution with a deferred-BatchNorm input, and the end-of-forward finalisation ---------------------------------------
- * dsn_conv2d_fwd_lazy: dsn_conv2d_fwd / dsn_conv2d_fwd_bnacc whose input x holds raw pre-BN values for the channel segments of
- *   `lazy` (NULL or nseg == 0: plain input).  acc != NULL: also emit the BatchNorm sums of y (dsn_conv2d_fwd_bnacc; bias NULL,
- *   act NONE, no residual).  DSN_EUNSUPPORTED when the layer cannot take the 16-byte staging paths, has more than 1024 input
- *   channels or segment bounds that are not multiples of the vector width: materialise x (dsn_bn_act_fwd_acc) and call the plain
- *   entry point.
+/* ---- the end-of-forward BatchNorm finalisation and the BatchNorm + activation pass from accumulators ----------------------------
  * dsn_bn_finalize_multi: for n BatchNorm modules whose sums are complete, write scale = g*rstd, shift = b - mean*scale, mean, rstd
  *   (saved for the backward pass) and update the running statistics (torch_utils.py:164-165 momentum 0.03, unbiased variance) --
  *   ONE launch per 40 modules at the end of the forward pass instead of one per layer.  entries: HOST array. */
@@ -511,23 +508,7 @@ typedef struct {
     float*       rstd;
     float        momentum, eps;
 } dsn_bn_final;
-int dsn_conv2d_fwd_lazy(const dsn_tensor* x, const dsn_lazy_in* lazy, const void* w_packed, const float* bias,
-                        const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p, void* acc, int64_t acc_bytes,
-                        void* stream);
-/* dsn_conv2d_fwd_lazy + z: the materialised input (act(bn(x)) on the deferred segments of `lazy`, x elsewhere; shape of x) is
- * written to z as a side effect -- by the convolution kernel itself where it stages whole tiles through LDS (3x3 / stride 1 and
- * 1x1 / stride 1 with whole 128-byte channel slabs: the tile is transformed once per block, in LDS), by one elementwise launch
- * ahead of the convolution for every other layer.  Replaces the BatchNorm + SiLU pass between two Conv modules
- * (reference core/models/common.py:38-57: Conv.forward = act(bn(conv(x)))). */
-int dsn_conv2d_fwd_lazy_z(const dsn_tensor* x, const dsn_lazy_in* lazy, const dsn_tensor* z, const void* w_packed,
-                          const float* bias, const dsn_tensor* residual, const dsn_tensor* y, const dsn_conv_params* p,
-                          void* acc, int64_t acc_bytes, void* stream);
 int dsn_bn_finalize_multi(const dsn_bn_final* entries_host, int32_t n, void* stream);
-/* dsn_conv2d_wgrad_plan with a deferred-BatchNorm x operand: lx segments carry scale / shift arrays (acc NULL; the backward pass
- * runs after dsn_bn_finalize_multi); the queued kernels apply z = act(x*scale + shift) while staging x.  DSN_EUNSUPPORTED when
- * the layer cannot take the grouped 16-byte paths: materialise x and plan / run the plain form. */
-int dsn_conv2d_wgrad_plan_lazy(const dsn_tensor* x, const dsn_lazy_in* lx, const dsn_tensor* dy, float* dw, int32_t ci_pad,
-                               int32_t oihw, const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* job_out);
 /* z = act(x*scale + shift) per segment of lx (NULL: copy) [+ the same of `residual` under lres: a Bottleneck shortcut,
  * common.py:111, rounded to the storage type before the add exactly as a materialised shortcut would be].  No side effects on
  * BatchNorm state.  DSN_EUNSUPPORTED without 16-byte channel vectors or above 1024 channels. */

@@ -1,6 +1,5 @@
 """Host-side planning logic that decides where BatchNorm work is fused (no GPU): which top-level layers complete the gradient of
-their input (Model._final_consumer -> conv_impl.conv_block_bwd(fuse_up=True)), which may leave a deferred output
-(Model._lazy_plan), and the memory-range registry that maps a consumer's input view to the BatchNorm blocks that produced it
+their input (Model._final_consumer -> conv_impl.conv_block_bwd(fuse_up=True)), and the memory-range registry that maps a consumer's input view to the BatchNorm blocks that produced it
 (runtime.Tape.bn_register / bn_producers, zero-copy concats and channel slices included)."""
 import os
 
