@@ -172,6 +172,8 @@ PROTOTYPES = {
     "dsn_det_loss_workspace_bytes": (i64, [i32, i32, i32, i32, i64]),
     "dsn_det_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, vp,
                            vp, i64, vp]),
+    "dsn_det_loss_opt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32,
+                               vp, i32, i32, vp, vp, i64, vp]),
     "dsn_seg_ce_workspace_bytes": (i64, []),
     "dsn_seg_ce": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
     "dsn_seg_ce_up_workspace_bytes": (i64, [i32, i32, i32, i32, i32]),

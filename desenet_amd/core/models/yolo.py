@@ -420,9 +420,35 @@ class Model(HipModule):
 
     # ---- forward / backward ---------------------------------------------------------------------------------------
     def forward(self, x, augment=False, profile=False, visualize=False):
-        if augment or profile or visualize:
-            raise NotImplementedError("augment / profile / visualize are outside the hot path (SURVEY.md 2 row 5)")
+        if profile or visualize:
+            raise NotImplementedError("profile / visualize are outside the hot path (SURVEY.md 2 row 5)")
+        if augment:
+            return self._forward_augment(x)
         return run_module(self, x)
+
+    def _forward_augment(self, x):
+        """Test-time augmentation (yolo.py:331-342,358-374): scales 1 / 0.83 / 0.67, left-right flip on the second, de-scaled and
+        de-flipped predictions concatenated along the box axis; returns `(cat, None)` as the reference's return statement does.
+        NOTE: the reference's own path cannot run -- with the seg head `_forward_once(xi)[0]` is the TUPLE (pred, raws)
+        (yolo.py:356), and `_descale_pred` indexes it with `p[..., :4]` (TypeError) -- so this follows the evident intent
+        (upstream YOLOv5: the decoded predictions): oracle/desenet_ref.forward_augment restates the same arithmetic."""
+        from ..utils.torch_utils import scale_img
+        if self.training:
+            raise RuntimeError("augmented inference needs model.eval()")
+        img_size = x.shape[-2:]
+        gs = int(float(self.stride.max()))
+        y = []
+        for si, fi in zip([1, 0.83, 0.67], [None, 3, None]):
+            xi = scale_img(x.flip(fi) if fi else x, si, gs=gs)
+            (pred, _), _ = run_module(self, xi)
+            p = pred.clone()
+            p[..., :4] /= si                                   # de-scale
+            if fi == 2:
+                p[..., 1] = img_size[0] - p[..., 1]            # de-flip ud
+            elif fi == 3:
+                p[..., 0] = img_size[1] - p[..., 0]            # de-flip lr
+            y.append(p)
+        return torch.cat(y, 1), None
 
     # ---- per-step, whole-model preparation (training): one pack launch, one BN-counter increment --------------------------
     def _prepare_training_step(self, dtype, device):

@@ -69,8 +69,20 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     """prediction: (bs, n, 5+nc) -> list of (n_i, 6) tensors [x1, y1, x2, y2, conf, cls] per image."""
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
-    if labels:
-        raise NotImplementedError("apriori `labels` (auto-labelling) are outside the hot path")
+    if labels and any(len(l) for l in labels):
+        # apriori labels (general.py:690-697, auto-labelling): rows [box, conf 1, one-hot class] appended AFTER each image's own
+        # rows (the candidate order the stable score sort preserves).  The kernels take one row count for the batch: images with
+        # fewer labels get rows of objectness 0, which the confidence filter (general.py:668,687) drops.
+        bs, n, no = prediction.shape
+        lmax = max(len(l) for l in labels)
+        extra = torch.zeros((bs, lmax, no), dtype=prediction.dtype, device=prediction.device)
+        for xi, l in enumerate(labels):
+            if len(l):
+                l = torch.as_tensor(l, dtype=prediction.dtype, device=prediction.device)
+                extra[xi, :len(l), :4] = l[:, 1:5]
+                extra[xi, :len(l), 4] = 1.0
+                extra[xi, torch.arange(len(l), device=prediction.device), l[:, 0].long() + 5] = 1.0
+        prediction = torch.cat((prediction, extra), 1)
     out, cnt = ops.nms(prediction, conf_thres, iou_thres, multi_label, agnostic, classes, max_det)
     counts = cnt.cpu().tolist()      # the one host sync (the reference syncs per image on x.shape[0])
     return [out[i, :c] for i, c in enumerate(counts)]

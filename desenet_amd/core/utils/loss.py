@@ -12,7 +12,10 @@ produced.  `forward_backward(...)` returns loss and gradients directly (what des
 Deviations from the reference, both deliberate: the int64 clamp with float-tensor bounds of loss.py:218 (rejected by
 torch >= 1.12) is an integer clamp; a cell matched by several candidates takes the LAST one in the reference's candidate
 order as its objectness target (the reference's scatter with duplicate indices is order-dependent on a GPU).
-Unsupported reference options raise: focal loss (fl_gamma > 0), autobalance, auxiliary / SE segmentation losses.
+Reference options off in scripts/train.py but inside loss.py:91-168 are implemented: focal loss (hyp['fl_gamma'] > 0) and
+`autobalance=True` -- the latter keeps the per-level balance on the DEVICE (the reference reads each level's loss back with
+`.item()`, a host synchronisation per level and step); `.balance` returns it as a list on demand.  Still raising: auxiliary / SE
+segmentation losses (heads outside the hot path).
 """
 from __future__ import annotations
 
@@ -42,22 +45,33 @@ class _DetLossFn(torch.autograd.Function):
 
 class ComputeLoss:
     def __init__(self, model, autobalance=False):
-        if autobalance:
-            raise NotImplementedError("autobalance is off in the reference training script")
         h = model.hyp
-        if h.get("fl_gamma", 0.0) > 0:
-            raise NotImplementedError("focal loss (fl_gamma > 0) is outside the scratch.yaml configuration")
+        self.fl_gamma = float(h.get("fl_gamma", 0.0))                   # loss.py:106-110: FocalLoss around both criteria when > 0
         self.cp, self.cn = smooth_BCE(eps=h.get("label_smoothing", 0.0))
         det = de_parallel(model).model[-1]
-        self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, .02])
+        self._balance0 = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, .02])
+        self.autobalance = bool(autobalance)
+        self.ssi = list(float(s) for s in det.stride).index(16.0) if autobalance else 0      # loss.py:113
+        self._balance_dev = None                                        # created on the first call (device of the predictions)
         self.gr, self.hyp = 1.0, h
         self.na, self.nc, self.nl, self.anchors = det.na, det.nc, det.nl, det.anchors
         self._anchors_host = det.anchors.detach().float().cpu().reshape(-1).tolist()    # once: (nl, na, 2) grid units
 
+    @property
+    def balance(self):
+        """The per-level objectness weights as a list (the reference's attribute).  With autobalance they live on the device and
+        this read synchronises; the step itself never does."""
+        if self._balance_dev is not None:
+            return [float(v) for v in self._balance_dev.detach().cpu()]
+        return list(self._balance0)
+
     def _launch(self, p, targets, gain):
         h = self.hyp
-        return ops.det_loss(p, targets, self._anchors_host, self.balance[:len(p)], h["box"], h["obj"], h["cls"], h["cls_pw"],
-                            h["obj_pw"], h["anchor_t"], self.cp, self.cn, self.nc, gain)
+        if self.autobalance and self._balance_dev is None:
+            self._balance_dev = torch.tensor(self._balance0[:len(p)], dtype=torch.float32, device=p[0].device)
+        return ops.det_loss(p, targets, self._anchors_host, self._balance0[:len(p)], h["box"], h["obj"], h["cls"], h["cls_pw"],
+                            h["obj_pw"], h["anchor_t"], self.cp, self.cn, self.nc, gain, fl_gamma=self.fl_gamma,
+                            balance_dev=self._balance_dev, autobalance=self.autobalance, ssi=self.ssi)
 
     def __call__(self, p, targets):
         return _DetLossFn.apply(self, targets, *p)

@@ -37,6 +37,23 @@ def fuse_conv_and_bn(conv, bn):
     return fused
 
 
+def scale_img(img, ratio=1.0, same_shape=False, gs=32):
+    """torch_utils.py:262-272: img (bs, 3, y, x) scaled by `ratio` (bilinear, align_corners=False) and padded with 0.447 to a
+    multiple of gs.  On the GPU the resize is the library's kernel (dsn_resize_bilinear_nchw); the pad is a copy."""
+    if ratio == 1.0:
+        return img
+    h, w = img.shape[2:]
+    s = (int(h * ratio), int(w * ratio))
+    if img.is_cuda:
+        from ... import hip_ops as ops
+        img = ops.resize_bilinear_nchw(img, s, align_corners=False)
+    else:
+        img = torch.nn.functional.interpolate(img, size=s, mode="bilinear", align_corners=False)
+    if not same_shape:
+        h, w = [math.ceil(x * ratio / gs) * gs for x in (h, w)]
+    return torch.nn.functional.pad(img, [0, w - s[1], 0, h - s[0]], value=0.447)
+
+
 def intersect_dicts(da, db, exclude=()):
     return {k: v for k, v in da.items() if k in db and not any(x in k for x in exclude) and v.shape == db[k].shape}
 

@@ -63,9 +63,28 @@ __device__ __forceinline__ float bce_logits(float x, float t, float pw, float* d
     return (1.f - t) * x + lw * sp;
 }
 
+// FocalLoss wrapped around the same criterion (loss.py:36-61, 106-110; alpha = 0.25 as the reference constructs it):
+//   loss = bce * w,  w = af * (1 - p_t)^gamma,  p_t = t p + (1 - t)(1 - p),  af = t alpha + (1 - t)(1 - alpha),  p = sigmoid(x)
+//   d loss / dx = dbce/dx * w + bce * af * gamma (1 - p_t)^(gamma - 1) * (-(2t - 1) p (1 - p))
+// gamma <= 0: the plain criterion (bit-identical to bce_logits).
+__device__ __forceinline__ float bce_focal(float x, float t, float pw, float gamma, float* dx) {
+    float d0;
+    const float l0 = bce_logits(x, t, pw, &d0);
+    if (!(gamma > 0.f)) { *dx = d0; return l0; }
+    const float alpha = 0.25f;
+    const float p = 1.f / (1.f + expf(-x));
+    const float pt = t * p + (1.f - t) * (1.f - p);
+    const float af = t * alpha + (1.f - t) * (1.f - alpha);
+    const float om = fmaxf(1.f - pt, 0.f);
+    const float m = powf(om, gamma);
+    const float dm = om > 0.f ? gamma * powf(om, gamma - 1.f) * (-(2.f * t - 1.f) * p * (1.f - p)) : 0.f;
+    *dx = af * (d0 * m + l0 * dm);
+    return l0 * af * m;
+}
+
 struct DetParams {
     int32_t bs, na, no, nc, ny, nx, nt;
-    float anchor_t, cls_pw, obj_pw, cp, cn;
+    float anchor_t, cls_pw, obj_pw, cp, cn, fl_gamma;
     float anchors[6];              // this level, grid units, [na<=3][2]
 };
 
@@ -88,10 +107,11 @@ struct DetLevel {
     float* mpart;                  // [MAX_MB][3] match block sums (n active, sum(1 - ciou), sum class BCE)
     float* acc;                    // [4]: n active, sum(1 - ciou), sum class BCE, sum objectness BCE
     DetParams q;
-    float obj_coef;
+    float obj_coef;                // h_obj * bs / cells (* the level's balance when that is a host constant)
     int32_t ob, mb, sb;            // blocks of the obj / match / scatter stages
 };
-struct DetLevels { DetLevel l[5]; int32_t nl; float box_coef, cls_coef; };
+// bal_dev != NULL: the per-level objectness weights live on the device (autobalance updates them every step, loss.py:158-164)
+struct DetLevels { DetLevel l[5]; int32_t nl; float box_coef, cls_coef; const float* bal_dev; };
 
 __global__ __launch_bounds__(LT) void det_clear_kernel(const DetLevels L) {
     const DetLevel& v = L.l[blockIdx.y];
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(LT) void det_match_kernel(const DetLevels L, const 
             if (q.nc > 1) {
                 for (int k = 0; k < q.nc; ++k) {
                     float dx;
-                    s_cls += bce_logits(ps[5 + k], k == c.cls ? q.cp : q.cn, q.cls_pw, &dx);
+                    s_cls += bce_focal(ps[5 + k], k == c.cls ? q.cp : q.cn, q.cls_pw, q.fl_gamma, &dx);
                     dcls[(int64_t)id * q.nc + k] = dx;
                 }
             }
@@ -199,7 +219,7 @@ __global__ __launch_bounds__(LT) void det_obj_kernel(const DetLevels L) {
     const Cand* __restrict__ cands = v.cands;
     const int32_t* __restrict__ owner = v.owner;
     float* __restrict__ dp = v.dp;
-    const float obj_coef = v.obj_coef;
+    const float obj_coef = L.bal_dev ? v.obj_coef * L.bal_dev[blockIdx.y] : v.obj_coef;
     float* __restrict__ partial = v.partial;
     __shared__ float red[LT];
     const int64_t ncell = (int64_t)q.bs * q.na * q.ny * q.nx;
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(LT) void det_obj_kernel(const DetLevels L) {
         const int own = owner[cell];
         const float tobj = (own >= 0 && own < ncand) ? fmaxf(cands[own].iou, 0.f) : 0.f;   // (a stale table can never index out of range)
         float dx;
-        s += bce_logits(p[cell * q.no + 4], tobj, q.obj_pw, &dx);
+        s += bce_focal(p[cell * q.no + 4], tobj, q.obj_pw, q.fl_gamma, &dx);
         float* d = dp + cell * q.no;
         for (int k = 0; k < q.no; ++k) d[k] = 0.f;
         d[4] = dx * obj_coef;
@@ -257,16 +277,25 @@ __global__ __launch_bounds__(LT) void det_scatter_kernel(const DetLevels L) {
 // acc: [nl][4];  out[0] = (lbox + lobj + lcls) * bs, out[1..3] = lbox, lobj, lcls (already multiplied by their gains)
 struct DetMeta { float ncells[5], balance[5]; };
 __global__ void det_finalize_kernel(const float* __restrict__ acc, int nl, DetMeta meta, float h_box, float h_obj,
-                                    float h_cls, int nc, int bs, float* __restrict__ out) {
+                                    float h_cls, int nc, int bs, float* __restrict__ out, float* __restrict__ bal_dev,
+                                    int autobalance, int ssi) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float lbox = 0.f, lobj = 0.f, lcls = 0.f;
+    float nb[5];
     for (int i = 0; i < nl; ++i) {
         const float n = acc[i * 4];
         if (n > 0.f) {
             lbox += acc[i * 4 + 1] / n;
             if (nc > 1) lcls += acc[i * 4 + 2] / (n * (float)nc);
         }
-        lobj += acc[i * 4 + 3] / meta.ncells[i] * meta.balance[i];
+        const float bal = bal_dev ? bal_dev[i] : meta.balance[i];
+        const float obji = acc[i * 4 + 3] / meta.ncells[i];
+        lobj += obji * bal;
+        nb[i] = bal * 0.9999f + 0.0001f / obji;           // loss.py:160 (applied below when autobalance)
+    }
+    if (autobalance && bal_dev) {                         // loss.py:158-164: running rescale, normalised by the stride-16 level
+        const float norm = nb[ssi];
+        for (int i = 0; i < nl; ++i) bal_dev[i] = nb[i] / norm;
     }
     lbox *= h_box; lobj *= h_obj; lcls *= h_cls;
     out[0] = (lbox + lobj + lcls) * (float)bs;
@@ -559,8 +588,23 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
                             const float* balance, float h_box, float h_obj, float h_cls, float cls_pw, float obj_pw,
                             float anchor_t, float cp, float cn, float* out, void* workspace, int64_t workspace_bytes,
                             void* stream) {
-    DSN_CHECK_ARG(p && dp && ny && nx && out && workspace && anchors && balance && nl > 0 && nl <= 5 && na > 0 && na <= 3,
+    return dsn_det_loss_opt(p, dp, ny, nx, nl, bs, na, nc, targets, nt, anchors, balance, h_box, h_obj, h_cls, cls_pw, obj_pw,
+                            anchor_t, cp, cn, 0.f, nullptr, 0, 0, out, workspace, workspace_bytes, stream);
+}
+
+// The same with the options scripts/train.py leaves off: fl_gamma > 0 wraps both BCE criteria in the reference's FocalLoss
+// (loss.py:106-110); balance_dev != NULL: [nl] DEVICE floats used instead of `balance` (which may then be NULL), and with
+// autobalance != 0 updated after the losses are formed (loss.py:158-164; ssi: index of the stride-16 level, loss.py:113) -- the
+// reference calls `.item()` per level there; here the state never leaves the device, so the step stays capturable.
+extern "C" int dsn_det_loss_opt(const float* const* p, float* const* dp, const int32_t* ny, const int32_t* nx, int32_t nl,
+                                int32_t bs, int32_t na, int32_t nc, const float* targets, int32_t nt, const float* anchors,
+                                const float* balance, float h_box, float h_obj, float h_cls, float cls_pw, float obj_pw,
+                                float anchor_t, float cp, float cn, float fl_gamma, float* balance_dev, int32_t autobalance,
+                                int32_t ssi, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    DSN_CHECK_ARG(p && dp && ny && nx && out && workspace && anchors && (balance || balance_dev) && nl > 0 && nl <= 5 && na > 0 &&
+                      na <= 3,
                   "det_loss: bad arguments");
+    DSN_CHECK_ARG(fl_gamma >= 0.f && (!autobalance || (balance_dev && ssi >= 0 && ssi < nl)), "det_loss: bad focal / autobalance options");
     DSN_CHECK_ARG(nc >= 1 && nc <= MAX_NC && bs > 0 && nt >= 0 && (nt == 0 || targets), "det_loss: bad sizes");
     int64_t max_cells = 0;
     for (int i = 0; i < nl; ++i) {
@@ -577,15 +621,15 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
     w += 256;
     DetMeta meta{};
     DetLevels L{};
-    L.nl = nl; L.box_coef = h_box * (float)bs; L.cls_coef = h_cls * (float)bs;
+    L.nl = nl; L.box_coef = h_box * (float)bs; L.cls_coef = h_cls * (float)bs; L.bal_dev = balance_dev;
     int max_ob = 1, max_mb = 1, max_sb = 1, max_cb = 1;
     for (int i = 0; i < nl; ++i) {
         meta.ncells[i] = (float)((int64_t)bs * na * ny[i] * nx[i]);
-        meta.balance[i] = balance[i];
+        meta.balance[i] = balance_dev ? 1.f : balance[i];
         DetLevel& v = L.l[i];
         DetParams& q = v.q;
         q.bs = bs; q.na = na; q.no = no; q.nc = nc; q.ny = ny[i]; q.nx = nx[i]; q.nt = nt;
-        q.anchor_t = anchor_t; q.cls_pw = cls_pw; q.obj_pw = obj_pw; q.cp = cp; q.cn = cn;
+        q.anchor_t = anchor_t; q.cls_pw = cls_pw; q.obj_pw = obj_pw; q.cp = cp; q.cn = cn; q.fl_gamma = fl_gamma;
         for (int k = 0; k < 2 * na; ++k) q.anchors[k] = anchors[i * na * 2 + k];
         v.p = p[i]; v.dp = dp[i]; v.acc = acc + i * 4;
         v.cands = (Cand*)w;                              w += ncand * sizeof(Cand);
@@ -597,7 +641,7 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
         v.mpart = v.partial + 960;                       // 64 floats at the tail of the 1024-float block: MAX_MB*3 = 48
         v.mb = nt > 0 ? lgrid(ncand, MAX_MB) : 0;
         v.sb = nt > 0 ? lgrid(ncand, 64) : 1;
-        v.obj_coef = h_obj * balance[i] * (float)bs / (float)ncell;
+        v.obj_coef = h_obj * (balance_dev ? 1.f : balance[i]) * (float)bs / (float)ncell;
         max_ob = v.ob > max_ob ? v.ob : max_ob;
         max_mb = v.mb > max_mb ? v.mb : max_mb;
         max_sb = v.sb > max_sb ? v.sb : max_sb;
@@ -610,7 +654,8 @@ extern "C" int dsn_det_loss(const float* const* p, float* const* dp, const int32
     hipLaunchKernelGGL(det_obj_kernel, dim3(max_ob, nl), dim3(LT), 0, st, L);
     hipLaunchKernelGGL(det_scatter_kernel, dim3(max_sb, nl), dim3(LT), 0, st, L);
     DSN_LAUNCH_CHECK("det_loss");
-    hipLaunchKernelGGL(det_finalize_kernel, dim3(1), dim3(1), 0, st, acc, nl, meta, h_box, h_obj, h_cls, nc, bs, out);
+    hipLaunchKernelGGL(det_finalize_kernel, dim3(1), dim3(1), 0, st, acc, nl, meta, h_box, h_obj, h_cls, nc, bs, out, balance_dev,
+                       autobalance, ssi);
     DSN_LAUNCH_CHECK("det_loss finalize");
     return DSN_OK;
 }

@@ -1124,9 +1124,12 @@ def pp_stages_bwd(xs, ws, zs, dys, dxs, stats, dgammas, dbetas, dws, act, accumu
 
 
 # ------------------------------------------------------------------------------------------------ losses
-def det_loss(p, targets, anchors_host, balance, h_box, h_obj, h_cls, cls_pw, obj_pw, anchor_t, cp, cn, nc, gain=1.0):
+def det_loss(p, targets, anchors_host, balance, h_box, h_obj, h_cls, cls_pw, obj_pw, anchor_t, cp, cn, nc, gain=1.0,
+             fl_gamma=0.0, balance_dev=None, autobalance=False, ssi=0):
     """p: list of fp32 contiguous [bs,na,ny,nx,5+nc] raw Detect outputs.  Returns (out [4] = {gain*(lbox+lobj+lcls)*bs,
-    gain*lbox, gain*lobj, gain*lcls} on the device, [d out[0] / d p_i])."""
+    gain*lbox, gain*lobj, gain*lcls} on the device, [d out[0] / d p_i]).
+    fl_gamma > 0: focal loss around both BCE criteria (loss.py:106-110).  balance_dev: fp32 [nl] DEVICE tensor used instead of
+    the host list `balance`; autobalance updates it in place (loss.py:158-164, ssi = index of the stride-16 level)."""
     L = _lib.lib()
     nl = len(p)
     for t in p:
@@ -1147,6 +1150,14 @@ def det_loss(p, targets, anchors_host, balance, h_box, h_obj, h_cls, cls_pw, obj
     nbytes = L.dsn_det_loss_workspace_bytes(nl, na, nt, nc, max_cells)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=p[0].device)
     out = torch.empty(4, dtype=torch.float32, device=p[0].device)
+    if fl_gamma > 0 or balance_dev is not None:
+        if balance_dev is not None and (balance_dev.dtype != torch.float32 or balance_dev.numel() < nl or not balance_dev.is_cuda):
+            raise ValueError("det_loss: balance_dev must be a CUDA fp32 tensor of nl elements")
+        _lib.check(L.dsn_det_loss_opt(pp, dpp, ny, nx, nl, bs, na, nc, tg.data_ptr() if nt else None, nt, anc, bal,
+                                      h_box * gain, h_obj * gain, h_cls * gain, cls_pw, obj_pw, anchor_t, cp, cn, float(fl_gamma),
+                                      _p(balance_dev), int(bool(autobalance)), int(ssi), out.data_ptr(), ws.data_ptr(), nbytes,
+                                      stream_ptr()), "det_loss_opt")
+        return out, dp
     _lib.check(L.dsn_det_loss(pp, dpp, ny, nx, nl, bs, na, nc, tg.data_ptr() if nt else None, nt, anc, bal,
                               h_box * gain, h_obj * gain, h_cls * gain, cls_pw, obj_pw, anchor_t, cp, cn, out.data_ptr(),
                               ws.data_ptr(), nbytes, stream_ptr()), "det_loss")

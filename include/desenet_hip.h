@@ -438,6 +438,18 @@ int dsn_det_loss(const float* const* p, float* const* dp, const int32_t* ny, con
                  int32_t na, int32_t nc, const float* targets, int32_t nt, const float* anchors, const float* balance,
                  float h_box, float h_obj, float h_cls, float cls_pw, float obj_pw, float anchor_t, float cp, float cn,
                  float* out, void* workspace, int64_t workspace_bytes, void* stream);
+/* dsn_det_loss with the options scripts/train.py leaves off (core/utils/loss.py:91-168):
+ *   fl_gamma > 0   : both BCE criteria wrapped in FocalLoss (loss.py:36-61,106-110; alpha 0.25, element-wise, then the mean);
+ *   balance_dev    : [nl] DEVICE floats used as the per-level objectness weights instead of the host array `balance` (may be NULL
+ *                    then); with autobalance != 0 they are updated in place after the losses are formed,
+ *                    b_i <- 0.9999 b_i + 0.0001 / mean objectness loss of level i, then all divided by b_ssi (loss.py:158-164; ssi =
+ *                    index of the stride-16 level, loss.py:113).  The reference reads each level's loss back with `.item()`; here
+ *                    the state stays on the device and the step remains graph-capturable. */
+int dsn_det_loss_opt(const float* const* p, float* const* dp, const int32_t* ny, const int32_t* nx, int32_t nl, int32_t bs,
+                     int32_t na, int32_t nc, const float* targets, int32_t nt, const float* anchors, const float* balance,
+                     float h_box, float h_obj, float h_cls, float cls_pw, float obj_pw, float anchor_t, float cp, float cn,
+                     float fl_gamma, float* balance_dev, int32_t autobalance, int32_t ssi, float* out, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 int64_t dsn_seg_ce_workspace_bytes(void);
 int dsn_seg_ce(const float* logits, const int64_t* target, int32_t n, int32_t c, int32_t h, int32_t w,
                int32_t ignore_index, float* out, float* dlogits, void* workspace, int64_t workspace_bytes, void* stream);

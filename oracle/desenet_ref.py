@@ -328,6 +328,31 @@ def forward(cfg, sd, x, training=False, fused=False, keep=None):
     return out, y[-2], saved
 
 
+def forward_augment(cfg, sd, x, fused=False):
+    """Test-time augmentation, yolo.py:331-342 + _descale_pred :358-374 + torch_utils.scale_img :262-272 (scales 1 / .83 / .67,
+    left-right flip on the second, gs = 32).  The reference's own code path raises (it hands `_descale_pred` the (pred, raws)
+    TUPLE that `_forward_once(...)[0]` is once the seg head exists, yolo.py:356); this restates the evident intent -- the
+    upstream-YOLOv5 form on the decoded predictions -- and returns what the reference's return statement would: (cat, None)."""
+    import math
+    img_size = x.shape[-2:]
+    ys = []
+    for si, fi in zip([1, 0.83, 0.67], [None, 3, None]):
+        xi = x.flip(fi) if fi else x
+        if si != 1:
+            h, w = xi.shape[2:]
+            s = (int(h * si), int(w * si))
+            xi = F.interpolate(xi, size=s, mode="bilinear", align_corners=False)
+            hh, ww = [math.ceil(v * si / 32) * 32 for v in (h, w)]
+            xi = F.pad(xi, [0, ww - s[1], 0, hh - s[0]], value=0.447)
+        (pred, _), _, _ = forward(cfg, sd, xi, fused=fused)
+        p = pred.clone()
+        p[..., :4] /= si
+        if fi == 3:
+            p[..., 0] = img_size[1] - p[..., 0]
+        ys.append(p)
+    return torch.cat(ys, 1), None
+
+
 # --------------------------------------------------------------------------------------------------
 # BN folding                                              (torch_utils.py:196-216, yolo.py:409-417)
 # --------------------------------------------------------------------------------------------------

@@ -2,8 +2,10 @@
 
 Restates on PyTorch-CPU fp32 ops (autograd supplies the gradients):
 
-    det_loss      core/utils/loss.py:91-223   ComputeLoss.__call__ / build_targets, fl_gamma = 0, autobalance off,
-                                              label_smoothing 0 (cp=1, cn=0), gr = 1, balance [4, 1, .4]
+    det_loss      core/utils/loss.py:91-223   ComputeLoss.__call__ / build_targets, label_smoothing 0 (cp=1, cn=0), gr = 1,
+                                              balance [4, 1, .4]; options: focal loss (loss.py:36-61,106-110, fl_gamma > 0,
+                                              alpha .25) and autobalance (loss.py:113,158-164) -- pinned by
+                                              tests/golden/loss_opts.npz (tools/gen_golden_loss_opts.py runs the reference)
     ciou          core/utils/metrics.py:202-244  bbox_iou(x1y1x2y2=False, CIoU=True)
     seg_loss      core/utils/loss.py:227-243  plain nn.CrossEntropyLoss(ignore_index=-1), mean
     scale_hyp     scripts/train.py:258-260    box*=3/nl, cls*=nc/80*3/nl, obj*=(imgsz/640)^2*3/nl
@@ -95,11 +97,28 @@ def build_targets(p, targets, anchors, anchor_t):
     return tcls, tbox, indices, anch
 
 
-def det_loss(p, targets, anchors, hyp, nc):
-    """Returns (loss * bs, items[lbox, lobj, lcls]) exactly as ComputeLoss.__call__ (loss.py:117-168)."""
+def _bce(x, t, pw, gamma, alpha=0.25):
+    """nn.BCEWithLogitsLoss(pos_weight) -- mean -- or, for gamma > 0, FocalLoss wrapped around it (loss.py:36-61): the element-wise
+    loss times alpha_factor * (1 - p_t)^gamma, then the mean."""
+    if gamma <= 0:
+        return F.binary_cross_entropy_with_logits(x, t, pos_weight=pw)
+    loss = F.binary_cross_entropy_with_logits(x, t, pos_weight=pw, reduction="none")
+    prob = torch.sigmoid(x)
+    p_t = t * prob + (1 - t) * (1 - prob)
+    alpha_factor = t * alpha + (1 - t) * (1 - alpha)
+    return (loss * alpha_factor * (1.0 - p_t) ** gamma).mean()
+
+
+def det_loss(p, targets, anchors, hyp, nc, balance=None, autobalance=False, ssi=1):
+    """Returns (loss * bs, items[lbox, lobj, lcls]) exactly as ComputeLoss.__call__ (loss.py:117-168).
+    balance: the per-level objectness weights (a LIST: updated in place when autobalance, loss.py:158-164; ssi = index of the
+    stride-16 level, loss.py:113); default the reference's constants for three levels."""
     lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
     tcls, tbox, indices, anch = build_targets(p, targets, anchors, hyp["anchor_t"])
     pw_cls, pw_obj = torch.tensor([hyp["cls_pw"]]), torch.tensor([hyp["obj_pw"]])
+    gamma = float(hyp.get("fl_gamma", 0.0))
+    if balance is None:
+        balance = list(BALANCE)
     for i, pi in enumerate(p):
         b, a, gj, gi = indices[i]
         tobj = torch.zeros_like(pi[..., 0])
@@ -114,8 +133,15 @@ def det_loss(p, targets, anchors, hyp, nc):
             if nc > 1:
                 t = torch.zeros_like(ps[:, 5:])
                 t[range(n), tcls[i]] = 1.0
-                lcls = lcls + F.binary_cross_entropy_with_logits(ps[:, 5:], t, pos_weight=pw_cls)
-        lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 4], tobj, pos_weight=pw_obj) * BALANCE[i]
+                lcls = lcls + _bce(ps[:, 5:], t, pw_cls, gamma)
+        obji = _bce(pi[..., 4], tobj, pw_obj, gamma)
+        lobj = lobj + obji * balance[i]
+        if autobalance:
+            balance[i] = balance[i] * 0.9999 + 0.0001 / obji.detach().item()
+    if autobalance:
+        norm = balance[ssi]
+        for i in range(len(balance)):
+            balance[i] = balance[i] / norm
     lbox, lobj, lcls = lbox * hyp["box"], lobj * hyp["obj"], lcls * hyp["cls"]
     bs = p[0].shape[0]
     return (lbox + lobj + lcls) * bs, torch.cat((lbox, lobj, lcls)).detach()

@@ -540,6 +540,40 @@ def test_nms_bit_exact_vs_golden(ops, case):
         np.testing.assert_array_equal(out[i, :c].cpu().numpy(), g[f"{case}/out{i}"])
 
 
+def test_nms_apriori_labels(ops):
+    """non_max_suppression(labels=...) (general.py:690-697, auto-labelling): per image, rows [box, conf 1, one-hot class] are
+    appended behind the image's own candidates.  Exact selection against the from-spec restatement run on the concatenated rows;
+    images with different label counts (and none) in one batch."""
+    import numpy as np
+    from desenet_amd.core.utils.general import non_max_suppression
+    from oracle import nms_ref
+    rng = np.random.RandomState(11)
+    bs, n, nc = 3, 500, 6
+    p = np.zeros((bs, n, 5 + nc), np.float32)
+    p[..., 0:2] = rng.uniform(0, 320, (bs, n, 2))
+    p[..., 2:4] = rng.uniform(8, 120, (bs, n, 2))
+    p[..., 4] = rng.uniform(0, 1, (bs, n))
+    p[..., 5:] = rng.uniform(0, 1, (bs, n, nc))
+    labels = [np.array([[2, 100, 120, 40, 50], [5, 30, 40, 20, 20], [2, 102, 121, 41, 49]], np.float32),      # class, xywh
+              np.zeros((0, 5), np.float32),
+              np.array([[0, 200, 210, 80, 60]], np.float32)]
+    for multi in (False, True):
+        got = non_max_suppression(torch.from_numpy(p).cuda(), 0.3, 0.5, multi_label=multi, labels=[torch.from_numpy(l) for l in labels],
+                                  max_det=300)
+        for xi in range(bs):
+            l = labels[xi]
+            v = np.zeros((len(l), 5 + nc), np.float32)
+            if len(l):
+                v[:, :4] = l[:, 1:5]
+                v[:, 4] = 1.0
+                v[np.arange(len(l)), l[:, 0].astype(int) + 5] = 1.0
+            rows = np.concatenate([p[xi], v], 0)[None]
+            want = nms_ref.non_max_suppression(rows, 0.3, 0.5, multi_label=multi, max_det=300)[0]
+            assert got[xi].shape == want.shape and np.array_equal(got[xi].cpu().numpy(), want), (multi, xi, got[xi].shape, want.shape)
+            if len(l):       # a label row (conf 1.0) outranks every candidate of its class
+                assert float(got[xi][:, 4].max()) == 1.0
+
+
 def test_nms_vs_oracle_random_large(ops):
     """25200 x 6 candidates at the val setting (conf .001, multi-label): exercises the >8192-key sort and the 30000 cap."""
     from oracle import nms_ref

@@ -144,3 +144,33 @@ def test_seg_ce_fused_with_the_x8_bilinear(dtype, tol, n, h, w):
     assert float(ops.padded_view(dl)[:, 2:].abs().max()) == 0.0, "row padding of the gradient must be zero"
     out2, dl2 = ops.seg_ce_up(lg, tgt, (H, W), -1)                 # the accumulator workspace was restored to zero
     assert rel_err(dl2.float().cpu(), dl.float().cpu()) < tol and float(out2[0]) == float(out[0])     # (fp32 atomics: order varies)
+
+
+@pytest.mark.parametrize("tag", ["focal", "focal_pw", "auto", "focal_auto"])
+def test_det_loss_focal_and_autobalance_vs_reference_golden(tag):
+    """The options of ComputeLoss that scripts/train.py leaves off (loss.py:106-113,158-164) on the HIP kernels, against vectors the
+    REFERENCE produced (tools/gen_golden_loss_opts.py): three consecutive calls -- with autobalance the per-level weights are state,
+    kept on the device here -- losses 1e-4, gradients 1e-3, balance 1e-5."""
+    import numpy as np
+    from desenet_amd.core.utils.loss import ComputeLoss
+    from tests.util import golden
+    g = golden("loss_opts")
+    box, obj, cls, cls_pw, obj_pw, anchor_t, gamma, auto = [float(v) for v in g[f"{tag}/hyp"]]
+    hyp = dict(box=box, obj=obj, cls=cls, cls_pw=cls_pw, obj_pw=obj_pw, anchor_t=anchor_t, fl_gamma=gamma, label_smoothing=0.0)
+
+    class Det(_Det):
+        stride = torch.tensor([8., 16., 32.])
+
+    m = _Model(hyp)
+    m.model = [Det()]
+    cl = ComputeLoss(m, autobalance=bool(auto))
+    det_t = torch.from_numpy(g[f"{tag}/targets"]).cuda()
+    for step in range(3):
+        pd = [torch.from_numpy(g[f"{tag}/{step}/p{i}"]).cuda().requires_grad_(True) for i in range(3)]
+        loss, it = cl(pd, det_t)
+        loss.sum().backward()
+        assert_close(loss.cpu(), g[f"{tag}/{step}/loss"], 1e-4, "det loss")
+        assert_close(it.cpu(), g[f"{tag}/{step}/items"], 1e-4, "loss items")
+        for i in range(3):
+            assert_close(pd[i].grad.cpu(), g[f"{tag}/{step}/dp{i}"], 1e-3, f"d det_loss / d raw {i}")
+        assert np.allclose(cl.balance, g[f"{tag}/{step}/balance"], rtol=1e-5, atol=0), (cl.balance, g[f"{tag}/{step}/balance"])

@@ -156,6 +156,25 @@ def test_config2_at_its_own_batch_fused_fp32_vs_oracle(net):
     assert kept > 0
 
 
+def test_augmented_inference_vs_oracle(net):
+    """Model.forward(augment=True) (yolo.py:331-342): three scales, one flip, de-scaled predictions concatenated -- against the
+    oracle's restatement on the same seeded image, 1e-3 per tensor.  (The reference's own TTA path raises once the seg head
+    exists; see Model._forward_augment.)"""
+    from oracle import desenet_ref as R
+    _, m = net
+    cfg = load_cfg()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = synth_images(1, (96, 160), 41)
+    with torch.no_grad():
+        ref, none_ref = R.forward_augment(cfg, sd, x)
+        m.eval()
+        out, none_hip = m(x.cuda(), augment=True)
+    assert none_ref is None and none_hip is None
+    n1 = 3 * (12 * 20 + 6 * 10 + 3 * 5)
+    assert tuple(out.shape) == tuple(ref.shape) and out.shape[1] > 2 * n1
+    assert_close(out.cpu(), ref, 1e-3, "augmented pred")
+
+
 def _train_step(dsn, m, bs, size, seed, dtype):
     import copy
     from desenet_amd.core.utils.loss import ComputeLoss, SegmentationLosses

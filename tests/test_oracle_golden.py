@@ -250,3 +250,26 @@ def test_nms_strict_threshold_and_ties():
     assert nms_ref.nms_greedy(b, s, thr).tolist() == [0, 1]      # IoU(0,1)=1/3 not > thr; box 2 overlaps 0 at 0.6
     assert nms_ref.nms_greedy(b, s, 0.7).tolist() == [0, 1, 2]
     assert nms_ref.nms_greedy(b[:0], s[:0], 0.5).tolist() == []
+
+
+@pytest.mark.parametrize("tag", ["focal", "focal_pw", "auto", "focal_auto"])
+def test_det_loss_options_vs_reference(tag):
+    """Focal loss (loss.py:36-61,106-110) and autobalance (loss.py:113,158-164) of the oracle's det_loss against the reference's
+    ComputeLoss run by tools/gen_golden_loss_opts.py: three consecutive calls (the balance list is state), losses 1e-5, gradients
+    1e-4, balance 1e-6."""
+    g = golden("loss_opts")
+    box, obj, cls, cls_pw, obj_pw, anchor_t, gamma, auto = [float(v) for v in g[f"{tag}/hyp"]]
+    hyp = dict(box=box, obj=obj, cls=cls, cls_pw=cls_pw, obj_pw=obj_pw, anchor_t=anchor_t, fl_gamma=gamma)
+    anchors = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]).float().view(3, 3, 2) \
+        / torch.tensor([8., 16., 32.]).view(3, 1, 1)
+    det_t = torch.from_numpy(g[f"{tag}/targets"])
+    balance = [4.0, 1.0, 0.4]
+    for step in range(3):
+        p = [torch.from_numpy(g[f"{tag}/{step}/p{i}"]).clone().requires_grad_(True) for i in range(3)]
+        loss, items = loss_ref.det_loss(p, det_t, anchors, hyp, 6, balance=balance, autobalance=bool(auto), ssi=1)
+        loss.sum().backward()
+        assert_close(loss.detach(), g[f"{tag}/{step}/loss"], 1e-5, "loss")
+        assert_close(items, g[f"{tag}/{step}/items"], 1e-5, "items")
+        for i in range(3):
+            assert_close(p[i].grad, g[f"{tag}/{step}/dp{i}"], 1e-4, f"dp{i}")
+        assert np.allclose(balance, g[f"{tag}/{step}/balance"], rtol=1e-6, atol=0)
