@@ -792,6 +792,222 @@ __global__ __launch_bounds__(256, 2) void wgrad128_kernel(const bf16_t* __restri
     wgrad_body128<PK>(x, dy, out, g, blockIdx.x);
 }
 
+// ---- ping-pong "row" kernel (kind 5; bf16, 3x3 / stride 1 / pad 1 / dilation 1, same-size maps) --------------------------------
+// The per-tap 128 x 128 kernel above stages 16 KB of operands per 64 MFMAs of the block: at the MFMA rate that is 64 B per clock
+// and CU out of L2 -- it runs at the aggregate L2 bandwidth (645 TFLOP/s = 26 % of the bf16 rate on config 5), not on the matrix
+// cores.  Here a block owns ONE KERNEL ROW (ky; the three taps kx = 0, 1, 2) of a 128 (co) x 128 (ci) tile over a range of
+// 16 x 16-pixel patches: per k-step (2 patch rows x 16 columns = 32 pixels) it stages the dy rows once (8 KB) and the x rows of
+// that kernel row WITH their two halo columns (2 x 18 pixels, 9 KB) and the three taps read the same x tile at pixel offsets
+// kx = 0, 1, 2 -- 17 KB per 384 MFMAs, 22 B per clock and CU at the full MFMA rate.  Structure as conv_pp.hip: 512 threads, two
+// wave groups staggered by one barrier (one group reads fragments and issues LDS-DMA while the other runs its 24 MFMAs), a ring of
+// six 20 KB stages filled by LDS-DMA four k-steps ahead, counted s_waitcnt vmcnt (never 0 in the loop), raw s_barrier.
+//   wave (group g, wq): co half hc = wq & 1 (64 channels), ci quarter qc = 2 g + (wq >> 1) (32 channels), all three taps:
+//   3 x 4 x 2 accumulator tiles = 96 registers; per k-step 4 A fragments (dy, shared by the taps) + 3 x 2 B fragments (x).
+//   Operands are pixel-major in LDS ([pixel][128 channels] = 256-byte rows) and transposed on the way out (ds_read_b64_tr_b16: per
+//   16-lane group 4 pixels x 16 channels); the 32-byte channel group g of pixel slot s sits at g ^ f(s), f(s) = (s & 3) | ((s >> 3)
+//   & 1) << 2: the eight pixel rows a 32-lane half reads ({b .. b+3} and {b+8 .. b+11} for every base b, i.e. for every tap offset)
+//   get eight different groups -- conflict-free.  LDS-DMA writes lane-linearly, so the swizzle is applied to the SOURCE slot.
+//   Borders: dy / x pixels outside the image (ragged patches, the halo columns and rows of the zero padding) and channels beyond
+//   Co / Ci are out-of-range DMA lanes = zeros.
+constexpr int WPP_STAGE = 32 * 256 + 48 * 256;       // dy tile + x tile (48 pixel slots, 36 used) = 20480 B
+constexpr int WPP_R = 6, WPP_D = 4;                   // ring stages, prefetch distance (a stage is refilled >= 2 phases after its read)
+constexpr int WPP_LDS = WPP_R * WPP_STAGE;            // 122880 B
+
+__device__ __forceinline__ int wpp_f(int s) { return (s & 3) | (((s >> 3) & 1) << 2); }
+template <int N> __device__ __forceinline__ void wpp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ out,
+                                              const WGeom& g, int bid, unsigned char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wq = wave & 3;
+    const int hc = wq & 1, qc = 2 * grp + (wq >> 1);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int taps = 9;
+    const int tci = bid % g.tiles_ci; bid /= g.tiles_ci;
+    const int tco = bid % g.tiles_co; bid /= g.tiles_co;
+    const int ky = bid % 3;
+    const int split = bid / 3;
+    const int co0 = tco * 128, ci0 = tci * 128;
+    const int pb = split * g.ppb;                                   // patches [pb, pe) of the N * npy * npx list
+    const int pe = (pb + g.ppb < g.P) ? pb + g.ppb : g.P;
+    const int T = 8 * (pe - pb);                                    // k-steps
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.dy_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+
+    // ---- DMA cursor: the patch the prefetch is in (it runs WPP_D k-steps ahead of the compute) -----------------------------------
+    // lane -> (pixel slot, 16-byte slot v): dy instruction `wave` covers pixels 4 wave .. + 4; x instructions wave (and wave + 8 for
+    // group 0) cover pixel slots 4 t .. + 4 of the 2 x 18 tile (slots >= 36: padding, always out of range)
+    const int v = lane & 15;
+    const int ka = 4 * wave + (lane >> 4);                           // dy pixel of the k-step: row ka >> 4, column ka & 15
+    const int lsa = ((((v >> 1) ^ wpp_f(ka)) << 1) | (v & 1)) * 8;   // logical channel offset this lane fetches
+    int sb[2], lsb[2], xrw[2], xcl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        sb[u] = 4 * (wave + 8 * u) + (lane >> 4);
+        lsb[u] = ((((v >> 1) ^ wpp_f(sb[u])) << 1) | (v & 1)) * 8;
+        xrw[u] = sb[u] / 18;
+        xcl[u] = sb[u] - xrw[u] * 18;
+    }
+    const uint32_t arow = (uint32_t)(2 * g.Wo * (int)g.yld) * 2u, brow = (uint32_t)(2 * g.Wi * (int)g.xld) * 2u;   // two image rows
+    // (validity is a flag of its own: the x offset of image 0's row -1 is a NEGATIVE number wrapped to 32 bits -- it becomes valid
+    //  once hk * brow is added -- and one such value coincides with the out-of-range sentinel)
+    uint32_t a_off = 0, b_off[2] = {0, 0};
+    bool a_ok = false, b_ok[2] = {false, false};
+    int a_ylim = 0, b_y[2] = {0, 0};
+    auto cursor = [&](int patch) {                                  // per-lane source offsets of k-step 0 of `patch`
+        a_ok = false; b_ok[0] = false; b_ok[1] = false;
+        if (patch >= pe) return;
+        const int per = g.npy * g.npx;
+        const int n = patch / per, rem = patch - n * per;
+        const int y0 = (rem / g.npx) * 16, x0 = (rem % g.npx) * 16;
+        const int ya = y0 + (ka >> 4), xa = x0 + (ka & 15);
+        a_ylim = g.Ho - ya;
+        a_ok = xa < g.Wo && co0 + lsa < g.Co;
+        a_off = (uint32_t)(((n * g.Ho + ya) * g.Wo + xa) * (int)g.yld + co0 + lsa) * 2u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int yb = y0 + xrw[u] + ky - 1, xb = x0 + xcl[u] - 1;
+            b_y[u] = yb;
+            b_ok[u] = sb[u] < 36 && (unsigned)xb < (unsigned)g.Wi && ci0 + lsb[u] < g.CiLoad;
+            b_off[u] = (uint32_t)(((n * g.Hi + yb) * g.Wi + xb) * (int)g.xld + ci0 + lsb[u]) * 2u;          // (yb = -1: wraps; rows are masked below)
+        }
+    };
+    auto issue = [&](int hk, int slot) {                            // LDS-DMA of k-step hk of the cursor's patch into ring stage `slot`
+        unsigned char* st = smem + slot * WPP_STAGE;
+        const uint32_t oa = (a_ok && 2 * hk < a_ylim) ? a_off + (uint32_t)hk * arow : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(st + wave * 1024), 16, oa, 0, 0, 0);
+        const uint32_t o0 = (b_ok[0] && (unsigned)(b_y[0] + 2 * hk) < (unsigned)g.Hi) ? b_off[0] + (uint32_t)hk * brow : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + wave * 1024), 16, o0, 0, 0, 0);
+        if (grp == 0) {
+            const uint32_t o1 = (b_ok[1] && (unsigned)(b_y[1] + 2 * hk) < (unsigned)g.Hi) ? b_off[1] + (uint32_t)hk * brow : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + (wave + 8) * 1024), 16, o1, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses (stage-relative) -----------------------------------------------------------------------------------
+    const int q = fr >> 2, pp = fr & 3;
+    int a_addr[4], b_addr[3][2][2];                                 // A: co block i; B: tap kx, k half (pixels +0 / +4), ci block jn
+    {
+        const int k = 8 * fg + q;                                   // pixel of the lower half of the fragment (upper: + 4, same f)
+        const int f = wpp_f(k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_addr[i] = k * 256 + (((hc * 4 + i) ^ f) << 5) + pp * 8;
+        const int s0 = (fg >> 1) * 18 + 8 * (fg & 1) + q;          // x pixel slot of pixel k at tap 0
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = s0 + kx + 4 * h;
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) b_addr[kx][h][jn] = 8192 + s * 256 + (((qc * 2 + jn) ^ wpp_f(s)) << 5) + pp * 8;
+            }
+    }
+    f32x4 acc[3][4][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[kx][i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto tr2 = [&](const unsigned char* p, bool second_a) -> bf16x8 {     // two transposing reads: pixels +0..3 and +4..7
+        (void)second_a;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 256));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    // ---- prologue: k-steps 0 .. D-1 in flight, k-step 0 landed -----------------------------------------------------------------------
+    cursor(pb);
+#pragma unroll
+    for (int j = 0; j < WPP_D; ++j) issue(j, j);
+    if (grp == 0) wpp_wait<3 * (WPP_D - 1)>(); else wpp_wait<2 * (WPP_D - 1)>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int sc = 0;                                                     // ring stage of the k-step being computed
+    for (int pi = pb; pi < pe; ++pi) {
+#pragma unroll
+        for (int hk = 0; hk < 8; ++hk) {
+            const unsigned char* st = smem + sc * WPP_STAGE;
+            // ---- load segment: fragments of this k-step, then the prefetch of k-step + D ---------------------------------------------
+            bf16x8 a[4], b[3][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr2(st + a_addr[i], true);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + b_addr[kx][0][jn]));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + b_addr[kx][1][jn]));
+                    b[kx][jn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            // k-step + 1 landed: the DMAs of k-steps + 2, + 3 (issued in the two phases before this one) may stay in flight
+            if (grp == 0) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>();
+            if (hk == 8 - WPP_D) cursor(pi + 1);                     // the prefetch enters the next patch (all lanes OOB past the range)
+            int sd = sc + WPP_D;
+            if (sd >= WPP_R) sd -= WPP_R;
+            issue((hk + WPP_D) & 7, sd);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA segment ----------------------------------------------------------------------------------------------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        acc[kx][i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[kx][jn], acc[kx][i][jn], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            sc = sc + 1 == WPP_R ? 0 : sc + 1;
+        }
+    }
+    if (grp == 0) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)T;
+    // ---- epilogue: the three taps of this kernel row, straight from the accumulators (row = co, column = ci of each 16 x 16 tile)
+    float* o = out + (g.S > 1 ? (int64_t)split * g.Co * taps * g.Cip : 0);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int tap = ky * 3 + kx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + hc * 64 + i * 16 + fg * 4 + e;
+                    const int ci = ci0 + qc * 32 + jn * 16 + fr;
+                    if (co < g.Co && ci < g.Ci) {
+                        float* d = (g.S == 1 && g.oihw) ? o + ((int64_t)co * g.Ci + ci) * taps + tap
+                                                        : o + ((int64_t)co * taps + tap) * g.Cip + ci;
+                        float val = acc[kx][i][jn][e];
+                        if (g.S == 1 && g.accumulate) val += *d;
+                        *d = val;
+                    }
+                }
+    }
+}
+__global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          float* __restrict__ out, const WGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wpp_smem[];
+    wgrad_pp_body(x, dy, out, g, blockIdx.x, wpp_smem);
+}
+
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                             float* __restrict__ out, const WGeom g) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[2][HALO_A];
@@ -817,10 +1033,11 @@ struct WJob {
     float* out;            // slabs (S > 1) or dw
     float* dw;
     WGeom g;
-    int32_t kind;          // 0: per-tap blocks (64 x 64 tiles), 1: all-taps blocks, 3: per-tap blocks with 128 x 128 tiles, 4: halo-tile all-taps
+    int32_t kind;          // 0: per-tap blocks (64 x 64 tiles), 1: all-taps blocks, 3: per-tap blocks with 128 x 128 tiles, 4: halo-tile all-taps,
+                           // 5: ping-pong kernel-row blocks (128 x 128 x 3 taps)
     int32_t dtype;
-    int32_t blocks[5];     // blocks of this job in the per-tap / all-taps / reduce / 128-tile / halo-tile launch
-    int32_t start[5];      // first block of this job in each launch
+    int32_t blocks[6];     // blocks of this job in the per-tap / all-taps / reduce / 128-tile / halo-tile / ping-pong launch
+    int32_t start[6];      // first block of this job in each launch
     int64_t n_out;
     double flops, bytes;
 };
@@ -868,6 +1085,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_grouped_kernel(const WJob* 
     const int b = xcd_local(blockIdx.x - jobs[l].start[4], jobs[l].blocks[4]);
     if (g.stride == 2) wgrad_halo_body<2>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, b, sA, sB);
     else wgrad_halo_body<1>((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g, b, sA, sB);
+}
+__global__ __launch_bounds__(512, 2) void wgrad_pp_grouped_kernel(const WJob* __restrict__ jobs, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wpp_smem[];
+    const int l = find_job(jobs, n, blockIdx.x, 5);
+    const WGeom g = jobs[l].g;
+    wgrad_pp_body((const bf16_t*)jobs[l].x, (const bf16_t*)jobs[l].dy, jobs[l].out, g,
+                  xcd_local(blockIdx.x - jobs[l].start[5], jobs[l].blocks[5]), wpp_smem);
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WJob* __restrict__ jobs, int n) {
     __shared__ __attribute__((aligned(16))) float part[4][RED_W + 4];
@@ -926,6 +1150,42 @@ inline bool use_tile128(const dsn_tensor* x, const dsn_tensor* dy, const dsn_con
     return mode == 1 || npix(dy) >= minpx;
 }
 
+// ping-pong kernel-row kernel (kind 5): bf16, same-size 3x3 / stride 1 / pad 1 / dilation 1, whole 128-channel tiles on both sides,
+// 16 x 16 patches that cover >= 80 % of the map (DSN_WGRAD_PP: 0 never, 1 default, 2 every eligible layer)
+int g_wgrad_pp_mode = getenv("DSN_WGRAD_PP") ? atoi(getenv("DSN_WGRAD_PP")) : 1;
+inline bool use_pp(const dsn_tensor* x, const dsn_tensor* dy, const dsn_conv_params* p, int32_t oihw, int32_t ci_pad) {
+    const int mode = g_wgrad_pp_mode;
+    static const int minpx = [] { const char* e = getenv("DSN_WGRAD_PP_MINPX"); return e ? atoi(e) : 12800; }();
+    if (mode == 0 || x->dtype != DSN_BF16) return false;
+    if (p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != 1 || p->dil != 1 || x->h != dy->h || x->w != dy->w) return false;
+    (void)oihw;
+    if (dy->c % 128 != 0 || x->c % 128 != 0 || ci_pad != x->c) return false;
+    const bool vl = (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) && ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0) &&
+                    ((npix(x) - 1) * x->ldc + x->c) * 2 < (1ll << 31) && ((npix(dy) - 1) * dy->ldc + dy->c) * 2 < (1ll << 31);
+    if (!vl) return false;
+    if (mode == 2) return true;
+    const int ty = (dy->h + 15) / 16, tx = (dy->w + 15) / 16;
+    if ((double)dy->h * dy->w / ((double)ty * tx * 256.0) < 0.8 || npix(dy) < minpx) return false;
+    // Measured (MI355X, whole step, alternated runs): config 5 (thirteen 128 -> 128 @160, fifteen 256 -> 256 @80, 512 <-> 256 @160
+    // layers share the launch) 18.60 -> 18.47 ms; config 3, where FFM's 256 -> 128 @80 would be the ONLY job of this launch (96
+    // blocks on 256 CUs while the launch it left loses its largest job): 3.91 -> 3.98 ms.  So: layers with >= 256 output channels or
+    // >= 100k output pixels -- config 5's, not config 3's.
+    static const int big_px = [] { const char* e = getenv("DSN_WGRAD_PP_BIGPX"); return e ? atoi(e) : 100000; }();
+    return dy->c >= 256 || npix(dy) >= big_px;
+}
+// patches per block of the ping-pong kernel: about DSN_WGRAD_BLOCKSPP blocks per job (3 kernel rows x tiles x splits)
+inline void pp_split(const dsn_tensor* x, const dsn_tensor* dy, int* S, int* ppb, int* P) {
+    static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKSPP"); return e ? atoi(e) : 96; }();
+    const int np = dy->n * ((dy->h + 15) / 16) * ((dy->w + 15) / 16);
+    const int base = 3 * (dy->c / 128) * (x->c / 128);
+    int s = (target + base - 1) / base;
+    if (s > np) s = np;
+    if (s < 1) s = 1;
+    *ppb = (np + s - 1) / s;
+    *S = (np + *ppb - 1) / *ppb;
+    *P = np;
+}
+
 inline int choose_split(const WGeom& g, bool alltaps = false, bool t128 = false) {
     const int64_t base = (int64_t)g.tiles_co * g.tiles_ci * (alltaps ? 1 : g.KH * g.KW);
     static const int target = [] { const char* e = getenv("DSN_WGRAD_BLOCKS"); return e ? atoi(e) : 320; }();
@@ -949,6 +1209,11 @@ inline int choose_split(const WGeom& g, bool alltaps = false, bool t128 = false)
 extern "C" int64_t dsn_conv2d_wgrad_workspace_bytes(const dsn_tensor* x, const dsn_tensor* dy,
                                                     const dsn_conv_params* p, int32_t ci_pad) {
     if (!x || !dy || !p) return 0;
+    if (use_pp(x, dy, p, 1, x->c) && ci_pad == x->c) {
+        int S, ppb, P;
+        pp_split(x, dy, &S, &ppb, &P);
+        return S > 1 ? (int64_t)S * dy->c * 9 * x->c * sizeof(float) : 0;
+    }
     WGeom g{};
     g.P = (int32_t)npix(dy);
     const bool hl = use_halo(x, dy, p);
@@ -984,9 +1249,10 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.Co = dy->c; g.Ci = x->c; g.Cip = ci_pad;
     g.KH = p->kh; g.KW = p->kw; g.stride = p->stride; g.pad = p->pad; g.dil = p->dil;
     g.yld = dy->ldc; g.xld = x->ldc;
-    const bool halo = use_halo(x, dy, p) && (!oihw || ci_pad >= 0);
-    const bool alltaps = !halo && use_alltaps(x, dy, p);
-    bool t128 = use_tile128(x, dy, p, alltaps || halo);
+    const bool pp = use_pp(x, dy, p, oihw, ci_pad);
+    const bool halo = !pp && use_halo(x, dy, p) && (!oihw || ci_pad >= 0);
+    const bool alltaps = !pp && !halo && use_alltaps(x, dy, p);
+    bool t128 = !pp && use_tile128(x, dy, p, alltaps || halo);
     {   // (the 128-tile kernel exists for the 16-byte paths only: the same conditions as *vec_out below)
         const int es0 = 2;
         t128 = t128 && (dy->ldc % 8 == 0) && (x->ldc % 8 == 0) && ((uintptr_t)x->ptr % 16 == 0) && ((uintptr_t)dy->ptr % 16 == 0) &&
@@ -1003,6 +1269,13 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     const int PK = gpk;       // pixel ranges are multiples of the largest chunk any kernel variant may use
     g.ppb = (((g.P + g.S - 1) / g.S) + PK - 1) / PK * PK;
     g.S = (g.P + g.ppb - 1) / g.ppb;
+    if (pp) {       // the unit of work is a 16 x 16 patch; blocks = kernel rows x 128 x 128 tiles x splits
+        g.tiles_co = g.Co / 128; g.tiles_ci = g.Ci / 128;
+        g.npx = (g.Wo + 15) / 16; g.npy = (g.Ho + 15) / 16;
+        int S, ppb, P;
+        pp_split(x, dy, &S, &ppb, &P);
+        g.S = S; g.ppb = ppb; g.P = P;
+    }
     if (halo) {     // the unit of work is a 4 x 8 patch: P and ppb count patches from here on (flops / bytes below use npix)
         g.npx = (g.Wo + 7) / 8; g.npy = (g.Ho + 3) / 4;
         const int S0 = choose_split(g, true, false);
@@ -1036,9 +1309,9 @@ int make_job(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pa
     g.dy_bytes = (uint32_t)(yb < (1ll << 31) ? yb : 0);
     *job = WJob{};
     job->x = x->ptr; job->dy = dy->ptr; job->out = out; job->dw = dw; job->g = g;
-    job->kind = halo ? 4 : alltaps ? 1 : (t128 ? 3 : 0);
+    job->kind = pp ? 5 : halo ? 4 : alltaps ? 1 : (t128 ? 3 : 0);
     job->dtype = x->dtype;
-    job->blocks[job->kind] = g.tiles_ci * g.tiles_co * ((alltaps || halo) ? 1 : g.KH * g.KW) * g.S;
+    job->blocks[job->kind] = g.tiles_ci * g.tiles_co * (pp ? 3 : (alltaps || halo) ? 1 : g.KH * g.KW) * g.S;
     job->blocks[2] = g.S > 1 ? (int32_t)((n_out + RED_W - 1) / RED_W) : 0;
     job->n_out = n_out;
     job->flops = 2.0 * (double)npix(dy) * g.Co * g.Ci * g.KH * g.KW;
@@ -1054,6 +1327,11 @@ int alltaps_attr_once() {
 }
 
 }  // namespace
+
+extern "C" int dsn_wgrad_pp_mode(int32_t mode) {
+    if (mode >= 0) g_wgrad_pp_mode = mode;
+    return g_wgrad_pp_mode;
+}
 
 extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float* dw, int32_t ci_pad, int32_t oihw,
                                 const dsn_conv_params* p, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -1074,7 +1352,10 @@ extern "C" int dsn_conv2d_wgrad(const dsn_tensor* x, const dsn_tensor* dy, float
     dim3 grid(job.blocks[job.kind]), block(256);
     {
         ProfScope prof(KID_WGRAD + (x->dtype == DSN_BF16 ? 1 : 0), job.flops, job.bytes, st);
-        if (job.kind == 4) {
+        if (job.kind == 5) {
+            DSN_LDS_ATTR(wgrad_pp_kernel, WPP_LDS);
+            hipLaunchKernelGGL(wgrad_pp_kernel, grid, dim3(512), WPP_LDS, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
+        } else if (job.kind == 4) {
             hipLaunchKernelGGL(wgrad_halo_kernel, grid, block, 0, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
         } else if (job.kind == 3) {
             hipLaunchKernelGGL(wgrad128_kernel<32>, grid, block, 0, st, (const bf16_t*)x->ptr, (const bf16_t*)dy->ptr, out, g);
@@ -1139,11 +1420,11 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
     // longest blocks first: a block's life is its pixel range, and the hardware dispatches blocks in index order -- heavy
     // jobs at the end of the grid would leave a tail of a few long blocks on an otherwise drained chip
     std::stable_sort(jobs, jobs + n, [](const WJob& a, const WJob& b) { return a.g.ppb > b.g.ppb; });
-    int64_t start[5] = {0, 0, 0, 0, 0};
+    int64_t start[6] = {0, 0, 0, 0, 0, 0};
     double flops = 0, bytes = 0, rbytes = 0;
     for (int i = 0; i < n; ++i) {
         DSN_CHECK_ARG(jobs[i].dtype == jobs[0].dtype, "conv wgrad plan_finish: mixed dtypes in one queue");
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 6; ++k) {
             jobs[i].start[k] = (int32_t)start[k];
             start[k] += jobs[i].blocks[k];
         }
@@ -1151,17 +1432,17 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
         bytes += jobs[i].bytes;
         if (jobs[i].g.S > 1) rbytes += (double)(jobs[i].g.S + 1) * jobs[i].n_out * 4;
     }
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
         DSN_CHECK_ARG(start[k] < (1ll << 31), "conv wgrad plan_finish: too many blocks");
     launch_out[0] = (double)start[0]; launch_out[1] = (double)start[1]; launch_out[2] = (double)start[2];
     launch_out[3] = (double)jobs[0].dtype; launch_out[4] = flops; launch_out[5] = bytes; launch_out[6] = rbytes;
-    launch_out[7] = 0.0;                    // (reserved: was "some x operand carries deferred-BatchNorm segments")
+    launch_out[7] = (double)start[5];       // grid of the ping-pong kernel-row launch
     launch_out[8] = (double)start[3];       // grid of the 128 x 128-tile launch
     launch_out[9] = (double)start[4];       // grid of the halo-tile all-taps launch
     static const bool dump = getenv("DSN_WGRAD_DUMP") && atoi(getenv("DSN_WGRAD_DUMP"));     // the plan, one line per job (stderr)
     if (dump) {
-        static const char* kinds[5] = {"tap64", "alltaps", "-", "tap128", "halo"};
-        double kb[5] = {0, 0, 0, 0, 0};
+        static const char* kinds[6] = {"tap64", "alltaps", "-", "tap128", "halo", "pprow"};
+        double kb[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < n; ++i) {
             const WGeom& g = jobs[i].g;
             fprintf(stderr, "wgrad job %2d %-7s %4d->%4d k%dx%d s%d out %3dx%3d  S %3d ppb %6d tiles %dx%d blocks %4d  operands %6.1f MB slabs %6.1f MB\n",
@@ -1169,8 +1450,8 @@ extern "C" int dsn_conv2d_wgrad_plan_finish(void* jobs_host, int32_t n, double* 
                     jobs[i].blocks[jobs[i].kind], jobs[i].bytes / 1e6, g.S > 1 ? (double)g.S * jobs[i].n_out * 4 / 1e6 : 0.0);
             kb[jobs[i].kind] += jobs[i].bytes;
         }
-        fprintf(stderr, "wgrad plan: operands by kind: tap64 %.1f MB, tap128 %.1f MB, halo %.1f MB, alltaps %.1f MB\n", kb[0] / 1e6, kb[3] / 1e6,
-                kb[4] / 1e6, kb[1] / 1e6);
+        fprintf(stderr, "wgrad plan: operands by kind: tap64 %.1f MB, tap128 %.1f MB, halo %.1f MB, alltaps %.1f MB, pprow %.1f MB\n", kb[0] / 1e6,
+                kb[3] / 1e6, kb[4] / 1e6, kb[1] / 1e6, kb[5] / 1e6);
     }
     return DSN_OK;
 }
@@ -1184,9 +1465,14 @@ extern "C" int dsn_conv2d_wgrad_run(const void* jobs_dev, int32_t n, const doubl
     hipStream_t st = (hipStream_t)stream;
     const WJob* jobs = (const WJob*)jobs_dev;
     const int g0 = (int)launch[0], g1 = (int)launch[1], g2 = (int)launch[2], dtype = (int)launch[3];
-    const int g3 = (int)launch[8], g4 = (int)launch[9];
+    const int g3 = (int)launch[8], g4 = (int)launch[9], g5 = (int)launch[7];
     {
         ProfScope prof(KID_WGRAD + (dtype == DSN_BF16 ? 1 : 0), launch[4], launch[5], st);
+        if (g5 > 0) {      // (first: its blocks are the longest)
+            DSN_CHECK_ARG(dtype == DSN_BF16, "conv wgrad run: ping-pong jobs are bf16 only");
+            DSN_LDS_ATTR(wgrad_pp_grouped_kernel, WPP_LDS);
+            hipLaunchKernelGGL(wgrad_pp_grouped_kernel, dim3(g5), dim3(512), WPP_LDS, st, jobs, n);
+        }
         if (g0 > 0) {
             static const int gpk = [] { const char* e = getenv("DSN_WGRAD_GPK"); return (e && atoi(e) == 64) ? 64 : 32; }();
             if (dtype == DSN_F32)

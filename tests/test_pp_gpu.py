@@ -195,3 +195,79 @@ def test_production_grids_three_launches_each():
                 assert e1 < 2e-2 and e2 < 2e-2, ((n, ci, h, w, co), rep, e1, e2)
     finally:
         desenet_amd.set_compute_dtype(torch.float32)
+
+
+WGRAD_SHAPES = [  # n, ci, co, h, w
+    (2, 128, 128, 32, 32),
+    (1, 256, 128, 48, 40),        # ragged columns: 40 = 2 * 16 + 8
+    (3, 128, 256, 19, 35),        # ragged both ways
+    (2, 128, 128, 16, 16),        # one patch per image
+    (1, 384, 128, 33, 17),        # three ci tiles
+]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", WGRAD_SHAPES)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_wgrad_kernel_row_ping_pong_vs_aten_and_the_other_kernels(n, ci, co, h, w, accumulate):
+    """wgrad.hip kind 5 (a block = one kernel row x 128 x 128 tile over a range of 16 x 16 patches; the three taps share the staged
+    x rows): single-layer and queued launches against ATen on the CPU (2e-2, bf16 operands) and against the kernels it replaces
+    (same products, fp32 summation order differs: 1e-4), OIHW output with and without accumulation, split-K slabs."""
+    import desenet_amd
+    from desenet_amd import _lib, hip_ops as ops
+    dt = torch.bfloat16
+    desenet_amd.set_compute_dtype(dt)
+    L = _lib.lib()
+    try:
+        x, gy = _rand((n, ci, h, w), 1), _rand((n, co, h, w), 2)
+        q = lambda t: t.to(dt).float().cpu()
+        wq = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        F.conv2d(q(x), wq, None, 1, 1).backward(q(gy))
+        base = _rand((co, ci, 3, 3), 3)
+        want = wq.grad + (base.cpu() if accumulate else 0)
+        xd, gd = ops.as_act(x.to(dt)), ops.as_act(gy.to(dt))
+        p = ops.conv_params(3, 1, 1, 1, accumulate=accumulate)
+        got = {}
+        for mode in (2, 0):
+            L.dsn_wgrad_pp_mode(mode)
+            g1 = base.clone() if accumulate else torch.zeros_like(base)
+            ops.conv2d_wgrad(xd, gd, g1, ci, p, oihw=True)
+            queue = ops.WgradQueue(torch.device("cuda", torch.cuda.current_device()))
+            g2 = base.clone() if accumulate else torch.zeros_like(base)
+            ops.conv2d_wgrad(xd, gd, g2, ci, p, oihw=True, queue=queue)
+            assert queue.n == 1
+            queue.flush()
+            torch.cuda.synchronize()
+            got[mode] = (g1, g2)
+        for g in got[2]:
+            e = float((g.cpu() - want).abs().max() / want.abs().max())
+            assert e < 2e-2, e
+        scale = float(got[0][0].abs().max())
+        assert float((got[2][0] - got[0][0]).abs().max()) <= 1e-4 * scale
+        assert float((got[2][1] - got[2][0]).abs().max()) <= 1e-5 * scale       # queued == single-layer (same kernel, same split)
+    finally:
+        L.dsn_wgrad_pp_mode(1)
+        desenet_amd.set_compute_dtype(torch.float32)
+
+
+def test_wgrad_kernel_row_production_shapes():
+    """Config 3 / config 5 layer shapes under the default selection, three launches each (several resident-block generations)."""
+    import desenet_amd
+    from desenet_amd import hip_ops as ops
+    dt = torch.bfloat16
+    desenet_amd.set_compute_dtype(dt)
+    try:
+        g = torch.Generator().manual_seed(7)
+        q = lambda t: t.to(dt).float()
+        for (n, ci, h, w, co) in [(8, 256, 80, 80, 128), (4, 128, 160, 160, 128), (4, 256, 80, 80, 256)]:
+            x = torch.randn((n, ci, h, w), generator=g)
+            gy = torch.randn((n, co, h, w), generator=g)
+            wq = torch.zeros(co, ci, 3, 3, requires_grad=True)
+            F.conv2d(q(x), wq, None, 1, 1).backward(q(gy))
+            xd, gd = ops.as_act(x.cuda().to(dt)), ops.as_act(gy.cuda().to(dt))
+            for rep in range(3):
+                gw = torch.zeros((co, ci, 3, 3), device="cuda")
+                ops.conv2d_wgrad(xd, gd, gw, ci, ops.conv_params(3, 1, 1, 1), oihw=True)
+                e = float((gw.cpu() - wq.grad).abs().max() / wq.grad.abs().max())
+                assert e < 2e-2, ((n, ci, h, w, co), rep, e)
+    finally:
+        desenet_amd.set_compute_dtype(torch.float32)
