@@ -560,7 +560,7 @@ int launch_pp(const dsn_tensor* s, const void* w, const float* bias, const dsn_t
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
     const double elems = (double)g.N * g.H * g.W * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(br)) +
                          9.0 * g.Cs * g.Cd;
-    const ProfConv pc(TWO ? "conv3x3_pp_kernel/2" : "conv3x3_pp_kernel", true, 256, BN, g.flip != 0, 3, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
+    const ProfConv pc(TWO ? "conv3x3_pp2_kernel" : "conv3x3_pp_kernel", true, 256, BN, g.flip != 0, 3, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
     ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.Cd * 9.0 * g.Cs, elems * 2, st);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), LDS, st, (const bf16_t*)s->ptr, (const bf16_t*)w, bias,
                        r ? (const bf16_t*)r->ptr : nullptr, (bf16_t*)d->ptr, fin, g, br ? *br : BnRed{});
