@@ -179,6 +179,10 @@ template <int BN, bool TWO, int MH>
 __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                         const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi);
+#ifdef DSN_PP_STAMP
+__device__ unsigned long long pp_stamp_buf[6 * 4096];
+#endif
+
 template <int BN, bool TWO, int MH>
 __device__ __forceinline__ void conv3x3_pp_epilogue(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                    const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
@@ -219,6 +223,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
     const int n = tmi / tiles_img, trem = tmi - n * tiles_img;
     const int y0 = (trem / g.tiles_x) * PT, x0 = (trem % g.tiles_x) * PT;
     const int n0 = tn * BN;
+#ifdef DSN_PP_STAMP
+    const unsigned long long st_re = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
@@ -301,6 +308,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         __builtin_amdgcn_sched_barrier(0);
     }
 
+#ifdef DSN_PP_STAMP      // diagnostic build only (tools/exp/pp_clock.sh): shader clock held inside the main loop (MI355X_MICROARCH.md, DVFS item 6)
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     u32x4 fa[4], fb[4];
     for (int s = 0; s < g.nslab; ++s) {
         const unsigned char* hb = sH + (TWO ? 0 : (s & 1) * HALO_BYTES);
@@ -376,6 +386,15 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef DSN_PP_STAMP
+    if (tid == 0 && blockIdx.x < 4096) {        // (a buffer of its own: no output value depends on the stamps)
+        pp_stamp_buf[6 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_t0;
+        pp_stamp_buf[6 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        pp_stamp_buf[6 * blockIdx.x + 2] = st_re;
+        pp_stamp_buf[6 * blockIdx.x + 3] = st_r0 - st_re;
+    }
+    const unsigned long long st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the out-of-range DMAs past the end of K: zeros into dead stages)
     __syncthreads();
     // (opaque moves: they end the accumulators' main-loop live ranges here, so that the register pressure of the epilogue cannot
@@ -387,6 +406,10 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[m][i][j]));
     conv3x3_pp_epilogue<BN, TWO, MH>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
+#ifdef DSN_PP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 4096) pp_stamp_buf[6 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime() - st_r1;
+#endif
 }
 
 // The epilogue re-derives its lane coordinates from threadIdx.x behind an opaque move: nothing of them stays live across the main
@@ -569,6 +592,14 @@ int launch_pp(const dsn_tensor* s, const void* w, const float* bias, const dsn_t
 }
 
 }  // namespace
+
+#ifdef DSN_PP_STAMP
+// diagnostic build: (shader cycles, 100 MHz ticks) of the main loop of the first n blocks of the last launch
+extern "C" int dsn_pp_stamp_read(unsigned long long* out, int32_t n) {
+    if (n > 4096) n = 4096;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamp_buf), (size_t)n * 6 * sizeof(unsigned long long));
+}
+#endif
 
 // selection mode (environment DSN_PP at load time, dsn_pp_mode() at run time: tests, A/B runs)
 static int g_pp_mode = getenv("DSN_PP") ? atoi(getenv("DSN_PP")) : 1;
