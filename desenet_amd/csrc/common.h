@@ -400,6 +400,10 @@ int dsn_conv3x3_ws_try(const dsn_tensor* s, const void* w, const float* bias, co
 int dsn_conv3x3_pp_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
 
+// conv_pp.hip: the same schedule for 1x1 / stride 1 (256 consecutive pixels x 128 / 256 channels, both operands through the ring)
+int dsn_conv1x1_pp_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
+
 // the gather forms of the 1x1 kernel: 3x3 / stride 2 / pad 1 forward, and its data gradient (2x2 form, depth-to-space store)
 int dsn_conv3x3s2_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                          const dsn_conv_params* p, const BnAcc* finp, void* stream);

@@ -175,7 +175,7 @@ template <int NIT, bool PREF> struct PpRed {
     }
 };
 
-template <int BN, bool TWO, int MH>
+template <int BN, bool TWO, int MH, bool LIN>
 __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                         const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi);
@@ -183,11 +183,11 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
 __device__ unsigned long long pp_stamp_buf[6 * 4096];
 #endif
 
-template <int BN, bool TWO, int MH>
+template <int BN, bool TWO, int MH, bool LIN = false>
 __device__ __forceinline__ void conv3x3_pp_epilogue(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                    const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                    const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi) {
-    conv3x3_pp_epilogue_impl<BN, TWO, MH>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
+    conv3x3_pp_epilogue_impl<BN, TWO, MH, LIN>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
 }
 
 template <int BN, bool FLIP, bool TWO>
@@ -414,7 +414,8 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
 
 // The epilogue re-derives its lane coordinates from threadIdx.x behind an opaque move: nothing of them stays live across the main
 // loop (TWO runs at 128 VGPRs: 64 accumulators + 32 fragment registers leave 32 for everything else).
-template <int BN, bool TWO, int MH>
+// LIN (the 1x1 kernel below): tile row r is pixel 256 tmi + r of the [N H W] pixel list instead of patch pixel (r >> 4, r & 15).
+template <int BN, bool TWO, int MH, bool LIN>
 __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                         const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi) {
@@ -439,23 +440,36 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
     constexpr int VPR = EPW / VEC;                  // channel vectors per staged row
     constexpr int NIT = (256 * VPR) / 512;          // vectors per thread
     const int vh = (g.H - y0 < PT) ? g.H - y0 : PT, vw = (g.W - x0 < PT) ? g.W - x0 : PT;      // valid part of the patch
+    const int64_t m0 = (int64_t)tmi * 256;
+    const int vrows = LIN ? (int)((int64_t)g.N * g.H * g.W - m0 < 256 ? (int64_t)g.N * g.H * g.W - m0 : 256) : 256;
+    auto valid = [&](int rl) { return LIN ? rl < vrows : ((rl >> 4) < vh && (rl & 15) < vw); };
+    auto grow = [&](int rl) -> int64_t { return LIN ? m0 + rl : ((int64_t)n * g.H + y0 + (rl >> 4)) * g.W + x0 + (rl & 15); };
     float* sC = reinterpret_cast<float*>(smem);
     float* red = sC + 256 * PLDC;                   // scratch for the per-channel folds (<= 8 KB)
     float* tab = red + 2048;                        // [4][EPW] BatchNorm constants of this pass's columns (<= 2 KB)
     auto chan = [&](int pass, int cl) { return NPASS == 1 ? n0 + cl : n0 + (cl >> 5) * 64 + 32 * pass + (cl & 31); };
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        PpRed<NIT, !TWO> bl;            // (TWO: y is loaded inside the store loop -- no register set held across the staging)
+        // (TWO, and the 1x1 kernel's 256-channel tile -- 128 live accumulators: y is loaded inside the store loop, no register set
+        //  held across the staging)
+        constexpr bool PREF = !TWO && !(LIN && MH == 2);
+        PpRed<NIT, PREF> bl;
         if (br.nseg) {
             bl.init(br, chan(pass, (tid % VPR) * VEC));
-            if (tid < EPW) PpRed<NIT, !TWO>::fill(br, tab, EPW, tid, chan(pass, tid));
+            if (tid < EPW) PpRed<NIT, PREF>::fill(br, tab, EPW, tid, chan(pass, tid));
 #pragma unroll
-            for (int it = 0; it < (TWO ? 0 : NIT); ++it) {
-                const int idx = tid + it * 512, rl = idx / VPR, ty = rl >> 4, tx = rl & 15;
-                const bool ok = ty < vh && tx < vw && chan(pass, (idx - rl * VPR) * VEC) < g.Cd;
-                bl.prefetch(it, ok ? ((int64_t)n * g.H + y0 + ty) * g.W + x0 + tx : -1);
+            for (int it = 0; it < (PREF ? NIT : 0); ++it) {
+                const int idx = tid + it * 512, rl = idx / VPR;
+                const bool ok = valid(rl) && chan(pass, (idx - rl * VPR) * VEC) < g.Cd;
+                bl.prefetch(it, ok ? grow(rl) : -1);
             }
         }
+        // BatchNorm partial sums (forward): taken from the accumulator registers while they are staged -- a lane owns one column of
+        // 16 MH rows per channel block, the four row groups of a wave fold by two shuffles, the waves of a column through LDS
+        float cs0[4 / NPASS], cs1[4 / NPASS];
+#pragma unroll
+        for (int jl = 0; jl < 4 / NPASS; ++jl) cs0[jl] = cs1[jl] = 0.f;
+        const bool full = LIN ? vrows == 256 : (vh == PT && vw == PT);
 #pragma unroll
         for (int jl = 0; jl < 4 / NPASS; ++jl) {
             const int j = NPASS == 1 ? jl : 2 * pass + jl;
@@ -471,32 +485,42 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
                     for (int e = 0; e < 4; ++e) v4[e] = acc[m][i][j][e] + bv;
                     apply_act_vec<4>(v4, g.act);
                     const int py = 8 * grp + 4 * (MH == 2 ? m : wm) + i;
+                    if (fin.acc) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = (full || valid(py * 16 + fg * 4 + e)) ? v4[e] : 0.f;
+                            cs0[jl] += t;
+                            cs1[jl] += t * t;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sC[(py * 16 + fg * 4 + e) * PLDC + cl] = v4[e];
                 }
         }
-        __syncthreads();
         if (fin.acc) {
-            constexpr int TYS = 512 / EPW;                       // row groups per column
-            const int tx = tid % EPW, ty = tid / EPW;
-            float s0 = 0.f, s1 = 0.f;
-            for (int r = ty; r < 256; r += TYS) {
-                if ((r >> 4) < vh && (r & 15) < vw) {
-                    const float val = sC[r * PLDC + tx];
-                    s0 += val;
-                    s1 += val * val;
+#pragma unroll
+            for (int jl = 0; jl < 4 / NPASS; ++jl) {
+                cs0[jl] += __shfl_xor(cs0[jl], 16); cs1[jl] += __shfl_xor(cs1[jl], 16);
+                cs0[jl] += __shfl_xor(cs0[jl], 32); cs1[jl] += __shfl_xor(cs1[jl], 32);
+                if (fg == 0) {
+                    red[(wave * 64 + jl * 16 + fr) * 2] = cs0[jl];
+                    red[(wave * 64 + jl * 16 + fr) * 2 + 1] = cs1[jl];
                 }
             }
-            red[ty * EPW + tx] = s0;
-            red[512 + ty * EPW + tx] = s1;
-            __syncthreads();
+        }
+        __syncthreads();
+        if (fin.acc) {
             if (tid < EPW && chan(pass, tid) < g.Cd) {
+                const int wn_ = NPASS == 1 ? tid >> 6 : tid >> 5, ci = NPASS == 1 ? tid & 63 : tid & 31;
                 float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-                for (int q = 0; q < TYS; ++q) {
-                    t0 += red[q * EPW + tid];
-                    t1 += red[512 + q * EPW + tid];
-                }
+                for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                    for (int wm_ = 0; wm_ < 4 / WGN; ++wm_) {
+                        const int w = gq * 4 + wm_ * WGN + wn_;
+                        t0 += red[(w * 64 + ci) * 2];
+                        t1 += red[(w * 64 + ci) * 2 + 1];
+                    }
                 bn_acc_add(fin, tmi, chan(pass, tid), t0, t1);
             }
         }
@@ -505,10 +529,9 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
             const int idx = tid + it * 512;
             const int rl = idx / VPR, cv = idx - rl * VPR;
             const int col = chan(pass, cv * VEC);
-            const int ty = rl >> 4, tx = rl & 15;
-            if (ty >= vh || tx >= vw || col >= g.Cd) continue;
-            const int64_t row = ((int64_t)n * g.H + y0 + ty) * g.W + x0 + tx;
-            if (TWO && br.nseg) bl.prefetch(it, row);
+            if (!valid(rl) || col >= g.Cd) continue;
+            const int64_t row = grow(rl);
+            if (!PREF && br.nseg) bl.prefetch(it, row);
             float vals[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; e += 4) {
@@ -591,6 +614,199 @@ int launch_pp(const dsn_tensor* s, const void* w, const float* bias, const dsn_t
     return DSN_OK;
 }
 
+
+// ---- 1x1 / stride-1 convolution (forward and data gradient) with the same two-group schedule ----------------------------------------
+// C[M = N H W pixels][Cd] = A[M][Cs] * W[Cd][Cs]^T, block tile 256 consecutive pixels x BN channels.  Both operands are K-contiguous
+// rows, so BOTH stream through the ring: piece j = k-half j (32 channels) = A part [256 rows][64 B] + B part [BN rows][64 B], rows
+// swizzled like the weight pieces above.  BN 128: 6 stages x 24 KB, prefetch distance 4 (96 KB in flight per CU -- these layers
+// are HBM-bound below ~512 channels, the prefetch depth is what matters); BN 256: 4 x 32 KB, distance 3, the piece issued in two
+// halves -- the first phase of a k-half refills the B part and the A rows of pixel half 0 (last read two phases earlier), the
+// second phase the A rows of pixel half 1 (the same rule as above: refill no earlier than two phases after the read).
+// Per wave and piece: 2 A DMAs (rows 16 py .. + 16 for the wave's py of each pixel half) + BN / 128 B DMAs, a static schedule.
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk,
+                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            bf16_t* __restrict__ dst, const BnAcc fin, const PGeom g, const BnRed br) {
+    static_assert(BN == 128 || BN == 256, "block tiles of 128 or 256 output channels");
+    constexpr int MH = BN / 128, GW = BN / 128;
+    constexpr int APIECE = 256 * 64;
+    constexpr int PIECE = APIECE + BN * 64;
+    constexpr int R = BN == 128 ? 6 : 4;
+    constexpr int D = MH == 1 ? R - 2 : R - 1;
+    constexpr int NPK = 2 + GW;                  // DMAs per wave and piece
+    constexpr int WGN = BN == 128 ? 2 : 4;
+    constexpr int VEC = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wq = wave & 3;
+    const int wm = wq / WGN, wn = wq % WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tile = pp_xcd_remap(blockIdx.x, g.tiles_y * g.tiles_n);        // (tiles_y: 256-pixel tiles of the pixel list)
+    const int tn = tile % g.tiles_n, tmi = tile / g.tiles_n;
+    const int n0 = tn * BN;
+    const int64_t M = (int64_t)g.N * g.H * g.W, m0 = (int64_t)tmi * 256;
+#ifdef DSN_PP_STAMP
+    const unsigned long long st_re = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, g.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+
+    // lane -> (row lane >> 2 of the 16 rows of a DMA, physical slot lane & 3); logical slot fetched: the swizzle's inverse (an involution)
+    const int dls = (lane & 3) ^ ((-(lane >> 4)) & 3);
+    uint32_t aoff[2], woff[GW];
+    int apy[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        apy[q] = (wave >> 2) * 8 + 4 * q + (wave & 3);                       // 16-row group: pixel half q of its group's rows
+        const int64_t m = m0 + apy[q] * 16 + (lane >> 2);
+        aoff[q] = m < M ? (uint32_t)((m * g.sld + dls * VEC) * 2) : OOB;
+    }
+#pragma unroll
+    for (int part = 0; part < GW; ++part) {
+        const int row = 16 * (wave + 8 * part) + (lane >> 2);
+        woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * g.Cs + dls * VEC) * 2u : OOB;
+    }
+    const int T = g.Cs >> 5;                                                 // k-halves
+    auto load_a = [&](int jp, int slot, int q) {
+        const uint32_t off = (aoff[q] == OOB || jp >= T) ? OOB : aoff[q] + (uint32_t)jp * 64u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(smem + slot * PIECE + apy[q] * 1024), 16, off, 0, 0, 0);
+    };
+    auto load_b = [&](int jp, int slot, int part) {
+        const uint32_t off = (woff[part] == OOB || jp >= T) ? OOB : woff[part] + (uint32_t)jp * 64u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(smem + slot * PIECE + APIECE + (wave + 8 * part) * 1024), 16, off, 0, 0, 0);
+    };
+
+    const int swz = (fg ^ ((-(fr >> 2)) & 3)) << 4;
+    const int a_base = ((8 * grp + (MH == 2 ? 0 : 4 * wm)) * 16 + fr) * 64 + swz;
+    const int b_base = APIECE + (wn * 64 + fr) * 64 + swz;
+
+    f32x4 acc[MH][4][4];
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: pieces 0 .. D-1; piece 0 landed before the first barrier ---------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        load_a(i, i % R, 0);
+        load_a(i, i % R, 1);
+#pragma unroll
+        for (int part = 0; part < GW; ++part) load_b(i, i % R, part);
+    }
+    pp_wait_vm((D - 1) * NPK);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+#ifdef DSN_PP_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    u32x4 fa[4], fb[4];
+    for (int jb = 0; jb < T; jb += R) {
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            if (jb + jj >= T) break;                                         // (block-uniform)
+            const unsigned char* st = smem + jj * PIECE;
+            const int slot_w = (jj + D) % R;
+#pragma unroll
+            for (int mh = 0; mh < MH; ++mh) {
+                // ---- load segment ----------------------------------------------------------------------------------------------
+                if (mh == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + b_base + j * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + a_base + (4 * mh + i) * 1024);
+                if (MH == 1) {
+                    pp_wait_vm((D - 2) * NPK);                               // piece j+1 landed (this wave's share)
+                    load_a(jb + jj + D, slot_w, 0);
+                    load_a(jb + jj + D, slot_w, 1);
+                    load_b(jb + jj + D, slot_w, 0);
+                } else if (mh == 0) {
+                    load_b(jb + jj + D, slot_w, 0);
+                    load_b(jb + jj + D, slot_w, 1);
+                    load_a(jb + jj + D, slot_w, 0);
+                } else {
+                    pp_wait_vm((D - 2) * NPK + 3);
+                    load_a(jb + jj + D, slot_w, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA segment ----------------------------------------------------------------------------------------------
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                               __builtin_bit_cast(bf16x8, fb[j]), acc[mh][i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (grp == 0) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef DSN_PP_STAMP
+    if (tid == 0 && blockIdx.x < 4096) {
+        pp_stamp_buf[6 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_t0;
+        pp_stamp_buf[6 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        pp_stamp_buf[6 * blockIdx.x + 2] = st_re;
+        pp_stamp_buf[6 * blockIdx.x + 3] = st_r0 - st_re;
+    }
+    const unsigned long long st_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[m][i][j]));
+    conv3x3_pp_epilogue<BN, false, MH, true>(acc, smem, bias, res, dst, fin, g, br, 0, 0, 0, n0, tmi);
+#ifdef DSN_PP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 4096) pp_stamp_buf[6 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime() - st_r1;
+#endif
+}
+
+template <int BN>
+int launch_pp1(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, PGeom g, const BnAcc& fin,
+               const BnRed* br, hipStream_t st) {
+    const int64_t M = (int64_t)g.N * g.H * g.W;
+    g.tiles_y = (int32_t)((M + 255) / 256);
+    g.tiles_x = 1;
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    auto kern = conv1x1_pp_kernel<BN>;
+    constexpr int LDS = (BN == 128 ? 6 * 24576 : 4 * 32768) > PP_LDS ? (BN == 128 ? 6 * 24576 : 4 * 32768) : PP_LDS;   // (ring; epilogue staging)
+    DSN_LDS_ATTR(kern, LDS);
+    const int blocks = g.tiles_y * g.tiles_n;
+    const double elems = (double)M * (g.Cs + (double)g.Cd * (1 + (r ? 1 : 0) + (g.accumulate ? 1 : 0)) + bnred_channels(br)) + (double)g.Cs * g.Cd;
+    const ProfConv pc("conv1x1_pp_kernel", true, 256, BN, g.flip != 0, 1, 1, 1, g.Cs, g.Cd, g.N, g.H, g.W);
+    ProfScope prof(pc.label, pc.layer, 2.0 * M * g.Cd * g.Cs, elems * 2, st);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), LDS, st, (const bf16_t*)s->ptr, (const bf16_t*)w, bias,
+                       r ? (const bf16_t*)r->ptr : nullptr, (bf16_t*)d->ptr, fin, g, br ? *br : BnRed{});
+    DSN_LAUNCH_CHECK("conv1x1 (ping-pong big tile)");
+    return DSN_OK;
+}
+
 }  // namespace
 
 #ifdef DSN_PP_STAMP
@@ -658,4 +874,57 @@ int dsn_conv3x3_pp_try(const dsn_tensor* s, const void* w, const float* bias, co
     const int64_t blocks128 = patches * ((d->c + 127) / 128);
     if (md != 5 && (md == 4 || (blocks128 >= two_min && g.nslab <= two_maxslab))) return launch_pp<128, true>(s, w, bias, r, d, g, fin, brp, (hipStream_t)stream);
     return launch_pp<128, false>(s, w, bias, r, d, g, fin, brp, (hipStream_t)stream);
+}
+
+// 1x1 / stride 1: tried first by the 1x1 chains of igemm.hip.  Mode (DSN_PP1 / dsn_pp1_mode): 0 never, 1 default (see below), 2 every
+// eligible layer on 128-channel tiles, 3 the same with 256-channel tiles wherever the channel count allows.
+static int g_pp1_mode = getenv("DSN_PP1") ? atoi(getenv("DSN_PP1")) : 1;
+extern "C" int dsn_pp1_mode(int32_t mode) {
+    if (mode >= 0) g_pp1_mode = mode;
+    return g_pp1_mode;
+}
+
+int dsn_conv1x1_pp_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
+                       const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const BnRed* br) {
+    const int md = g_pp1_mode;
+    if (!md) return 1;
+    if (s->dtype != DSN_BF16 || d->dtype != DSN_BF16) return 1;
+    if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0) return 1;
+    if (s->h != d->h || s->w != d->w || s->n != d->n) return 1;
+    if (s->c % 32 != 0 || d->c % 8 != 0 || s->ldc % 8 != 0 || d->ldc % 8 != 0) return 1;
+    if (((uintptr_t)s->ptr | (uintptr_t)d->ptr | (uintptr_t)w) % 16 != 0) return 1;
+    if (r && (r->ldc % 8 != 0 || (uintptr_t)r->ptr % 16 != 0)) return 1;
+    const int64_t sb = ((npix(s) - 1) * s->ldc + s->c) * 2, wb = (int64_t)d->c * s->c * 2;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || npix(d) * d->ldc * 2 >= (1ll << 40)) return 1;
+    const int64_t tiles_m = (npix(s) + 255) / 256;
+    bool wide = d->c % 256 == 0 && md == 3;
+    if (md == 1) {
+        // Chosen from per-layer times INSIDE config 5's training step (profiles/r04c_pp1_layers_in_step.txt; the stand-alone
+        // microbenchmark flatters this kernel: in the step the forward carries the BatchNorm sums and the data gradient the
+        // BatchNorm-backward sums in the epilogue).  us per launch, weights-stationary / implicit-GEMM kernels -> this one:
+        //   768 -> 256 @4x160x160 fwd 117.5 -> 75.9 (256-channel tiles), 512 -> 512 @4x80x80 fwd 37.0 -> 32.1 / dgrad 51.1 -> 43.2 (256),
+        //   512 -> 256 @4x160x160 fwd 70.0 -> 61.9 (256), 1024 -> 512 @4x80x80 fwd 63.5 -> 43.0 (256), 1024 -> 1024 @4x40x40 fwd 32.5 -> 26.0 /
+        //   dgrad 36.8 -> 33.2 (128), 2048 -> 1024 @4x40x40 fwd 50.4 -> 42.1 / its twin dgrad 53.1 -> 42.8 (128), 512 -> 256 @4x80x80 fwd 22.6 -> 19.0 (128);
+        //   it loses below 512 input channels (256 -> 256 @4x80x80 fwd 13.8 -> 16.4, 128 -> 128 @4x160x160 16.5 -> 22.8: pure streams),
+        //   on grids of ~100 blocks (512 -> 512 @4x40x40 14.1 -> 16.6), and -- with the BatchNorm-backward sums -- for 256 output
+        //   channels at K = 512 (256 -> 512 @4x160x160 dgrad 91.7 -> 101.6).  256-channel tiles from 200 blocks up; at 100
+        //   blocks they lose (1024 -> 1024 @4x40x40 fwd 32.5 -> 39.5).
+        static const int min_blocks = [] { const char* e = getenv("DSN_PP1_MIN_BLOCKS"); return e ? atoi(e) : 160; }();
+        static const int min_k = [] { const char* e = getenv("DSN_PP1_MIN_K"); return e ? atoi(e) : 512; }();
+        if (d->c < 256 || s->c < min_k) return 1;
+        if (br && br->nseg > 0 && d->c < 512 && s->c < 1024) return 1;
+        wide = d->c % 256 == 0 && tiles_m * (d->c / 256) >= 200;
+        if (!wide && tiles_m * ((d->c + 127) / 128) < min_blocks) return 1;
+    }
+    PGeom g{};
+    g.N = s->n; g.H = s->h; g.W = s->w; g.Cs = s->c; g.Cd = d->c; g.flip = is_dgrad ? 1 : 0;
+    g.act = p->act; g.accumulate = p->accumulate;
+    g.sld = s->ldc; g.dld = d->ldc; g.rld = r ? r->ldc : 0;
+    g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
+    g.nslab = 0;
+    BnAcc fin{};
+    if (finp) fin = *finp;
+    const BnRed* brp = (br && br->nseg > 0) ? br : nullptr;
+    if (wide) return launch_pp1<256>(s, w, bias, r, d, g, fin, brp, (hipStream_t)stream);
+    return launch_pp1<128>(s, w, bias, r, d, g, fin, brp, (hipStream_t)stream);
 }

@@ -748,6 +748,8 @@ int conv_fwd_impl(const dsn_tensor* x, const void* w, const float* bias, const d
                           residual->h == y->h && residual->w == y->w && residual->c == y->c,
                       "conv fwd: residual shape mismatch");
     if (!stats) {      // 3x3 / stride 1 with whole 64-channel slabs: the halo-tile kernel (conv3x3.hip)
+        rc = dsn_conv1x1_pp_try(x, w, bias, residual, y, p, 0, finp, stream);       // long-K 1x1 on big tiles (conv_pp.hip)
+        if (rc != 1) return rc;
         rc = dsn_conv1x1_ws_try(x, w, bias, residual, y, p, 0, finp, stream);       // 1x1, weights-stationary persistent blocks
         if (rc != 1) return rc;
         rc = dsn_conv3x3_pp_try(x, w, bias, residual, y, p, 0, finp, stream);       // 3x3 / stride 1 on big tiles (conv_pp.hip)
@@ -878,6 +880,8 @@ int conv_dgrad_impl(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, c
         DSN_CHECK_ARG(tensor_ok(residual) && residual->dtype == dx->dtype && residual->n == dx->n && residual->h == dx->h &&
                           residual->w == dx->w && residual->c == dx->c && p->stride == 1,
                       "conv dgrad: residual must have dx's shape (stride-1 convolutions only)");
+    rc = dsn_conv1x1_pp_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, br);       // long-K 1x1 on big tiles (conv_pp.hip)
+    if (rc != 1) return rc;
     rc = dsn_conv1x1_ws_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, br);
     if (rc != 1) return rc;
     rc = dsn_conv3x3_pp_try(dy, w, nullptr, residual, dx, p, 1, nullptr, stream, br);       // big-tile ping-pong kernel (conv_pp.hip)

@@ -127,6 +127,10 @@ int         dsn_ws_mode(int32_t mode_1x1, int32_t mode_3x3);
  * and give >= 160 blocks), 2 = every eligible layer, 3 = the same with 256-channel tiles wherever possible, 4 / 5 = every eligible layer on 128-channel tiles with two / one
  * block(s) per CU (tests, A/B runs).  Negative: unchanged.  Returns the mode after the update. */
 int         dsn_pp_mode(int32_t mode);
+/* The same for the 1x1 form of that kernel (256 consecutive pixels x 128 / 256 channels, bf16, k1 / s1, input channels a multiple
+ * of 32): 0 = never, 1 = default (>= 512 input and >= 256 output channels, >= 160 blocks), 2 = every eligible layer on 128-channel
+ * tiles, 3 = the same with 256-channel tiles wherever possible.  Negative: unchanged.  Returns the mode after the update. */
+int         dsn_pp1_mode(int32_t mode);
 /* The same for the ping-pong kernel-row weight-gradient kernel (csrc/wgrad.hip kind 5: 128 x 128 tiles x the three taps of a kernel
  * row per block; bf16, same-size 3x3 / s1 / p1 / d1, whole 128-channel tiles): 0 = never, 1 = default (16 x 16 patches cover >= 80 %
  * of the map, >= 12800 output pixels), 2 = every eligible layer.  Negative: unchanged.  Returns the mode after the update. */

@@ -57,6 +57,27 @@ LAYERS_PP = [  # conv_pp.hip: the same 400-patch grid (4 x 160 x 160) with K = 5
     ("pp1 256->256 k3 @2x160", 2, 256, 160, 160, 256, 3, 1),
 ]
 
+LAYERS_1X1 = [  # the 1x1 layers of config 5 (batch 4, 1280x1280) and the larger ones of config 3 (batch 8, 640x640)
+    ("m 128->128 k1 @160", 4, 128, 160, 160, 128, 1, 1),
+    ("m 256->256 k1 @80", 4, 256, 80, 80, 256, 1, 1),
+    ("m 512->256 k1 @160", 4, 512, 160, 160, 256, 1, 1),
+    ("m 256->512 k1 @160", 4, 256, 160, 160, 512, 1, 1),
+    ("m 512->512 k1 @80", 4, 512, 80, 80, 512, 1, 1),
+    ("m 1024->1024 k1 @40", 4, 1024, 40, 40, 1024, 1, 1),
+    ("m 256->256 k1 @160", 4, 256, 160, 160, 256, 1, 1),
+    ("m 768->256 k1 @160", 4, 768, 160, 160, 256, 1, 1),
+    ("m 512->512 k1 @40", 4, 512, 40, 40, 512, 1, 1),
+    ("m 1024->512 k1 @80", 4, 1024, 80, 80, 512, 1, 1),
+    ("m 2048->1024 k1 @40", 4, 2048, 40, 40, 1024, 1, 1),
+    ("m 512->256 k1 @80", 4, 512, 80, 80, 256, 1, 1),
+    ("m 1024->512 k1 @40", 4, 1024, 40, 40, 512, 1, 1),
+    ("s 256->256 k1 @40", 8, 256, 40, 40, 256, 1, 1),
+    ("s 256->128 k1 @80", 8, 256, 80, 80, 128, 1, 1),
+    ("s 384->128 k1 @80", 8, 384, 80, 80, 128, 1, 1),
+    ("s 512->512 k1 @20", 8, 512, 20, 20, 512, 1, 1),
+    ("s 128->128 k1 @80", 8, 128, 80, 80, 128, 1, 1),
+]
+
 _STREAM = None
 
 
@@ -118,7 +139,7 @@ def main():
     if which == "bn":
         return bench_bn()
     import os
-    for name, n, ci, h, w, co, k, s in {"m": LAYERS_M, "pp": LAYERS_PP}.get(os.environ.get("DSN_BENCH_SET", ""), LAYERS):
+    for name, n, ci, h, w, co, k, s in {"m": LAYERS_M, "pp": LAYERS_PP, "1x1": LAYERS_1X1}.get(os.environ.get("DSN_BENCH_SET", ""), LAYERS):
         if only and only not in name:
             continue
         pad = k // 2
