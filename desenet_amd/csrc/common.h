@@ -404,6 +404,10 @@ int dsn_conv3x3_pp_try(const dsn_tensor* s, const void* w, const float* bias, co
 int dsn_conv1x1_pp_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                        const dsn_conv_params* p, int is_dgrad, const BnAcc* finp, void* stream, const dsn_bnred* br = nullptr);
 
+// conv_pp.hip: the 3x3 / stride-2 data gradient (2x2 form, depth-to-space store) on the same kernel
+int dsn_dgrad_s2_pp_try(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p, const dsn_bnred* br,
+                        void* stream);
+
 // the gather forms of the 1x1 kernel: 3x3 / stride 2 / pad 1 forward, and its data gradient (2x2 form, depth-to-space store)
 int dsn_conv3x3s2_ws_try(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d,
                          const dsn_conv_params* p, const BnAcc* finp, void* stream);

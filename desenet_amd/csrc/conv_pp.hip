@@ -59,6 +59,7 @@ struct PGeom {
     int64_t sld, dld, rld;
     uint32_t src_bytes, w_bytes;
     int32_t nslab;
+    int32_t d2s_c, Hout, Wout;   // 2x2 form of the stride-2 data gradient: GEMM column c = parity (c / d2s_c) of channel c % d2s_c
 };
 
 constexpr int PT = 16;                       // patch edge (output pixels)
@@ -110,6 +111,41 @@ __host__ __device__ constexpr int pp_wait_count(int jj, int MH, int GW, int D) {
     if (MH == 2) n += 1 + (pp_halo_at(jj) ? 1 : 0);             // phase (jj, 0) of this k-half: its weight DMA (+ halo DMA)
     return n;
 }
+
+// The same by simulation, for both tap sets (NT = 9: 3x3; NT = 4: the 2x2 form of the stride-2 data gradient, whose slab has
+// 8 k-halves and issues its 5 halo DMAs in k-halves 1..5, IN FRONT of that phase's weight DMA): walk the phases backwards from the
+// wait, in reverse program order, and count the DMAs that are younger than the youngest one the wait needs -- a part of piece
+// jj + 1, or, in the last k-half of a slab, a DMA of the next halo patch.
+__host__ __device__ constexpr bool pp_halo_at_g(int jj, int NT) {
+    const int KH = 2 * NT, m = ((jj % KH) + KH) % KH;
+    return NT == 9 ? pp_halo_at(jj) : (m >= 1 && m <= 5);
+}
+__host__ __device__ constexpr int pp_wait_count_g(int jj, int MH, int GW, int D, int NT) {
+    const int KH = 2 * NT;
+    const bool need_halo = jj == KH - 1;
+    int n = 0;
+    for (int ph = jj * MH + MH - 2; ph >= (jj - D - 2) * MH; --ph) {
+        const int i = ph >= 0 ? ph / MH : -((-ph + MH - 1) / MH), mh = ph - i * MH;
+        const bool h = mh == 0 && pp_halo_at_g(i, NT), hn = h && need_halo && i >= 0;
+        const bool wn = i + D == jj + 1;
+        if (NT == 9) {          // program order: weight, halo
+            if (h) { if (hn) return n; ++n; }
+            if (wn) return n;
+            ++n;
+        } else {                // program order: halo, weight
+            if (wn) return n;
+            ++n;
+            if (h) { if (hn) return n; ++n; }
+        }
+    }
+    return n;
+}
+constexpr bool pp_wait_count_same(int MH, int GW, int D) {
+    for (int jj = 0; jj < 18; ++jj)
+        if (pp_wait_count_g(jj, MH, GW, D, 9) != pp_wait_count(jj, MH, GW, D)) return false;
+    return true;
+}
+static_assert(pp_wait_count_same(1, 1, 4) && pp_wait_count_same(2, 2, 2), "the simulated wait counts reproduce the closed form of the 3x3 schedule");
 
 // BatchNorm backward sums of the block(s) whose dz this data gradient completes -- BnRedLane of common.h with the per-channel
 // constants (scale, shift, mean, rstd) in an LDS table [4][columns] instead of 32 registers per thread (the two-blocks-per-CU
@@ -175,7 +211,7 @@ template <int NIT, bool PREF> struct PpRed {
     }
 };
 
-template <int BN, bool TWO, int MH, bool LIN>
+template <int BN, bool TWO, int MH, bool LIN, bool D2S>
 __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                         const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi);
@@ -183,23 +219,32 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
 __device__ unsigned long long pp_stamp_buf[6 * 4096];
 #endif
 
-template <int BN, bool TWO, int MH, bool LIN = false>
+template <int BN, bool TWO, int MH, bool LIN = false, bool D2S = false>
 __device__ __forceinline__ void conv3x3_pp_epilogue(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                    const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                    const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi) {
-    conv3x3_pp_epilogue_impl<BN, TWO, MH, LIN>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
+    conv3x3_pp_epilogue_impl<BN, TWO, MH, LIN, D2S>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
 }
 
-template <int BN, bool FLIP, bool TWO>
+// NT = 4: the 2x2 / stride-1 form of the 3x3 / stride-2 data gradient (igemm.hip, dsn_conv2d_dgrad_s2): taps (ty, tx) in {0, 1}^2
+// read dy at (y + ty, x + tx) -- a 17 x 17 halo with the patch in its top-left corner --, weights [4 Ci][2][2][Co], 8 k-halves per
+// slab, depth-to-space store.  Ring: 8 x 8 KB, distance 6 (BN 128) / 4 x 16 KB, distance 3 (BN 256); halo buffers 2 x 40 KB.
+template <int BN, bool FLIP, bool TWO, int NT = 9>
 __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk,
                                                          const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                          bf16_t* __restrict__ dst, const BnAcc fin, const PGeom g, const BnRed br) {
     static_assert(BN == 128 || BN == 256, "block tiles of 128 or 256 output channels");
     static_assert(!TWO || BN == 128, "two blocks per CU: 128-channel tiles");
+    static_assert(NT == 9 || (NT == 4 && !FLIP && !TWO), "tap sets: 3x3, or the 2x2 form of the stride-2 data gradient");
+    constexpr int KH = 2 * NT;                   // k-halves per slab
+    constexpr int PADO = NT == 9 ? 1 : 0;        // halo rows / columns in front of the patch
+    constexpr int PIHN = NT == 9 ? PIH : 5;      // halo DMAs per wave and patch (NT 4: 17 rows x 18 slots = 306 <= 320)
+    constexpr int PNPN = NT == 9 ? PNP : 17 * PHW;
+    constexpr int HB = PIHN * 64 * 128;          // bytes of a halo buffer
     typedef bf16_t T;
     constexpr int MH = BN / 128;                 // 64-pixel halves of a wave's pixel rows = phases per k-half
     constexpr int GW = BN / 128;                 // weight DMAs per wave and piece
-    constexpr int R = TWO ? 4 : (BN == 128 ? 6 : 3);   // ring stages
+    constexpr int R = NT == 4 ? (BN == 128 ? 8 : 4) : TWO ? 4 : (BN == 128 ? 6 : 3);   // ring stages (KH % R == 0)
     // prefetch distance in k-halves.  A stage is refilled no earlier than TWO phases after the phase that read it (the reads of a
     // load segment are only known complete once their wave has run its MFMA segment, i.e. after the NEXT barrier pair): with one
     // phase per k-half that is distance R - 2, with two phases per k-half R - 1.
@@ -208,10 +253,10 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
     constexpr int PIECE = BN * 64;
     constexpr int WGN = BN == 128 ? 2 : 4;       // waves of a group across the output channels (64 each)
     constexpr int VEC = 8;
-    static_assert(R * PIECE == (TWO ? 4 * 8192 : RING_BYTES), "ring size");
+    static_assert(R * PIECE == (NT == 4 ? 65536 : TWO ? 4 * 8192 : RING_BYTES) && (TWO || KH % R == 0), "ring size");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sH = smem;
-    unsigned char* sB = smem + (TWO ? 1 : 2) * HALO_BYTES;
+    unsigned char* sB = smem + (TWO ? 1 : 2) * HB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, wq = wave & 3;
@@ -239,21 +284,21 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         const int lane = tq & 63, wave = tq >> 6;
         const int p = 64 * q + 8 * wave + (lane >> 3);
         const int hy = p / PHW, hx = p - hy * PHW;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = p < PNP && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        const int gy = y0 - PADO + hy, gx = x0 - PADO + hx;
+        const bool ok = p < PNPN && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
         const int ls = pp_hslot(lane & 7, hx);                       // logical slot fetched (pp_hslot is an involution in the slot)
         return ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + ls * VEC) * 2u : OOB;
     };
-    uint32_t hoff[TWO ? 1 : PIH];              // (TWO: recomputed at each slab boundary -- six registers fewer in the loop)
+    uint32_t hoff[TWO ? 1 : PIHN];              // (TWO: recomputed at each slab boundary -- six registers fewer in the loop)
     if constexpr (!TWO) {
 #pragma unroll
-        for (int q = 0; q < PIH; ++q) hoff[q] = halo_off(q, tid);
+        for (int q = 0; q < PIHN; ++q) hoff[q] = halo_off(q, tid);
     }
     auto load_halo1 = [&](int slab, int hbuf, int q, int tq = 0) {
         const uint32_t add = slab < g.nslab ? (uint32_t)slab * 128u : OOB;
         const uint32_t ho = TWO ? halo_off(q, tq) : hoff[TWO ? 0 : q];
         const uint32_t off = (ho == OOB || add == OOB) ? OOB : ho + add;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + hbuf * HALO_BYTES + (64 * q + 8 * wave) * 128), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + hbuf * HB + (64 * q + 8 * wave) * 128), 16, off, 0, 0, 0);
     };
     // ---- weight fetch plan: DMA `part` of this wave covers rows 16 (wave + 8 part) .. + 16 of the piece; lane -> row, physical slot
     uint32_t woff[GW];
@@ -261,12 +306,12 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
     for (int part = 0; part < GW; ++part) {
         const int row = 16 * (wave + 8 * part) + (lane >> 2);
         const int ls = (lane & 3) ^ ((-(lane >> 4)) & 3);             // ((row >> 2) & 3) == lane >> 4: logical slot of this lane
-        woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * 9 * g.Cs + ls * VEC) * 2u : OOB;
+        woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * NT * g.Cs + ls * VEC) * 2u : OOB;
     }
-    const int T_ALL = g.nslab * 18;                                   // k-halves
-    // piece jp (global k-half index): slab jp / 18, weight tap (jp % 18) / 2, channel half jp & 1
+    const int T_ALL = g.nslab * KH;                                   // k-halves
+    // piece jp (global k-half index): slab jp / KH, weight tap (jp % KH) / 2, channel half jp & 1
     auto load_w1 = [&](int jp, int slot, int part) {
-        const int s = jp / 18, jj = jp - s * 18, t = jj >> 1, kk = jj & 1;
+        const int s = jp / KH, jj = jp - s * KH, t = jj >> 1, kk = jj & 1;
         const uint32_t add = jp < T_ALL ? (uint32_t)(t * g.Cs + s * 64 + kk * 32) * 2u : OOB;
         const uint32_t off = (woff[part] == OOB || add == OOB) ? OOB : woff[part] + add;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + slot * PIECE + (wave + 8 * part) * 1024), 16, off, 0, 0, 0);
@@ -294,7 +339,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
 
     // ---- prologue: halo(0), pieces 0 .. D-1; halo(0) and piece 0 landed before the first barrier ------------------------------------
 #pragma unroll
-    for (int q = 0; q < PIH; ++q) load_halo1(0, 0, q, tid);
+    for (int q = 0; q < PIHN; ++q) load_halo1(0, 0, q, tid);
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -313,14 +358,14 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
 #endif
     u32x4 fa[4], fb[4];
     for (int s = 0; s < g.nslab; ++s) {
-        const unsigned char* hb = sH + (TWO ? 0 : (s & 1) * HALO_BYTES);
+        const unsigned char* hb = sH + (TWO ? 0 : (s & 1) * HB);
         const int so = TWO ? (s & 1) * 2 : 0;        // TWO: 18 k-halves per slab over 4 stages: the ring position shifts by 2 per slab
 #pragma unroll
-        for (int jj = 0; jj < 18; ++jj) {
+        for (int jj = 0; jj < KH; ++jj) {
             const int t = jj >> 1, kk = jj & 1;
             // halo offset of weight tap t (data gradient: mirrored -- the same tap order, hence the same fp32 summation order, as
             // the kernels of conv3x3.hip / conv_ws.hip / igemm.hip)
-            const int oy = FLIP ? 2 - t / 3 : t / 3, ox = FLIP ? 2 - t % 3 : t % 3;
+            const int oy = NT == 4 ? t >> 1 : FLIP ? 2 - t / 3 : t / 3, ox = NT == 4 ? t & 1 : FLIP ? 2 - t % 3 : t % 3;
             const int slot = TWO ? ((jj + so) & 3) : jj % R;       // (!TWO: 18 % R == 0, a compile-time function of jj)
             const int slot_w = TWO ? ((jj + D + so) & 3) : (jj + D) % R;
 #pragma unroll
@@ -335,9 +380,10 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
                 for (int i = 0; i < 4; ++i)
                     fa[i] = *reinterpret_cast<const u32x4*>(hb + a_base[ox][kk] + ((4 * mh + i + oy) * PHW + ox) * 128);
                 // piece j+1 (and, at jj == 17, the next halo patch) landed
-                if (mh == MH - 1) pp_wait_vm(TWO ? (D - 2) * GW : pp_wait_count(jj, MH, GW, D));
-                load_w1(s * 18 + jj + D, slot_w, GW == 1 ? 0 : mh);
-                if (!TWO && mh == 0 && pp_halo_at(jj)) load_halo1(s + 1, (s + 1) & 1, t - 1);
+                if (mh == MH - 1) pp_wait_vm(TWO ? (D - 2) * GW : pp_wait_count_g(jj, MH, GW, D, NT));
+                if (NT == 4 && mh == 0 && pp_halo_at_g(jj, NT)) load_halo1(s + 1, (s + 1) & 1, jj - 1);
+                load_w1(s * KH + jj + D, slot_w, GW == 1 ? 0 : mh);
+                if (NT == 9 && !TWO && mh == 0 && pp_halo_at(jj)) load_halo1(s + 1, (s + 1) & 1, t - 1);
                 // !TWO: no lgkmcnt wait here -- the fragment reads return while the wave waits at the barrier; the compiler's own
                 // counted waits in front of the MFMAs order the registers
                 if (TWO) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -405,7 +451,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[m][i][j]));
-    conv3x3_pp_epilogue<BN, TWO, MH>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
+    conv3x3_pp_epilogue<BN, TWO, MH, false, NT == 4>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
 #ifdef DSN_PP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && blockIdx.x < 4096) pp_stamp_buf[6 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime() - st_r1;
@@ -415,7 +461,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
 // The epilogue re-derives its lane coordinates from threadIdx.x behind an opaque move: nothing of them stays live across the main
 // loop (TWO runs at 128 VGPRs: 64 accumulators + 32 fragment registers leave 32 for everything else).
 // LIN (the 1x1 kernel below): tile row r is pixel 256 tmi + r of the [N H W] pixel list instead of patch pixel (r >> 4, r & 15).
-template <int BN, bool TWO, int MH, bool LIN>
+// D2S (2x2 form of the stride-2 data gradient): GEMM column c is channel c % d2s_c of destination pixel (2y + py, 2x + px),
+// (py, px) = parity c / d2s_c, of a destination Hout x Wout.
+template <int BN, bool TWO, int MH, bool LIN, bool D2S>
 __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
                                                         const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi) {
@@ -444,6 +492,13 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
     const int vrows = LIN ? (int)((int64_t)g.N * g.H * g.W - m0 < 256 ? (int64_t)g.N * g.H * g.W - m0 : 256) : 256;
     auto valid = [&](int rl) { return LIN ? rl < vrows : ((rl >> 4) < vh && (rl & 15) < vw); };
     auto grow = [&](int rl) -> int64_t { return LIN ? m0 + rl : ((int64_t)n * g.H + y0 + (rl >> 4)) * g.W + x0 + (rl & 15); };
+    // D2S: destination channel / pixel row of GEMM column `col` at tile row rl (-1: outside an odd-sized destination)
+    auto dch = [&](int col) { return D2S ? col % g.d2s_c : col; };
+    auto drow = [&](int rl, int col) -> int64_t {
+        if (!D2S) return grow(rl);
+        const int par = col / g.d2s_c, yy = 2 * (y0 + (rl >> 4)) + (par >> 1), xx = 2 * (x0 + (rl & 15)) + (par & 1);
+        return (yy < g.Hout && xx < g.Wout) ? ((int64_t)n * g.Hout + yy) * g.Wout + xx : -1;
+    };
     float* sC = reinterpret_cast<float*>(smem);
     float* red = sC + 256 * PLDC;                   // scratch for the per-channel folds (<= 8 KB)
     float* tab = red + 2048;                        // [4][EPW] BatchNorm constants of this pass's columns (<= 2 KB)
@@ -455,13 +510,14 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
         constexpr bool PREF = !TWO && !(LIN && MH == 2);
         PpRed<NIT, PREF> bl;
         if (br.nseg) {
-            bl.init(br, chan(pass, (tid % VPR) * VEC));
-            if (tid < EPW) PpRed<NIT, PREF>::fill(br, tab, EPW, tid, chan(pass, tid));
+            bl.init(br, dch(chan(pass, (tid % VPR) * VEC)));
+            if (tid < EPW) PpRed<NIT, PREF>::fill(br, tab, EPW, tid, dch(chan(pass, tid)));
 #pragma unroll
             for (int it = 0; it < (PREF ? NIT : 0); ++it) {
                 const int idx = tid + it * 512, rl = idx / VPR;
-                const bool ok = valid(rl) && chan(pass, (idx - rl * VPR) * VEC) < g.Cd;
-                bl.prefetch(it, ok ? grow(rl) : -1);
+                const int pc = chan(pass, (idx - rl * VPR) * VEC);
+                const bool ok = valid(rl) && pc < g.Cd;
+                bl.prefetch(it, ok ? drow(rl, pc) : -1);
             }
         }
         // BatchNorm partial sums (forward): taken from the accumulator registers while they are staged -- a lane owns one column of
@@ -530,7 +586,8 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
             const int rl = idx / VPR, cv = idx - rl * VPR;
             const int col = chan(pass, cv * VEC);
             if (!valid(rl) || col >= g.Cd) continue;
-            const int64_t row = grow(rl);
+            const int64_t row = drow(rl, col);
+            if (D2S && row < 0) continue;
             if (!PREF && br.nseg) bl.prefetch(it, row);
             float vals[VEC];
 #pragma unroll
@@ -538,10 +595,10 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(sC + rl * PLDC + cv * VEC + e);
                 vals[e] = t4[0]; vals[e + 1] = t4[1]; vals[e + 2] = t4[2]; vals[e + 3] = t4[3];
             }
-            T* o = dst + row * g.dld + col;
+            T* o = dst + row * g.dld + dch(col);
             if (res) {
                 T rv[VEC];
-                *reinterpret_cast<u32x4*>(rv) = *reinterpret_cast<const u32x4*>(res + row * g.rld + col);
+                *reinterpret_cast<u32x4*>(rv) = *reinterpret_cast<const u32x4*>(res + row * g.rld + dch(col));
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) vals[e] += to_f32<T>(rv[e]);
             }
@@ -583,7 +640,7 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
                     s0 += red[(w * EPW + tid) * 2];
                     s1 += red[(w * EPW + tid) * 2 + 1];
                 }
-                const int ch = chan(pass, tid);
+                const int ch = dch(chan(pass, tid));
                 for (int sg = 0; sg < br.nseg; ++sg) {
                     const dsn_bnred_seg& q = br.seg[sg];
                     if (ch >= q.c0 && ch < q.c1) bn_acc_add(BnAcc{(double*)q.acc, q.acc_c, 0.0}, tmi, q.ch0 + ch - q.c0, s0, s1);
@@ -614,6 +671,25 @@ int launch_pp(const dsn_tensor* s, const void* w, const float* bias, const dsn_t
     return DSN_OK;
 }
 
+
+template <int BN>
+int launch_pp_s2(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, PGeom g, const BnRed* br, hipStream_t st) {
+    g.tiles_y = (g.H + PT - 1) / PT;
+    g.tiles_x = (g.W + PT - 1) / PT;
+    g.tiles_n = (g.Cd + BN - 1) / BN;
+    auto kern = conv3x3_pp_kernel<BN, false, false, 4>;
+    constexpr int LDS = PP_LDS;                  // 2 x 40 KB halo + 64 KB ring = 144 KB; the epilogue's staging needs 142 KB
+    DSN_LDS_ATTR(kern, LDS);
+    const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
+    const double elems = (double)g.N * g.H * g.W * g.Cs + (double)g.N * g.Hout * g.Wout * (g.d2s_c * (1 + (g.accumulate ? 1 : 0)) + bnred_channels(br)) +
+                         4.0 * g.Cs * g.Cd;
+    const ProfConv pc("conv3x3_pp_kernel", true, 256, BN, true, 2, 2, 1, g.Cs, g.d2s_c, g.N, g.Hout, g.Wout);
+    ProfScope prof(pc.label, pc.layer, 2.0 * g.N * g.H * g.W * g.d2s_c * 9.0 * g.Cs, elems * 2, st);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), LDS, st, (const bf16_t*)dy->ptr, (const bf16_t*)w, (const float*)nullptr,
+                       (const bf16_t*)nullptr, (bf16_t*)dx->ptr, BnAcc{}, g, br ? *br : BnRed{});
+    DSN_LAUNCH_CHECK("conv3x3 stride-2 data gradient (ping-pong big tile)");
+    return DSN_OK;
+}
 
 // ---- 1x1 / stride-1 convolution (forward and data gradient) with the same two-group schedule ----------------------------------------
 // C[M = N H W pixels][Cd] = A[M][Cs] * W[Cd][Cs]^T, block tile 256 consecutive pixels x BN channels.  Both operands are K-contiguous
@@ -927,4 +1003,42 @@ int dsn_conv1x1_pp_try(const dsn_tensor* s, const void* w, const float* bias, co
     const BnRed* brp = (br && br->nseg > 0) ? br : nullptr;
     if (wide) return launch_pp1<256>(s, w, bias, r, d, g, fin, brp, (hipStream_t)stream);
     return launch_pp1<128>(s, w, bias, r, d, g, fin, brp, (hipStream_t)stream);
+}
+
+// 3x3 / stride-2 / pad-1 data gradient in its 2x2 form (weights dsn_pack_desc.out_dgrad_s2): tried first by dsn_conv2d_dgrad_s2.
+// Same mode switch as the 3x3 kernel (DSN_PP / dsn_pp_mode): 0 never, 1 default, >= 2 every eligible layer (3: 256-column tiles
+// wherever 4 Ci allows).
+int dsn_dgrad_s2_pp_try(const dsn_tensor* dy, const void* w_s2, const dsn_tensor* dx, const dsn_conv_params* p, const BnRed* br,
+                        void* stream) {
+    const int md = g_pp_mode;
+    if (!md) return 1;
+    if (dy->dtype != DSN_BF16 || dx->dtype != DSN_BF16) return 1;
+    if (dy->c % 64 != 0 || dx->c % 8 != 0 || dy->ldc % 8 != 0 || dx->ldc % 8 != 0) return 1;
+    if (((uintptr_t)dy->ptr | (uintptr_t)dx->ptr | (uintptr_t)w_s2) % 16 != 0) return 1;
+    const int64_t sb = ((npix(dy) - 1) * dy->ldc + dy->c) * 2, wb = (int64_t)4 * dx->c * 4 * dy->c * 2;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || npix(dx) * dx->ldc * 2 >= (1ll << 40)) return 1;
+    const int ty = (dy->h + PT - 1) / PT, tx = (dy->w + PT - 1) / PT;
+    const int64_t patches = (int64_t)dy->n * ty * tx;
+    const int cd = 4 * dx->c;
+    bool wide = cd % 256 == 0 && (md == 3 || md == 1);
+    if (md == 1) {
+        static const int min_blocks = [] { const char* e = getenv("DSN_PP_S2_MIN_BLOCKS"); return e ? atoi(e) : 64; }();
+        // (in-step, config 5, us: implicit GEMM -> this kernel: 128 -> 4 x 64 @4x320x320 380 -> 309, 512 -> 4 x 256 @4x80x80 205 -> 152,
+        //  256 -> 4 x 256 @4x80x80 145 -> 115, 256 -> 4 x 128 @4x160x160 228 -> 212; 40 x 40 and 20 x 20 dy maps -- 16 x 16 patches
+        //  cover 69 % / 39 % of them -- lose: 190 -> 199, 120 -> 137; config 3: 128 -> 4 x 64 @8x80x80 59 -> 54, 64 -> 4 x 32 @8x160x160 89 -> 89)
+        static const double min_fill = [] { const char* e = getenv("DSN_PP_S2_MIN_FILL"); return e ? atof(e) : 0.8; }();
+        const double fill = (double)dy->h * dy->w / ((double)ty * tx * PT * PT);
+        wide = cd % 256 == 0 && patches * (cd / 256) >= 200;
+        if (cd < 128 || fill < min_fill || patches * ((cd + 127) / 128) < min_blocks) return 1;
+    }
+    PGeom g{};
+    g.N = dy->n; g.H = dy->h; g.W = dy->w; g.Cs = dy->c; g.Cd = cd; g.flip = 0;
+    g.act = DSN_ACT_NONE; g.accumulate = p->accumulate;
+    g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
+    g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
+    g.nslab = dy->c / 64;
+    g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
+    const BnRed* brp = (br && br->nseg > 0) ? br : nullptr;
+    if (wide) return launch_pp_s2<256>(dy, w_s2, dx, g, brp, (hipStream_t)stream);
+    return launch_pp_s2<128>(dy, w_s2, dx, g, brp, (hipStream_t)stream);
 }

@@ -1850,6 +1850,12 @@ int dsn_dgrad_s2_ws_try(const dsn_tensor* dy, const void* w_s2, const dsn_tensor
                         void* stream) {
     static const int mode = [] { const char* e = getenv("DSN_WS_S2"); return e ? atoi(e) : 1; }();
     if (!mode || !g_ws_mode[0]) return 1;
+    // With the BatchNorm-backward sums this form is OFF unless DSN_WS_S2=2: round 4 found its sums off by 2-20 % against the
+    // stand-alone reduction on grids of 800 / 1600 / 2048 tiles with 32 channels per parity (8x32->64 @160, 2x32->64 @320,
+    // 16x32->64 @128: the stores are right, some channels' sums are not -- the extras' loads are not all behind the counted
+    // wait); config 3's own shapes (6400 tiles; 64 channels per parity) agree to 4e-7.  These layers now run on the 2x2 form of
+    // the ping-pong kernel (conv_pp.hip), the others on the implicit GEMM; tests/test_pp_gpu.py checks both against the reduction.
+    if (br && br->nseg > 0 && mode < 2) return 1;
     if (dy->dtype != DSN_BF16 || dx->dtype != DSN_BF16) return 1;
     if (dy->c % 8 != 0 || dx->c % 8 != 0 || dy->ldc % 8 != 0 || dx->ldc % 8 != 0) return 1;
     if (((uintptr_t)dy->ptr | (uintptr_t)dx->ptr | (uintptr_t)w_s2) % 16 != 0) return 1;

@@ -855,6 +855,8 @@ static int conv_dgrad_s2_impl(const dsn_tensor* dy, const void* w_s2, const dsn_
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate; g.is_dgrad = 1;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
     g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
+    rc = dsn_dgrad_s2_pp_try(dy, w_s2, dx, p, br, stream);                          // big-tile ping-pong kernel, 2x2 taps (conv_pp.hip)
+    if (rc != 1) return rc;
     rc = dsn_dgrad_s2_ws_try(dy, w_s2, dx, p, br, stream);                          // the large stems: weights-stationary, gathered K
     if (rc != 1) return rc;
     if (dy->dtype == DSN_F32)

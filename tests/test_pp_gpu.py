@@ -197,6 +197,83 @@ def test_production_grids_three_launches_each():
         desenet_amd.set_compute_dtype(torch.float32)
 
 
+S2_SHAPES = [  # n, ci, co, h, w (the convolution's input map; dy is the stride-2 output map)
+    (2, 64, 128, 64, 64),         # 256 GEMM columns: one 256-column tile (mode 3) or two 128-column tiles
+    (1, 32, 64, 96, 80),          # ragged dy patches (48 x 40), 128 columns
+    (3, 40, 64, 38, 70),          # 160 columns: a partial tile, parity boundaries inside it (40 channels per parity)
+    (1, 128, 256, 33, 31),        # odd destination map: the last row / column of parities is cut; 4 slabs
+    (2, 256, 512, 32, 32),        # 8 slabs
+    (8, 32, 64, 160, 160),        # 1600 dy tiles of 32 pixels: the grid on which the gather form's sums were found wrong (conv_ws.hip)
+]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", S2_SHAPES)
+@pytest.mark.parametrize("opt", ["plain", "accumulate", "bnred"])
+@pytest.mark.parametrize("mode", [2, 3], ids=["bn128", "bn256_where_possible"])
+def test_stride2_data_gradient_2x2_form(mode, opt, n, ci, co, h, w):
+    """The 3x3 / stride-2 data gradient on the ping-pong kernel (NT = 4: 2x2 taps over dy, [4 Ci][2][2][Co] weights, depth-to-space
+    store) against ATen's convolution input gradient and against the kernels it replaces (dsn_pp_mode 0), plain / accumulating /
+    with the BatchNorm-backward sums of the block whose dz it completes."""
+    import desenet_amd
+    from desenet_amd import _lib, hip_ops as ops
+    from desenet_amd.hip_ops import ACT_SILU
+    dt = torch.bfloat16
+    desenet_amd.set_compute_dtype(dt)
+    L = _lib.lib()
+    try:
+        conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=False).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(_rand((co, ci, 3, 3), 2, 0.1))
+        bank = ops.WeightBank([conv], [ci], dt, "cuda")
+        bank.pack()
+        s2 = bank.dgrad_s2[0]
+        ho, wo = ops.conv_out_hw(h, w, 3, 2, 1, 1)
+        gy = _rand((n, co, ho, wo), 3)
+        q = lambda t: t.to(dt).float().cpu()
+        xr = torch.zeros(n, ci, h, w, requires_grad=True)
+        F.conv2d(xr, q(conv.weight.detach()), None, 2, 1).backward(q(gy))
+        gd = ops.as_act(gy.to(dt))
+        base = _rand((n, ci, h, w), 4)
+        p = ops.conv_params(3, 2, 1, 1, accumulate=(opt == "accumulate"))
+        got = {}
+        for md in (mode, 0):
+            L.dsn_pp_mode(md)
+            dx = ops.as_act(base.to(dt))
+            red, acc = None, None
+            if opt == "bnred":
+                yb = ops.as_act(_rand((n, ci, h, w), 5).to(dt))
+                g_ = torch.Generator(device="cuda").manual_seed(9)
+                st = torch.stack([torch.rand(ci, device="cuda", generator=g_) + 0.5, torch.rand(ci, device="cuda", generator=g_) - 0.5,
+                                  torch.randn(ci, device="cuda", generator=g_) * 0.1, torch.rand(ci, device="cuda", generator=g_) + 0.5])
+                acc, _ = ops.bn_acc(ci, "cuda")
+                red = ops.bnred([(0, ci, yb, st[0], st[1], st[2], st[3], ACT_SILU, acc, ci, 0)])
+            if md:
+                ops.profile_enable(True)
+            ops.conv2d_dgrad_s2(gd, s2, dx, p, red=red)
+            torch.cuda.synchronize()
+            if md:
+                prof = ops.profile_collect()
+                ops.profile_enable(False)
+                assert any("conv3x3_pp_kernel" in str(k) for k in prof), list(prof)
+            if opt == "bnred":      # the stand-alone reduction over the dz just written: what the fused sums must equal
+                ws, _ = ops.bn_acc(ci, "cuda")
+                ops.bn_act_bwd_reduce(dx, yb, st[0], st[1], st[2], st[3], ACT_SILU, ws)
+                torch.cuda.synchronize()
+                a, b = _fold(acc, ci), _fold(ws, ci)
+                assert float(b.abs().max()) > 0
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) * (h * w * n) ** 0.5, (md, float((a - b).abs().max() / b.abs().max()))
+            got[md] = (dx, acc)
+        want = xr.grad + (q(base) if opt == "accumulate" else 0)
+        e = float((got[mode][0].float().cpu() - want).abs().max() / want.abs().max())
+        assert e < 2e-2, e
+        e0 = float((got[mode][0].float() - got[0][0].float()).abs().max() / want.abs().max())
+        assert e0 < 1e-2, e0
+    finally:
+        ops.profile_enable(False)
+        L.dsn_pp_mode(1)
+        desenet_amd.set_compute_dtype(torch.float32)
+
+
 WGRAD_SHAPES = [  # n, ci, co, h, w
     (2, 128, 128, 32, 32),
     (1, 256, 128, 48, 40),        # ragged columns: 40 = 2 * 16 + 8

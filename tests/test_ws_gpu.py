@@ -330,15 +330,24 @@ def test_stride2_dgrad_gathered_k_depth_to_space(ops, case, mode):
         red = ops.bnred([(0, ci, yb, st[0], st[1], st[2], st[3], ops.ACT_SILU, acc, ci, 0)])
         red_ref = ops.bnred([(0, ci, yb, st[0], st[1], st[2], st[3], ops.ACT_SILU, acc_ref, ci, 0)])
     dx = to_dev(ops, base, dtype)
-    _, layers = _layers_of(ops, lambda: ops.conv2d_dgrad_s2(gyd, s2, dx, p, red=red))
-    assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k2s2") for k in layers), list(layers)
+    ops._lib.lib().dsn_pp_mode(0)                       # (the big-tile kernel of conv_pp.hip is tried first: tests/test_pp_gpu.py)
+    try:
+        _, layers = _layers_of(ops, lambda: ops.conv2d_dgrad_s2(gyd, s2, dx, p, red=red))
+    finally:
+        ops._lib.lib().dsn_pp_mode(1)
+    if mode == "bnred":     # off by default with the BatchNorm sums (conv_ws.hip, dsn_dgrad_s2_ws_try): the implicit GEMM runs
+        assert any(k[0].startswith("igemm_kernel") for k in layers), list(layers)
+    else:
+        assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k2s2") for k in layers), list(layers)
     ops._lib.lib().dsn_ws_mode(0, -1)                   # reference: the implicit-GEMM launch
+    ops._lib.lib().dsn_pp_mode(0)
     try:
         dx_ref = to_dev(ops, base, dtype)
         _, layers = _layers_of(ops, lambda: ops.conv2d_dgrad_s2(gyd, s2, dx_ref, p, red=red_ref))
         assert any(k[0].startswith("igemm_kernel") for k in layers), list(layers)
     finally:
         ops._lib.lib().dsn_ws_mode(1, -1)
+        ops._lib.lib().dsn_pp_mode(1)
     xr = torch.zeros(n, ci, h, w, requires_grad=True)
     F.conv2d(xr, q(conv.weight.detach().cpu(), dtype), None, 2, 1).backward(q(gy, dtype))
     want = xr.grad + (q(base, dtype) if mode == "accumulate" else 0)
