@@ -524,7 +524,12 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
         if constexpr (EX) {
             // extras(t) were requested one tile ago: younger in the queue are DMA(t + 1), stores(t - 1), extras(t + 1), DMA(t + 2)
             // (first tile: requested in the prologue, behind it only extras(t + 1) and DMA(t + 2))
-            if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL + LPT) : "memory");
+            // G = 2 (stride-2 data gradient): FULL drain.  The counted form below gave wrong BatchNorm-backward sums on grids with 1-4
+            // tiles per block (round 4: either wait replaced by vmcnt(0) cures it, tighter counts do not -- the operations that
+            // retire out of the assumed order are among the all-out-of-range ones of the tiles past a block's share); the drain
+            // costs the DMA prefetch of one tile per step of these HBM-bound launches.
+            if (G == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL + LPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT + ST + XS::XL) : "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1850,12 +1855,10 @@ int dsn_dgrad_s2_ws_try(const dsn_tensor* dy, const void* w_s2, const dsn_tensor
                         void* stream) {
     static const int mode = [] { const char* e = getenv("DSN_WS_S2"); return e ? atoi(e) : 1; }();
     if (!mode || !g_ws_mode[0]) return 1;
-    // With the BatchNorm-backward sums this form is OFF unless DSN_WS_S2=2: round 4 found its sums off by 2-20 % against the
-    // stand-alone reduction on grids of 800 / 1600 / 2048 tiles with 32 channels per parity (8x32->64 @160, 2x32->64 @320,
-    // 16x32->64 @128: the stores are right, some channels' sums are not -- the extras' loads are not all behind the counted
-    // wait); config 3's own shapes (6400 tiles; 64 channels per parity) agree to 4e-7.  These layers now run on the 2x2 form of
-    // the ping-pong kernel (conv_pp.hip), the others on the implicit GEMM; tests/test_pp_gpu.py checks both against the reduction.
-    if (br && br->nseg > 0 && mode < 2) return 1;
+    // (Round 4: with the BatchNorm-backward sums the COUNTED wait in front of the extras gave wrong sums on grids of 1-4 tiles per
+    //  block -- 8x32->64 @160, 2x32->64 @320, 16x32->64 @128: 2-20 % off the stand-alone reduction, stores bit-identical; the kernel
+    //  now drains there, see tile_step; tests/test_pp_gpu.py::test_stride2_data_gradient_2x2_form holds every stride-2 dgrad kernel
+    //  to the reduction on those grids.)
     if (dy->dtype != DSN_BF16 || dx->dtype != DSN_BF16) return 1;
     if (dy->c % 8 != 0 || dx->c % 8 != 0 || dy->ldc % 8 != 0 || dx->ldc % 8 != 0) return 1;
     if (((uintptr_t)dy->ptr | (uintptr_t)dx->ptr | (uintptr_t)w_s2) % 16 != 0) return 1;

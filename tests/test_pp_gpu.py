@@ -203,7 +203,9 @@ S2_SHAPES = [  # n, ci, co, h, w (the convolution's input map; dy is the stride-
     (3, 40, 64, 38, 70),          # 160 columns: a partial tile, parity boundaries inside it (40 channels per parity)
     (1, 128, 256, 33, 31),        # odd destination map: the last row / column of parities is cut; 4 slabs
     (2, 256, 512, 32, 32),        # 8 slabs
-    (8, 32, 64, 160, 160),        # 1600 dy tiles of 32 pixels: the grid on which the gather form's sums were found wrong (conv_ws.hip)
+    (8, 32, 64, 160, 160),        # 1600 dy tiles of 32 pixels: the grids on which the gather form's sums were found wrong (conv_ws.hip;
+    (2, 32, 64, 320, 320),        # mode 0 runs that form here, now with a full drain in front of its extras)
+    (16, 32, 64, 128, 128),
 ]
 
 

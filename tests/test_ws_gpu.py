@@ -335,10 +335,7 @@ def test_stride2_dgrad_gathered_k_depth_to_space(ops, case, mode):
         _, layers = _layers_of(ops, lambda: ops.conv2d_dgrad_s2(gyd, s2, dx, p, red=red))
     finally:
         ops._lib.lib().dsn_pp_mode(1)
-    if mode == "bnred":     # off by default with the BatchNorm sums (conv_ws.hip, dsn_dgrad_s2_ws_try): the implicit GEMM runs
-        assert any(k[0].startswith("igemm_kernel") for k in layers), list(layers)
-    else:
-        assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k2s2") for k in layers), list(layers)
+    assert any(k[0].startswith("conv1x1_ws_kernel") and k[1].startswith("k2s2") for k in layers), list(layers)
     ops._lib.lib().dsn_ws_mode(0, -1)                   # reference: the implicit-GEMM launch
     ops._lib.lib().dsn_pp_mode(0)
     try:

@@ -7,7 +7,7 @@ dt = torch.bfloat16
 desenet_amd.set_compute_dtype(dt)
 L = _lib.lib()
 def fold(a, c): return a.view(torch.float64)[:8 * 2 * c].view(8, 2, c).sum(0)
-for (n, ci, co, h, w) in [(8, 32, 64, 320, 320), (8, 64, 128, 160, 160), (8, 32, 64, 160, 160), (8, 32, 64, 224, 224), (2, 32, 64, 320, 320), (8, 32, 64, 304, 304), (8, 64, 128, 152, 152), (4, 64, 128, 320, 320), (16, 32, 64, 128, 128), (8, 32, 64, 192, 192)]:
+for (n, ci, co, h, w) in [(8, 32, 64, 160, 160), (2, 32, 64, 320, 320), (16, 32, 64, 128, 128), (4, 32, 64, 160, 160), (8, 32, 64, 320, 320), (8, 64, 128, 160, 160)]:
     torch.manual_seed(0)
     conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=False).cuda()
     bank = ops.WeightBank([conv], [ci], dt, "cuda"); bank.pack()
