@@ -8,6 +8,10 @@ from desenet_amd.hip_ops import ACT_SILU
 dt = torch.bfloat16
 desenet_amd.set_compute_dtype(dt)
 L = _lib.lib()
+import os
+if os.environ.get("DBG_WS3"):      # extras variants of the weights-stationary kernels on every eligible shape
+    L.dsn_ws_mode(3, 3)
+    L.dsn_pp_mode(0); L.dsn_pp1_mode(0)
 def fold(a, c): return a.view(torch.float64)[:8 * 2 * c].view(8, 2, c).sum(0)
 bad = 0
 shapes = []
@@ -15,7 +19,9 @@ for k in (1, 3):
     for (n, ci, co, h, w) in [(8, 64, 64, 80, 80), (8, 128, 64, 80, 80), (8, 64, 128, 80, 80), (8, 128, 128, 40, 40), (8, 256, 256, 20, 20), (8, 32, 32, 160, 160),
                               (4, 128, 128, 160, 160), (2, 64, 64, 80, 80), (16, 64, 64, 64, 64), (8, 64, 64, 100, 100), (3, 128, 128, 50, 50), (8, 256, 128, 40, 40),
                               (8, 128, 256, 40, 40), (8, 512, 512, 20, 20), (4, 256, 256, 80, 80), (4, 512, 256, 80, 80), (1, 64, 64, 160, 160), (5, 32, 64, 72, 72),
-                              (8, 64, 32, 160, 160), (2, 128, 128, 80, 80), (6, 64, 64, 56, 56)]:
+                              (8, 64, 32, 160, 160), (2, 128, 128, 80, 80), (6, 64, 64, 56, 56), (1, 64, 64, 80, 80), (1, 128, 128, 64, 64), (2, 256, 64, 48, 48),
+                              (1, 192, 128, 96, 96), (4, 64, 64, 40, 40), (2, 64, 32, 100, 100), (1, 256, 256, 40, 40), (3, 192, 64, 64, 64), (1, 64, 64, 320, 320),
+                              (16, 64, 64, 32, 32), (2, 128, 32, 128, 128), (1, 128, 64, 200, 200)]:
         shapes.append((k, n, ci, co, h, w))
 for (k, n, ci, co, h, w) in shapes:
     torch.manual_seed(0)
