@@ -192,6 +192,7 @@ PROTOTYPES = {
     "dsn_ws_mode": (i32, [i32, i32]),
     "dsn_pp_mode": (i32, [i32]),
     "dsn_pp1_mode": (i32, [i32]),
+    "dsn_pp_dir": (i32, [i32]),
     "dsn_wgrad_pp_mode": (i32, [i32]),
     "dsn_pp_stages_supported": (i32, [i32, i32, i32, i32]),
     "dsn_pp_stages_fwd": (i32, [C.POINTER(dsn_pp_args), vp]),

@@ -219,6 +219,16 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
 __device__ unsigned long long pp_stamp_buf[6 * 4096];
 #endif
 
+// DIR variants: MFMA operands swapped (A = weights, B = pixels), so that a lane's accumulators are 4 consecutive channels of ONE pixel;
+// the weight rows of each 32-channel group are permuted in LDS (by the DMA's source addressing) so that the accumulators of the
+// MFMA pair (2q, 2q + 1) are 8 consecutive channels: physical row r of a piece holds channel pp_perm_row(r) of the tile.
+__device__ __forceinline__ int pp_perm_row(int r) { return (r & ~31) + (((r & 15) >> 2) << 3) + (((r >> 4) & 1) << 2) + (r & 3); }
+
+template <int BN, bool TWO, int MH, bool LIN, bool D2S>
+__device__ __forceinline__ void pp_epilogue_direct(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
+                                                  const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
+                                                  const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi);
+
 template <int BN, bool TWO, int MH, bool LIN = false, bool D2S = false>
 __device__ __forceinline__ void conv3x3_pp_epilogue(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
                                                    const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
@@ -229,7 +239,7 @@ __device__ __forceinline__ void conv3x3_pp_epilogue(f32x4 (&acc)[MH][4][4], unsi
 // NT = 4: the 2x2 / stride-1 form of the 3x3 / stride-2 data gradient (igemm.hip, dsn_conv2d_dgrad_s2): taps (ty, tx) in {0, 1}^2
 // read dy at (y + ty, x + tx) -- a 17 x 17 halo with the patch in its top-left corner --, weights [4 Ci][2][2][Co], 8 k-halves per
 // slab, depth-to-space store.  Ring: 8 x 8 KB, distance 6 (BN 128) / 4 x 16 KB, distance 3 (BN 256); halo buffers 2 x 40 KB.
-template <int BN, bool FLIP, bool TWO, int NT = 9>
+template <int BN, bool FLIP, bool TWO, int NT = 9, bool DIR = false>
 __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk,
                                                          const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                          bf16_t* __restrict__ dst, const BnAcc fin, const PGeom g, const BnRed br) {
@@ -304,8 +314,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
     uint32_t woff[GW];
 #pragma unroll
     for (int part = 0; part < GW; ++part) {
-        const int row = 16 * (wave + 8 * part) + (lane >> 2);
-        const int ls = (lane & 3) ^ ((-(lane >> 4)) & 3);             // ((row >> 2) & 3) == lane >> 4: logical slot of this lane
+        const int prow = 16 * (wave + 8 * part) + (lane >> 2);         // physical row of the piece
+        const int row = DIR ? pp_perm_row(prow) : prow;               // channel of the tile it holds
+        const int ls = (lane & 3) ^ ((-(lane >> 4)) & 3);             // ((prow >> 2) & 3) == lane >> 4: logical slot of this lane
         woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * NT * g.Cs + ls * VEC) * 2u : OOB;
     }
     const int T_ALL = g.nslab * KH;                                   // k-halves
@@ -396,8 +407,8 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[mh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                               __builtin_bit_cast(bf16x8, fb[j]), acc[mh][i][j], 0, 0, 0);
+                        acc[mh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, DIR ? fb[j] : fa[i]),
+                                                                               __builtin_bit_cast(bf16x8, DIR ? fa[i] : fb[j]), acc[mh][i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -451,7 +462,8 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[m][i][j]));
-    conv3x3_pp_epilogue<BN, TWO, MH, false, NT == 4>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
+    if constexpr (DIR) pp_epilogue_direct<BN, TWO, MH, false, NT == 4>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
+    else conv3x3_pp_epilogue<BN, TWO, MH, false, NT == 4>(acc, smem, bias, res, dst, fin, g, br, n, y0, x0, n0, tmi);
 #ifdef DSN_PP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && blockIdx.x < 4096) pp_stamp_buf[6 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime() - st_r1;
@@ -651,13 +663,210 @@ __device__ __forceinline__ void conv3x3_pp_epilogue_impl(f32x4 (&acc)[MH][4][4],
     }
 }
 
+
+// ---- epilogue straight from the accumulator registers (DIR) -----------------------------------------------------------------------------
+// Lane (fr, fg) of wave (grp, wm, wn) owns pixel row 16 py + fr of the tile for py = 8 grp + 4 (MH == 2 ? mh : wm) + i and the two channel
+// vectors wn 64 + q 32 + fg 8 .. + 8 (q = 0, 1): no LDS staging tile, no second pass; 16-byte stores, 64 contiguous bytes per pixel
+// and wave instruction.  The operands the epilogue reads (shortcut, old value, y of the BatchNorm-backward sums) are fetched one
+// (mh, i) step ahead.  BatchNorm sums (forward) / BatchNorm-backward sums stay in 32 registers per lane and are folded over the 16
+// pixel lanes by shuffles, over the waves of a column through LDS ([8][64][2] floats at the start of the dead LDS; the per-channel
+// constants of the backward sums in a table behind it).
+template <int BN, bool TWO, int MH, bool LIN, bool D2S>
+__device__ __forceinline__ void pp_epilogue_direct(f32x4 (&acc)[MH][4][4], unsigned char* smem, const float* __restrict__ bias,
+                                                  const bf16_t* __restrict__ res, bf16_t* __restrict__ dst, const BnAcc& fin,
+                                                  const PGeom& g, const BnRed& br, int n, int y0, int x0, int n0, int tmi) {
+    typedef bf16_t T;
+    constexpr int WGN = BN == 128 ? 2 : 4;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wq = wave & 3;
+    const int wm = wq / WGN, wn = wq % WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+    float* red = reinterpret_cast<float*>(smem);          // [8 waves][64 columns][2]
+    float* tab = red + 1024;                              // [4][BN]: scale | shift | mean | rstd of the block's columns
+    const int vh = (g.H - y0 < PT) ? g.H - y0 : PT, vw = (g.W - x0 < PT) ? g.W - x0 : PT;
+    const int64_t m0 = (int64_t)tmi * 256;
+    const int vrows = LIN ? (int)((int64_t)g.N * g.H * g.W - m0 < 256 ? (int64_t)g.N * g.H * g.W - m0 : 256) : 256;
+    auto valid = [&](int rl) { return LIN ? rl < vrows : ((rl >> 4) < vh && (rl & 15) < vw); };
+    int col[2], cch[2], par[2];
+    bool okc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        col[q] = n0 + wn * 64 + q * 32 + fg * 8;
+        okc[q] = col[q] < g.Cd;
+        par[q] = D2S ? col[q] / g.d2s_c : 0;
+        cch[q] = D2S ? col[q] - par[q] * g.d2s_c : col[q];
+    }
+    // destination pixel row of tile row rl for vector q (-1: nothing stored)
+    auto rowof = [&](int rl, int q) -> int64_t {
+        if (!valid(rl) || !okc[q]) return -1;
+        if (LIN) return m0 + rl;
+        if (!D2S) return ((int64_t)n * g.H + y0 + (rl >> 4)) * g.W + x0 + (rl & 15);
+        const int yy = 2 * (y0 + (rl >> 4)) + (par[q] >> 1), xx = 2 * (x0 + (rl & 15)) + (par[q] & 1);
+        return (yy < g.Hout && xx < g.Wout) ? ((int64_t)n * g.Hout + yy) * g.Wout + xx : -1;
+    };
+    // BatchNorm-backward sums: the segment of each of the lane's vectors, the block's table of constants
+    const T* yp[2] = {nullptr, nullptr};
+    int64_t yld[2] = {0, 0};
+    int yact[2] = {0, 0};
+    if (br.nseg) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            for (int sg = 0; sg < br.nseg; ++sg) {
+                const dsn_bnred_seg& z = br.seg[sg];
+                if (okc[q] && cch[q] >= z.c0 && cch[q] < z.c1) {
+                    yp[q] = (const T*)z.y + (cch[q] - z.c0);
+                    yld[q] = z.yld;
+                    yact[q] = z.act;
+                }
+            }
+        if (tid < BN) {
+            const int c = n0 + tid;
+            PpRed<1, false>::fill(br, tab, BN, tid, D2S ? c % g.d2s_c : c);
+        }
+        __syncthreads();
+    }
+    float bq[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bq[q][k] = (bias && okc[q]) ? bias[col[q] + k] : 0.f;
+    float s0[2][8], s1[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s0[q][k] = s1[q][k] = 0.f;
+
+    u32x4 rv[2][2], ov[2][2], yv[2][2];          // [stage][q]: shortcut, old value, y -- fetched one step ahead
+    auto tile_row = [&](int mi) { return (8 * grp + 4 * (MH == 2 ? (mi >> 2) : wm) + (mi & 3)) * 16 + fr; };
+    auto fetch = [&](int mi, int st) {
+        const int rl = tile_row(mi);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t row = rowof(rl, q);
+            if (row < 0) continue;
+            if (res) rv[st][q] = *reinterpret_cast<const u32x4*>(res + row * g.rld + cch[q]);
+            if (g.accumulate) ov[st][q] = *reinterpret_cast<const u32x4*>(dst + row * g.dld + cch[q]);
+            if (yp[q]) yv[st][q] = *reinterpret_cast<const u32x4*>(yp[q] + row * yld[q]);
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MH * 4; ++mi) {
+        const int st = mi & 1, mh = mi >> 2, i = mi & 3;
+        if (mi + 1 < MH * 4) fetch(mi + 1, st ^ 1);
+        const int rl = tile_row(mi);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t row = rowof(rl, q);
+            float vals[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vals[k] = acc[mh][i][2 * q + (k >> 2)][k & 3] + bq[q][k];
+            apply_act_vec<8>(vals, g.act);
+            if (fin.acc) {          // (forward: no shortcut / accumulate / activation in front of the statistics)
+                const bool in = okc[q] && valid(rl);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float t = in ? vals[k] : 0.f;
+                    s0[q][k] += t;
+                    s1[q][k] += t * t;
+                }
+            }
+            if (row < 0) continue;
+            if (res) {
+                T r8[8];
+                *reinterpret_cast<u32x4*>(r8) = rv[st][q];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vals[k] += to_f32<T>(r8[k]);
+            }
+            if (g.accumulate) {
+                T o8[8];
+                *reinterpret_cast<u32x4*>(o8) = ov[st][q];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vals[k] += to_f32<T>(o8[k]);
+            }
+            T outv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) outv[k] = from_f32<T>(vals[k]);
+            *reinterpret_cast<u32x4*>(dst + row * g.dld + cch[q]) = *reinterpret_cast<u32x4*>(outv);
+            if (yp[q]) {
+                T yl[8];
+                *reinterpret_cast<u32x4*>(yl) = yv[st][q];
+                const float* tc = tab + wn * 64 + q * 32 + fg * 8;
+#pragma unroll
+                for (int k = 0; k < 8; k += 4) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(tc + k), sh = *reinterpret_cast<const f32x4*>(tc + BN + k);
+                    float u[4], gr[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[e] = (float)yl[k + e] * sc[e] + sh[e];
+                    act_grad_vec<4>(u, yact[q], gr);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(tc + 2 * BN + k), rs = *reinterpret_cast<const f32x4*>(tc + 3 * BN + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = (float)yl[k + e];
+                        const float gk = (float)outv[k + e] * gr[e];
+                        s0[q][k + e] += gk;
+                        s1[q][k + e] += gk * ((y - mu[e]) * rs[e]);
+                    }
+                }
+            }
+        }
+    }
+    if (fin.acc || br.nseg) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s0[q][k] += __shfl_xor(s0[q][k], o);
+                    s1[q][k] += __shfl_xor(s1[q][k], o);
+                }
+                if (fr == 0) {
+                    red[(wave * 64 + q * 32 + fg * 8 + k) * 2] = s0[q][k];
+                    red[(wave * 64 + q * 32 + fg * 8 + k) * 2 + 1] = s1[q][k];
+                }
+            }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cd) {
+            const int wn_ = tid >> 6, ci = tid & 63;
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int wm_ = 0; wm_ < 4 / WGN; ++wm_) {
+                    const int w = gq * 4 + wm_ * WGN + wn_;
+                    t0 += red[(w * 64 + ci) * 2];
+                    t1 += red[(w * 64 + ci) * 2 + 1];
+                }
+            if (fin.acc) {
+                bn_acc_add(fin, tmi, n0 + tid, t0, t1);
+            } else {
+                const int ch = D2S ? (n0 + tid) % g.d2s_c : n0 + tid;
+                for (int sg = 0; sg < br.nseg; ++sg) {
+                    const dsn_bnred_seg& z = br.seg[sg];
+                    if (ch >= z.c0 && ch < z.c1) bn_acc_add(BnAcc{(double*)z.acc, z.acc_c, 0.0}, tmi, z.ch0 + ch - z.c0, t0, t1);
+                }
+            }
+        }
+    }
+}
+
+// epilogue form: 1 = straight from the accumulator registers (pp_epilogue_direct), 0 = staged through LDS (DSN_PP_DIR, dsn_pp_dir())
+int g_pp_dir = getenv("DSN_PP_DIR") ? atoi(getenv("DSN_PP_DIR")) : 0;
+inline bool pp_dir() { return g_pp_dir != 0; }
+
 template <int BN, bool TWO>
 int launch_pp(const dsn_tensor* s, const void* w, const float* bias, const dsn_tensor* r, const dsn_tensor* d, PGeom g, const BnAcc& fin,
               const BnRed* br, hipStream_t st) {
     g.tiles_y = (g.H + PT - 1) / PT;
     g.tiles_x = (g.W + PT - 1) / PT;
     g.tiles_n = (g.Cd + BN - 1) / BN;
-    auto kern = g.flip ? conv3x3_pp_kernel<BN, true, TWO> : conv3x3_pp_kernel<BN, false, TWO>;
+    // (the register epilogue exists for the 128-channel one-block-per-CU tile: with 128 live accumulators or a 128-VGPR budget it spills)
+    constexpr bool CAN_DIR = BN == 128 && !TWO;
+    auto kern = (CAN_DIR && pp_dir()) ? (g.flip ? conv3x3_pp_kernel<BN, true, TWO, 9, CAN_DIR> : conv3x3_pp_kernel<BN, false, TWO, 9, CAN_DIR>)
+                                      : (g.flip ? conv3x3_pp_kernel<BN, true, TWO> : conv3x3_pp_kernel<BN, false, TWO>);
     constexpr int LDS = TWO ? PP_LDS_TWO : PP_LDS;
     DSN_LDS_ATTR(kern, LDS);
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
@@ -677,7 +886,8 @@ int launch_pp_s2(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, PGeo
     g.tiles_y = (g.H + PT - 1) / PT;
     g.tiles_x = (g.W + PT - 1) / PT;
     g.tiles_n = (g.Cd + BN - 1) / BN;
-    auto kern = conv3x3_pp_kernel<BN, false, false, 4>;
+    constexpr bool CAN_DIR = BN == 128;
+    auto kern = (CAN_DIR && pp_dir()) ? conv3x3_pp_kernel<BN, false, false, 4, CAN_DIR> : conv3x3_pp_kernel<BN, false, false, 4>;
     constexpr int LDS = PP_LDS;                  // 2 x 40 KB halo + 64 KB ring = 144 KB; the epilogue's staging needs 142 KB
     DSN_LDS_ATTR(kern, LDS);
     const int blocks = g.N * g.tiles_y * g.tiles_x * g.tiles_n;
@@ -699,7 +909,7 @@ int launch_pp_s2(const dsn_tensor* dy, const void* w, const dsn_tensor* dx, PGeo
 // halves -- the first phase of a k-half refills the B part and the A rows of pixel half 0 (last read two phases earlier), the
 // second phase the A rows of pixel half 1 (the same rule as above: refill no earlier than two phases after the read).
 // Per wave and piece: 2 A DMAs (rows 16 py .. + 16 for the wave's py of each pixel half) + BN / 128 B DMAs, a static schedule.
-template <int BN>
+template <int BN, bool DIR = false>
 __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk,
                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res,
                                                             bf16_t* __restrict__ dst, const BnAcc fin, const PGeom g, const BnRed br) {
@@ -743,7 +953,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
     }
 #pragma unroll
     for (int part = 0; part < GW; ++part) {
-        const int row = 16 * (wave + 8 * part) + (lane >> 2);
+        const int prow = 16 * (wave + 8 * part) + (lane >> 2);
+        const int row = DIR ? pp_perm_row(prow) : prow;
         woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * g.Cs + dls * VEC) * 2u : OOB;
     }
     const int T = g.Cs >> 5;                                                 // k-halves
@@ -826,8 +1037,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[mh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                               __builtin_bit_cast(bf16x8, fb[j]), acc[mh][i][j], 0, 0, 0);
+                        acc[mh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, DIR ? fb[j] : fa[i]),
+                                                                               __builtin_bit_cast(bf16x8, DIR ? fa[i] : fb[j]), acc[mh][i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -856,7 +1067,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[m][i][j]));
-    conv3x3_pp_epilogue<BN, false, MH, true>(acc, smem, bias, res, dst, fin, g, br, 0, 0, 0, n0, tmi);
+    if constexpr (DIR) pp_epilogue_direct<BN, false, MH, true, false>(acc, smem, bias, res, dst, fin, g, br, 0, 0, 0, n0, tmi);
+    else conv3x3_pp_epilogue<BN, false, MH, true>(acc, smem, bias, res, dst, fin, g, br, 0, 0, 0, n0, tmi);
 #ifdef DSN_PP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && blockIdx.x < 4096) pp_stamp_buf[6 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime() - st_r1;
@@ -870,7 +1082,8 @@ int launch_pp1(const dsn_tensor* s, const void* w, const float* bias, const dsn_
     g.tiles_y = (int32_t)((M + 255) / 256);
     g.tiles_x = 1;
     g.tiles_n = (g.Cd + BN - 1) / BN;
-    auto kern = conv1x1_pp_kernel<BN>;
+    constexpr bool CAN_DIR = BN == 128;
+    auto kern = (CAN_DIR && pp_dir()) ? conv1x1_pp_kernel<BN, CAN_DIR> : conv1x1_pp_kernel<BN>;
     constexpr int LDS = (BN == 128 ? 6 * 24576 : 4 * 32768) > PP_LDS ? (BN == 128 ? 6 * 24576 : 4 * 32768) : PP_LDS;   // (ring; epilogue staging)
     DSN_LDS_ATTR(kern, LDS);
     const int blocks = g.tiles_y * g.tiles_n;
@@ -892,6 +1105,11 @@ extern "C" int dsn_pp_stamp_read(unsigned long long* out, int32_t n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamp_buf), (size_t)n * 6 * sizeof(unsigned long long));
 }
 #endif
+
+extern "C" int dsn_pp_dir(int32_t on) {
+    if (on >= 0) g_pp_dir = on;
+    return g_pp_dir;
+}
 
 // selection mode (environment DSN_PP at load time, dsn_pp_mode() at run time: tests, A/B runs)
 static int g_pp_mode = getenv("DSN_PP") ? atoi(getenv("DSN_PP")) : 1;

@@ -131,6 +131,10 @@ int         dsn_pp_mode(int32_t mode);
  * of 32): 0 = never, 1 = default (>= 512 input and >= 256 output channels, >= 160 blocks), 2 = every eligible layer on 128-channel
  * tiles, 3 = the same with 256-channel tiles wherever possible.  Negative: unchanged.  Returns the mode after the update. */
 int         dsn_pp1_mode(int32_t mode);
+/* Epilogue form of the three ping-pong kernels above: 1 = straight from the accumulator registers (MFMA operands swapped, weight
+ * rows permuted in LDS so that a lane owns 8 consecutive channels of a pixel: 16-byte stores, no LDS staging), 0 = staged through
+ * LDS.  Same stored values either way (BatchNorm sums differ in fp32 summation order).  Negative: unchanged.  Returns the form. */
+int         dsn_pp_dir(int32_t on);
 /* The same for the ping-pong kernel-row weight-gradient kernel (csrc/wgrad.hip kind 5: 128 x 128 tiles x the three taps of a kernel
  * row per block; bf16, same-size 3x3 / s1 / p1 / d1, whole 128-channel tiles): 0 = never, 1 = default (16 x 16 patches cover >= 80 %
  * of the map, >= 12800 output pixels), 2 = every eligible layer.  Negative: unchanged.  Returns the mode after the update. */

@@ -9,6 +9,16 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["staged_epilogue", "register_epilogue"])
+def _epilogue_form(request):
+    """Every test of this file runs with both epilogue forms of the ping-pong kernels (dsn_pp_dir)."""
+    from desenet_amd import _lib
+    L = _lib.lib()
+    L.dsn_pp_dir(request.param)
+    yield
+    L.dsn_pp_dir(0)
+
+
 @pytest.fixture(params=[2, 3], ids=["bn128", "bn256_where_possible"])
 def pp1_mode(request):
     from desenet_amd import _lib

@@ -10,6 +10,16 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["staged_epilogue", "register_epilogue"])
+def _epilogue_form(request):
+    """Every test of this file runs with both epilogue forms of the ping-pong kernels (dsn_pp_dir)."""
+    from desenet_amd import _lib
+    L = _lib.lib()
+    L.dsn_pp_dir(request.param)
+    yield
+    L.dsn_pp_dir(0)
+
+
 @pytest.fixture(params=[3, 4, 5], ids=["bn256_where_possible", "bn128_two_blocks_per_cu", "bn128_one_block_per_cu"])
 def pp_mode(request):
     from desenet_amd import _lib
