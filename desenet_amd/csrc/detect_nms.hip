@@ -8,8 +8,9 @@
 //                       (~bits(conf) << 32 | row*nc + cls) through a per-image atomic counter.  Keys are unique, and sorting
 //                       them ascending == stable descending-confidence order of the reference's row-major candidate list,
 //                       so the arrival order of the atomics is irrelevant (deterministic result).
-//   2. nms_sort       : one 1024-thread workgroup per image: bitonic sort, LDS-resident for <= 8192 keys (the detect
-//                       setting), LDS-tiled + global passes above that (val setting: up to 151,200 keys).
+//   2. sort           : bitonic network, hand-written: one 1024-thread workgroup per image in LDS for <= 8192 keys; four
+//                       8192-key tiles per image + two cross-tile merge launches up to 32768; above that (val setting: up to
+//                       151,200 keys) a radix select keeps the 30000 best first (stage 2 below).
 //   3. nms_greedy     : one 256-thread workgroup per image walks the sorted keys (capped at 30000) in chunks of 64: every
 //                       candidate is tested against the boxes kept so far (4 waves split the kept list), then wave 0
 //                       resolves the chunk internally with ballots; stops as soon as max_det boxes are kept.
@@ -21,6 +22,10 @@ constexpr int MAX_WH = 4096;
 constexpr int MAX_NMS = 30000;
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT_LDS_KEYS = 8192;   // 64 KiB of LDS
+// LDS position of key i of a tile: one key of padding per 32, so that the strided 8-byte accesses of the sort (lane stride 8, 16, ...
+// keys in the late phases of every merge) spread over all banks
+__device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
+constexpr int SORT_LDS_SLOTS = SORT_LDS_KEYS + SORT_LDS_KEYS / 32;
 constexpr int MAX_DET_CAP = 4096;
 
 #define GRID_STRIDE(i, total) \
@@ -176,12 +181,6 @@ __global__ __launch_bounds__(64) void detect_bias_finalize_kernel(const DetectLe
 __device__ __forceinline__ uint64_t make_key(float conf, uint32_t idx) {
     return ((uint64_t)(~__float_as_uint(conf)) << 32) | idx;
 }
-// flat layout of the large case (nms_sort.hip): image in bits 48.., the 30 significant bits of ~conf (0 < conf <= 1: sign and
-// top exponent bit are zero), 18 bits of candidate index
-constexpr int FLAT_IDX_BITS = 18;
-__device__ __forceinline__ uint64_t make_key_flat(int b, float conf, uint32_t idx) {
-    return ((uint64_t)b << 48) | ((uint64_t)(~__float_as_uint(conf) & 0x3FFFFFFFu) << FLAT_IDX_BITS) | idx;
-}
 
 // One returning atomic per 256-thread BLOCK, not per candidate: the lanes that keep a candidate are counted with a ballot, the four
 // waves' counts meet in LDS, ONE lane reserves the block's slots and every lane takes base + (kept lanes before it).  (One atomicAdd
@@ -207,7 +206,7 @@ __device__ __forceinline__ int block_slot(bool want, int32_t* counter, int* s_cn
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int bs, int n, int nc,
                                                              float conf_thres, int multi_label, uint64_t classes_mask,
                                                              uint64_t* __restrict__ keys, int64_t cap,
-                                                             int32_t* __restrict__ counts, int flat) {
+                                                             int32_t* __restrict__ counts) {
     __shared__ int s_cnt[5];
     const int no = 5 + nc;
     const int b = blockIdx.y;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
                 const float conf = live ? r[5 + j] * obj : 0.f;
                 const bool want = live && conf > conf_thres && (classes_mask == 0 || ((classes_mask >> j) & 1));
                 const int slot = block_slot(want, &counts[b], s_cnt);
-                if (want) kb[slot] = flat ? make_key_flat(b, conf, (uint32_t)(row * nc + j)) : make_key(conf, (uint32_t)(row * nc + j));
+                if (want) kb[slot] = make_key(conf, (uint32_t)(row * nc + j));
             }
         } else {
             float best = 0.f;
@@ -237,66 +236,173 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
             }
             const bool want = live && best > conf_thres && (classes_mask == 0 || ((classes_mask >> bj) & 1));
             const int slot = block_slot(want, &counts[b], s_cnt);
-            if (want) kb[slot] = flat ? make_key_flat(b, best, (uint32_t)(row * nc + bj)) : make_key(best, (uint32_t)(row * nc + bj));
+            if (want) kb[slot] = make_key(best, (uint32_t)(row * nc + bj));
         }
     }
 }
 
-// ---- NMS stage 2: bitonic sort, one workgroup per image ---------------------------------------------------------------
+// ---- NMS stage 2: sort of the candidate keys (ascending = confidence descending, candidate order on ties) ---------------------------
+// All hand-written (round 4; rounds 2-3 sent more than 8192 slots per image through rocPRIM's device sort: 18 launches, 129 us for
+// 16 x 25200 candidates).  Keys are unique, so every correct sort gives the same order: the selection stays bit-exact.
+//   cnt <= 8192          one workgroup per image: bitonic network in 64 KB of LDS (nms_tile_sort_kernel, tile 0)
+//   8192 < cnt <= 32768  the 32768-key bitonic network over FOUR 8192-key tiles per image, all of its compare-exchange phases of
+//                        distance < 8192 inside LDS; only three phases cross tiles (distance 8192 of the 16384-merge, distances
+//                        16384 and 8192 of the 32768-merge), and a tile computes its side of those straight from the source buffer
+//                        (the second one needs the partner's value AFTER the first: recomputed from four source keys), so the
+//                        whole sort is three launches of 4 x images workgroups, ping-ponging between two key buffers:
+//                        nms_tile_sort_kernel (in place) -> nms_merge16k_kernel (A -> B) -> nms_merge32k_kernel (B -> A).
+//                        Keys past cnt read as ~0 (they sort to the end), so nothing is padded in memory.
+//   cnt > 32768          (validation settings: conf 0.001 + multi_label, up to 151200 candidates) only the max_nms = 30000 best
+//                        are ever used (general.py:707-708): nms_select_kernel finds the 30000th smallest key by an 8-pass radix
+//                        SELECT (256-bin LDS histograms, one workgroup per image), compacts the keys <= it in place and sets the
+//                        image's count to 30000; then as above.
 __device__ __forceinline__ void cmpswap(uint64_t& a, uint64_t& b, bool up) {
     if ((a > b) == up) { const uint64_t t = a; a = b; b = t; }
 }
-
-__global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(uint64_t* __restrict__ keys, int64_t cap,
-                                                                const int32_t* __restrict__ counts) {
-    __shared__ uint64_t s[SORT_LDS_KEYS];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    uint64_t* k = keys + (int64_t)b * cap;
-    const int cnt = counts[b];
-    if (cnt <= 1) return;
-    int np = 1;
-    while (np < cnt) np <<= 1;
-    for (int i = cnt + tid; i < np; i += SORT_THREADS) k[i] = ~0ull;   // padding sorts to the end (cap >= np by contract)
+// Compare-exchange phases of distance jstart .. 1 of the merge of size `size` inside an LDS tile of n keys whose first key is global
+// index `base`.  The network is bound by LDS traffic (128 KB per phase of an 8192-key tile), so THREE consecutive phases (distances
+// j, j/2, j/4) are done per LDS round trip: a thread takes the 8 keys lo + r j/4 (r = 0 .. 7) of one 2j-key block -- every partner of
+// those three phases is among them -- into registers; 13 phases of the 8192-merge are 5 round trips.  Leftover phases: two (4 keys)
+// or one at a time.
+template <int NK> __device__ __forceinline__ void phases_in_regs(uint64_t* s, int tid, int n, int size, int j, int base) {
+    // NK = 8: distances j, j/2, j/4; NK = 4: j, j/2; NK = 2: j.  Key r of a thread lies at lo + r * (2j / NK).
+    const int step = (2 * j) / NK, ls = 31 - __clz(step);      // (powers of two: no integer division in the loop)
+    for (int t = tid; t < n / NK; t += SORT_THREADS) {
+        const int lo = ((t >> ls) * (2 * j)) | (t & (step - 1));
+        const bool up = ((base + lo) & size) == 0;
+        uint64_t v[NK];
+#pragma unroll
+        for (int r = 0; r < NK; ++r) v[r] = s[skew(lo + r * step)];
+#pragma unroll
+        for (int d = NK / 2; d > 0; d >>= 1)
+#pragma unroll
+            for (int r = 0; r < NK; ++r)
+                if ((r & d) == 0) cmpswap(v[r], v[r | d], up);
+#pragma unroll
+        for (int r = 0; r < NK; ++r) s[skew(lo + r * step)] = v[r];
+    }
     __syncthreads();
-    if (np <= SORT_LDS_KEYS) {
-        for (int i = tid; i < np; i += SORT_THREADS) s[i] = k[i];
+}
+__device__ __forceinline__ void tile_phases(uint64_t* s, int tid, int n, int size, int jstart, int base) {
+    int j = jstart;
+    while (j >= 4) { phases_in_regs<8>(s, tid, n, size, j, base); j >>= 3; }
+    if (j == 2) phases_in_regs<4>(s, tid, n, size, 2, base);
+    else if (j == 1) phases_in_regs<2>(s, tid, n, size, 1, base);
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void nms_tile_sort_kernel(uint64_t* __restrict__ keys, int64_t cap,
+                                                                     const int32_t* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) uint64_t s[SORT_LDS_SLOTS];
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    uint64_t* k = keys + (int64_t)b * cap;
+    const int cnt = counts[b] < cap ? counts[b] : (int)cap;
+    if (cnt <= 1 || (cnt <= SORT_LDS_KEYS && tile > 0)) return;
+    int np = SORT_LDS_KEYS;                         // keys this tile sorts: the whole (power-of-two padded) list when it fits
+    if (cnt <= SORT_LDS_KEYS) { np = 1; while (np < cnt) np <<= 1; }
+    const int base = tile * SORT_LDS_KEYS;
+    for (int i = tid; i < np; i += SORT_THREADS) s[skew(i)] = base + i < cnt ? k[base + i] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= np; size <<= 1) tile_phases(s, tid, np, size, size >> 1, base);
+    const int nst = cnt <= SORT_LDS_KEYS ? cnt : np;       // (the tiles of a larger list are stored whole: the merges read them)
+    for (int i = tid; i < nst; i += SORT_THREADS) k[base + i] = s[skew(i)];
+}
+
+// merge of size 16384 (tile pairs): phase of distance 8192 from the source buffer, the rest in LDS.  src -> dst.
+__global__ __launch_bounds__(SORT_THREADS) void nms_merge16k_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                                                                    int64_t cap, const int32_t* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) uint64_t s[SORT_LDS_SLOTS];
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (counts[b] <= SORT_LDS_KEYS) return;
+    const uint64_t* k = src + (int64_t)b * cap;
+    const int base = tile * SORT_LDS_KEYS;
+    for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) {
+        const int g = base + i;
+        const uint64_t a = k[g], p = k[g ^ SORT_LDS_KEYS];
+        const bool take_min = ((g & SORT_LDS_KEYS) == 0) == ((g & (2 * SORT_LDS_KEYS)) == 0);     // lower half of an ascending pair
+        s[skew(i)] = take_min ? (a < p ? a : p) : (a > p ? a : p);
+    }
+    __syncthreads();
+    tile_phases(s, tid, SORT_LDS_KEYS, 2 * SORT_LDS_KEYS, SORT_LDS_KEYS >> 1, base);
+    uint64_t* o = dst + (int64_t)b * cap;
+    for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) o[base + i] = s[skew(i)];
+}
+
+// merge of size 32768 (all four tiles, ascending): phases of distance 16384 and 8192 from the source buffer, the rest in LDS.
+__global__ __launch_bounds__(SORT_THREADS) void nms_merge32k_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                                                                    int64_t cap, const int32_t* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) uint64_t s[SORT_LDS_SLOTS];
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (counts[b] <= 2 * SORT_LDS_KEYS) return;
+    const uint64_t* k = src + (int64_t)b * cap;
+    const int base = tile * SORT_LDS_KEYS;
+    for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) {
+        const int g = base + i, h = g ^ SORT_LDS_KEYS;
+        const uint64_t a0 = k[g], a1 = k[g ^ (2 * SORT_LDS_KEYS)], b0 = k[h], b1 = k[h ^ (2 * SORT_LDS_KEYS)];
+        const bool low16 = (g & (2 * SORT_LDS_KEYS)) == 0;                    // (the same for g and its distance-8192 partner h)
+        const uint64_t x = low16 ? (a0 < a1 ? a0 : a1) : (a0 > a1 ? a0 : a1);  // this key after the distance-16384 phase
+        const uint64_t y = low16 ? (b0 < b1 ? b0 : b1) : (b0 > b1 ? b0 : b1);  // its partner after that phase
+        s[skew(i)] = (g & SORT_LDS_KEYS) == 0 ? (x < y ? x : y) : (x > y ? x : y);
+    }
+    __syncthreads();
+    tile_phases(s, tid, SORT_LDS_KEYS, 4 * SORT_LDS_KEYS, SORT_LDS_KEYS >> 1, base);
+    uint64_t* o = dst + (int64_t)b * cap;
+    for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) o[base + i] = s[skew(i)];
+}
+
+// More than 32768 candidates: keep the MAX_NMS smallest keys (radix select on the 64-bit key, most significant byte first), in place.
+__global__ __launch_bounds__(SORT_THREADS) void nms_select_kernel(uint64_t* __restrict__ keys, int64_t cap, int32_t* __restrict__ counts) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ int want_s, base_s, wcnt[SORT_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cnt = counts[b] < cap ? counts[b] : (int)cap;
+    if (cnt <= 4 * SORT_LDS_KEYS) return;
+    uint64_t* k = keys + (int64_t)b * cap;
+    if (tid == 0) { prefix_s = 0ull; want_s = MAX_NMS; }
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
         __syncthreads();
-        for (int size = 2; size <= np; size <<= 1)
-            for (int j = size >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (np >> 1); t += SORT_THREADS) {
-                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    cmpswap(s[lo], s[lo | j], (lo & size) == 0);
-                }
-                __syncthreads();
-            }
-        for (int i = tid; i < np; i += SORT_THREADS) k[i] = s[i];
-        return;
-    }
-    // large case: strides >= SORT_LDS_KEYS run on global memory, the rest of each merge runs tile-by-tile in LDS
-    for (int size = 2; size <= np; size <<= 1) {
-        int j = size >> 1;
-        for (; j >= SORT_LDS_KEYS; j >>= 1) {
-            for (int t = tid; t < (np >> 1); t += SORT_THREADS) {
-                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                uint64_t a = k[lo], c = k[lo | j];
-                if ((a > c) == ((lo & size) == 0)) { k[lo] = c; k[lo | j] = a; }
-            }
-            __syncthreads();
+        const unsigned long long prefix = prefix_s;
+        for (int i = tid; i < cnt; i += SORT_THREADS) {
+            const uint64_t v = k[i];
+            if (pass == 0 || (v >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(v >> shift) & 255u], 1u);
         }
-        for (int base = 0; base < np; base += SORT_LDS_KEYS) {
-            for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) s[i] = k[base + i];
-            __syncthreads();
-            for (int jj = j; jj > 0; jj >>= 1) {
-                for (int t = tid; t < (SORT_LDS_KEYS >> 1); t += SORT_THREADS) {
-                    const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                    cmpswap(s[lo], s[lo | jj], ((base + lo) & size) == 0);
-                }
-                __syncthreads();
+        __syncthreads();
+        if (tid == 0) {             // the digit in which the want-th smallest key of this prefix lies
+            int want = want_s, d = 0;
+            for (; d < 255; ++d) {
+                if ((int)hist[d] >= want) break;
+                want -= (int)hist[d];
             }
-            for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) k[base + i] = s[i];
-            __syncthreads();
+            want_s = want;
+            prefix_s = (prefix << 8) | (unsigned long long)d;
         }
+        __syncthreads();
     }
+    const uint64_t kth = prefix_s;              // exactly MAX_NMS keys are <= kth (keys are unique)
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    // in-place compaction, chunk by chunk in order: the write position never passes the read position
+    for (int c0 = 0; c0 < cnt; c0 += SORT_THREADS) {
+        const int i = c0 + tid;
+        const uint64_t v = i < cnt ? k[i] : ~0ull;
+        const bool keep = i < cnt && v <= kth;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        if (keep) k[off + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < SORT_THREADS / 64; ++w) t += wcnt[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) counts[b] = MAX_NMS;
 }
 
 // ---- NMS stage 3: greedy suppression ----------------------------------------------------------------------------------
@@ -318,18 +424,18 @@ __device__ __forceinline__ bool iou_gt(const Box& a, const Box& b, float thr) {
 // per 64 candidates.
 constexpr int CAND_W = 6;
 __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ pred, int n, int nc,
-                                                         const uint64_t* __restrict__ keys, int64_t cap,
-                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ starts,
+                                                         const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys_b,
+                                                         int64_t cap, const int32_t* __restrict__ counts,
                                                          float* __restrict__ cand, int64_t cand_cap) {
     const int b = blockIdx.y;
     const int no = 5 + nc;
-    const uint64_t* k = starts ? keys + starts[b] : keys + (int64_t)b * cap;      // flat (one sort over all images) / per-image
-    const uint32_t idx_mask = starts ? ((1u << FLAT_IDX_BITS) - 1u) : 0xFFFFFFFFu;
     int cnt = counts[b];
+    // where the sorted keys lie: the 16384-merge leaves them in the second buffer, everything else in the first (stage 2)
+    const uint64_t* k = ((cnt > SORT_LDS_KEYS && cnt <= 2 * SORT_LDS_KEYS) ? keys_b : keys) + (int64_t)b * cap;
     if (cnt > MAX_NMS) cnt = MAX_NMS;
     float* cb = cand + (int64_t)b * cand_cap * CAND_W;
     for (int ci = blockIdx.x * 256 + threadIdx.x; ci < cnt; ci += gridDim.x * 256) {
-        const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu) & idx_mask;
+        const uint32_t idx = (uint32_t)(k[ci] & 0xFFFFFFFFu);
         const int row = idx / nc, cls = idx - row * nc;
         const float* r = pred + ((int64_t)b * n + row) * no;
         const float hw = r[2] / 2.0f, hh = r[3] / 2.0f;
@@ -882,18 +988,11 @@ extern "C" int dsn_detect_head_fwd_multi(const dsn_tensor* xs, const void* const
     return DSN_OK;
 }
 
-// large case (nms_sort.hip): device-wide segmented radix sort into a second key buffer
-int64_t dsn_nms_radix_temp_bytes(int32_t bs, int64_t cap);
-int dsn_nms_radix_sort(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* counts, int32_t bs, int64_t cap, void* temp,
-                       int64_t temp_bytes, const int32_t** starts_out, hipStream_t st);
-constexpr int64_t RADIX_FROM = 8192;       // slots per image above which the one-workgroup bitonic network loses (it sorts <= 8192 keys in LDS)
-
 extern "C" int64_t dsn_nms_workspace_bytes(int32_t bs, int32_t n, int32_t nc, int32_t multi_label) {
     if (bs <= 0 || n <= 0 || nc <= 0) return 0;
     const int64_t cap = key_cap(n, nc, multi_label && nc > 1);
     int64_t bytes = (int64_t)bs * cap * 8 + (int64_t)((bs * 4 + 255) / 256) * 256;
-    if (cap > RADIX_FROM && cap <= (1ll << FLAT_IDX_BITS) && bs <= 256 && (int64_t)bs * cap < (1ll << 31))
-        bytes += (int64_t)bs * cap * 8 + 256 + dsn_nms_radix_temp_bytes(bs, cap);     // second key buffer + sort temp
+    if (cap > SORT_LDS_KEYS) bytes += (int64_t)bs * cap * 8 + 256;                    // second key buffer (tile merges ping-pong)
     bytes = (bytes + 255) / 256 * 256;
     bytes += (int64_t)bs * (cap < MAX_NMS ? cap : MAX_NMS) * CAND_W * 4;              // gathered candidate rows
     return bytes;
@@ -916,29 +1015,21 @@ extern "C" int dsn_nms(const float* pred, int32_t bs, int32_t n, int32_t nc, flo
     int32_t* counts = (int32_t*)workspace;
     uint64_t* keys = (uint64_t*)((char*)workspace + (int64_t)((bs * 4 + 255) / 256) * 256);
     dsn_fill_u32(counts, 0u, bs, st);
-    const bool flat = cap > RADIX_FROM && cap <= (1ll << FLAT_IDX_BITS) && bs <= 256 && (int64_t)bs * cap < (1ll << 31);
-    if (flat) dsn_fill_u32(keys, 0xFFFFFFFFu, bs * cap * 2, st);        // unused slots sort behind every image
     const int cb = (n + 255) / 256;
     hipLaunchKernelGGL(nms_candidates_kernel, dim3(cb < 128 ? cb : 128, bs), dim3(256), 0, st, pred, bs, n, nc, conf_thres,
-                       multi_label, classes_mask, keys, cap, counts, flat ? 1 : 0);
+                       multi_label, classes_mask, keys, cap, counts);
     DSN_LAUNCH_CHECK("nms candidates");
-    const uint64_t* sorted = keys;
-    const int32_t* starts = nullptr;
-    if (flat) {
-        uint64_t* keys2 = (uint64_t*)(((uintptr_t)(keys + (int64_t)bs * cap) + 255) / 256 * 256);
-        void* temp = keys2 + (int64_t)bs * cap;
-        const int64_t temp_bytes = workspace_bytes - (int64_t)((char*)temp - (char*)workspace);
-        const int rc = dsn_nms_radix_sort(keys, keys2, counts, bs, cap, temp, temp_bytes, &starts, st);
-        if (rc) DSN_FAIL(rc, "nms: radix sort failed");
-        sorted = keys2;
-    } else {
-        hipLaunchKernelGGL(nms_sort_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
-    }
+    uint64_t* keys2 = cap > SORT_LDS_KEYS ? (uint64_t*)(((uintptr_t)(keys + (int64_t)bs * cap) + 255) / 256 * 256) : keys;
+    if (cap > 4 * SORT_LDS_KEYS) hipLaunchKernelGGL(nms_select_kernel, dim3(bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
+    const int tiles = cap > SORT_LDS_KEYS ? (int)((cap < 4 * SORT_LDS_KEYS ? cap : 4 * SORT_LDS_KEYS) / SORT_LDS_KEYS) : 1;
+    hipLaunchKernelGGL(nms_tile_sort_kernel, dim3(tiles, bs), dim3(SORT_THREADS), 0, st, keys, cap, counts);
+    if (tiles >= 2) hipLaunchKernelGGL(nms_merge16k_kernel, dim3(tiles, bs), dim3(SORT_THREADS), 0, st, keys, keys2, cap, counts);
+    if (tiles >= 4) hipLaunchKernelGGL(nms_merge32k_kernel, dim3(tiles, bs), dim3(SORT_THREADS), 0, st, keys2, keys, cap, counts);
     DSN_LAUNCH_CHECK("nms sort");
     const int64_t cand_cap = cap < MAX_NMS ? cap : MAX_NMS;
     float* cand = (float*)((char*)workspace + workspace_bytes_needed - (int64_t)bs * cand_cap * CAND_W * 4);
     const int gb = (int)((cand_cap + 255) / 256);
-    hipLaunchKernelGGL(nms_gather_kernel, dim3(gb < 128 ? gb : 128, bs), dim3(256), 0, st, pred, n, nc, sorted, cap, counts, starts,
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(gb < 128 ? gb : 128, bs), dim3(256), 0, st, pred, n, nc, keys, keys2, cap, counts,
                        cand, cand_cap);
     DSN_LAUNCH_CHECK("nms gather");
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(bs), dim3(GREEDY_WAVES * 64), (size_t)((max_det + 3) / 4 * 4) * 5 * sizeof(float), st, cand, cand_cap,

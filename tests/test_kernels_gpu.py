@@ -594,6 +594,28 @@ def test_nms_vs_oracle_random_large(ops):
         np.testing.assert_array_equal(out[i, :r.shape[0]].cpu().numpy(), r)
 
 
+@pytest.mark.parametrize("n,conf", [(7000, 0.001), (9000, 0.001), (14000, 0.001), (20000, 0.4), (20000, 0.001), (32768, 0.001),
+                                    (33000, 0.3), (40000, 0.001), (70000, 0.55)])
+def test_nms_sort_ranges_vs_oracle(ops, n, conf):
+    """Every path of the hand-written candidate sort (detect_nms.hip stage 2) against the from-spec restatement: one LDS tile (<= 8192
+    candidates), two tiles + the 16384-merge, four tiles + both merges, with fewer candidates than tiles (the result then lies in the
+    second key buffer) and -- above 32768 candidates -- the radix select of the 30000 best.  Overlapping boxes, so the selection
+    depends on the order deep into the list; two images with different candidate counts."""
+    from oracle import nms_ref
+    rng = np.random.RandomState(n)
+    p = np.zeros((2, n, 6), np.float32)
+    p[..., 0:2] = rng.uniform(0, 640, (2, n, 2))
+    p[..., 2:4] = rng.uniform(4, 120, (2, n, 2))
+    p[..., 4] = rng.uniform(0, 1, (2, n))
+    p[1, : n // 3, 4] *= 0.5            # the second image keeps fewer candidates
+    p[..., 5] = rng.uniform(0.5, 1, (2, n))
+    ref = nms_ref.non_max_suppression(p, conf, 0.5, max_det=1000)
+    out, cnt = ops.nms(torch.from_numpy(p).cuda(), conf, 0.5, max_det=1000)
+    for i, r in enumerate(ref):
+        assert int(cnt[i]) == r.shape[0]
+        np.testing.assert_array_equal(out[i, :r.shape[0]].cpu().numpy(), r)
+
+
 def test_fused_sgd_matches_torch(ops):
     """dsn_sgd_step (one launch for every parameter, three groups) against torch.optim.SGD(momentum, nesterov, weight decay)
     over several steps, including a learning-rate change picked up from the device-side hyper table."""
