@@ -201,7 +201,10 @@ def test_concat_zero_copy_and_fallback(dsn):
 @pytest.mark.parametrize("shape", [(8, 128, 80, 80), (3, 64, 37, 41)])
 def test_pyramid_pooling_fused_branches_match_the_per_branch_path(shape, monkeypatch):
     """PyramidPooling's four conv + BatchNorm + SiLU branches as one launch each way (csrc/pp_fused.hip, bf16 training) against the
-    per-branch kernels on the same module: output, input gradient, every parameter gradient, running statistics."""
+    per-branch kernels on the same module: output, input gradient, every parameter gradient, running statistics.
+    This is a SELF-comparison (it localises a fault to the fused launch); the oracle legs for this module are the reference golden
+    `pyramid` in test_module_{eval,train_fwd_bwd} (non-divisible bins, fp32 1e-3) and, at the production shape 8 x 128 x 80 x 80, the
+    teacher-forced layer-24 forward / backward tests of test_net_gpu.py (SegMaskPSP contains this module; both run the fused path)."""
     import copy
     import desenet_amd
     from desenet_amd import hip_ops as ops
@@ -309,7 +312,9 @@ def test_detect_fused_head_forward_matches_the_per_level_path(n, hw, ch, nc, mon
 @pytest.mark.gpu
 def test_ffm_attention_fused_small_convs_match_the_layer_path(monkeypatch):
     """FFM's channel attention (two bias-free 1x1 convs on the pooled [n, c, 1, 1] vector, SiLU / Sigmoid: common.py:222-242) through
-    the one-block kernels of csrc/pp_fused.hip against the conv + activation launches: output, input and weight gradients."""
+    the one-block kernels of csrc/pp_fused.hip against the conv + activation launches: output, input and weight gradients.
+    A SELF-comparison of an OPTIONAL path (DSN_PP_FUSED=3, measured slower and off by default); the default layer path is held to the
+    reference golden `ffm` and to the oracle inside the teacher-forced layer-24 tests at 640 x 640."""
     import copy
     import desenet_amd
     from desenet_amd import hip_ops as ops

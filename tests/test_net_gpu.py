@@ -475,7 +475,11 @@ def test_config5_full_size_bf16_step_vs_fp32():
     """BASELINE.json config 5 at its stated per-GPU size and dtype: DeSeNet-m, 4 x 3 x 1280 x 1280, bf16 storage / fp32
     accumulation, one full training step (forward, both losses, backward).  The same step in fp32 on the HIP path -- itself held
     to the oracle at 128 / 256 above -- is the yard-stick: losses within 3e-2, finite outputs of the right shapes, finite
-    gradients for every parameter that has one, gradient norm within 25 % (the bf16 bound of the DeSeNet-s step)."""
+    gradients for every parameter that has one, gradient norm within 25 % (the bf16 bound of the DeSeNet-s step).
+    A SELF-comparison by necessity (the CPU oracle needs minutes and tens of GB at this size): what it adds over the oracle-checked
+    128 / 256 runs is the kernel SELECTION of the full-size maps -- the ping-pong 3x3 / 1x1 / stride-2 kernels, two blocks per CU,
+    256-channel tiles, kernel-row weight gradients -- each of which is held bit for bit (or to ATen) at these very grids in
+    test_pp_gpu.py / test_pp1_gpu.py (`test_production_grids_*`, `test_wgrad_kernel_row_production_shapes`)."""
     import os
     import desenet_amd
     from desenet_amd.core.models.yolo import Model
