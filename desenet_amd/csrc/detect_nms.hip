@@ -460,8 +460,8 @@ __global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const flo
                                                                        int32_t* __restrict__ out_count) {
     static_assert(GREEDY_WAVES == 16, "4 in-chunk candidates per wave, 16 nibbles per lane");
     extern __shared__ __attribute__((aligned(16))) float kept[];   // [max_det rounded up to 4][5]
-    __shared__ unsigned long long dead_s[GREEDY_WAVES];
-    __shared__ __attribute__((aligned(16))) unsigned char sup_s[64][GREEDY_WAVES];      // [lane][wave]: 4 bits each
+    __shared__ unsigned long long dead_s[2][GREEDY_WAVES];
+    __shared__ __attribute__((aligned(16))) unsigned char sup_s[2][64][GREEDY_WAVES];      // [buffer][lane][wave]: 4 bits each
     __shared__ int nkept_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
     int cnt = counts[b];
@@ -485,23 +485,19 @@ __global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const flo
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    float raw[6], nxt[6];
-    fetch(0, raw);
-    for (int base = 0; base < cnt; base += 64) {
-        const int nkept = nkept_s;
-        if (nkept >= max_det) break;
-        fetch(base + 64, nxt);
-        const bool valid = base + lane < cnt;
+    auto box_of = [&](const float (&r)[6], bool valid) {
         Box me{0.f, 0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            const float off = raw[5] * (agnostic ? 0.f : (float)MAX_WH);
-            me.x1 = raw[0] + off; me.y1 = raw[1] + off; me.x2 = raw[2] + off; me.y2 = raw[3] + off;
+            const float off = r[5] * (agnostic ? 0.f : (float)MAX_WH);
+            me.x1 = r[0] + off; me.y1 = r[1] + off; me.x2 = r[2] + off; me.y2 = r[3] + off;
             me.area = (me.x2 - me.x1) * (me.y2 - me.y1);
         }
-        // (a) against boxes kept so far: the waves split the kept list
-        // wave w takes boxes 4 (w + NW s) .. + 3: twenty consecutive floats = five broadcast ds_read_b128 per step
-        bool dead = !valid;
-        for (int q0 = 4 * part; q0 < nkept; q0 += 4 * GREEDY_WAVES) {
+        return me;
+    };
+    // my candidate against kept boxes [q_begin, q_end): this wave is number `w` of `nw` that share them, four boxes per step
+    // (twenty consecutive floats = five broadcast ds_read_b128; the first step starts at a multiple of four and masks the front)
+    auto vs_kept = [&](const Box& me, int q_begin, int q_end, int w, int nw, bool dead) {
+        for (int q0 = (q_begin & ~3) + 4 * w; q0 < q_end; q0 += 4 * nw) {
             float kb[20];
 #pragma unroll
             for (int v = 0; v < 5; ++v) {
@@ -510,12 +506,14 @@ __global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const flo
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (q0 + u < nkept && iou_gt(Box{kb[5 * u], kb[5 * u + 1], kb[5 * u + 2], kb[5 * u + 3], kb[5 * u + 4]}, me, iou_thres))
+                if (q0 + u >= q_begin && q0 + u < q_end &&
+                    iou_gt(Box{kb[5 * u], kb[5 * u + 1], kb[5 * u + 2], kb[5 * u + 3], kb[5 * u + 4]}, me, iou_thres))
                     dead = true;
         }
-        const unsigned long long dm = __ballot(dead);
-        if (lane == 0) dead_s[part] = dm;
-        // (b) inside the chunk: bit jj of `bits` = candidate 4 * part + jj (earlier, higher score) overlaps me
+        return dead;
+    };
+    // inside a chunk: bit jj = candidate 4 * part + jj (earlier, higher score) overlaps me
+    auto in_chunk = [&](const Box& me) {
         unsigned bits = 0u;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -525,13 +523,36 @@ __global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const flo
             o.area = __shfl(me.area, j);
             if (j < lane && iou_gt(o, me, iou_thres)) bits |= 1u << jj;
         }
-        sup_s[lane][part] = (unsigned char)bits;
-        lds_barrier();
+        return bits;
+    };
+    // PIPELINE (round 4): while wave 0 sweeps chunk c (serial: up to 64 decisions), the other fifteen waves already test chunk c + 1
+    // against the boxes kept BEFORE chunk c and among themselves; after the sweep all waves test chunk c + 1 against the (<= 64)
+    // boxes chunk c added.  Same comparisons and the same order of decisions as the serial reference (torchvision.ops.nms semantics,
+    // general.py:714): a candidate is dropped iff it overlaps a box kept earlier.
+    float raw[6], nxt[6], nn[6];
+    fetch(0, raw);
+    fetch(64, nxt);
+    int cur = 0;
+    {   // chunk 0: nothing kept yet
+        const Box me0 = box_of(raw, lane < cnt);
+        const unsigned long long dm = __ballot(!(lane < cnt));
+        if (lane == 0) dead_s[0][part] = dm;
+        sup_s[0][lane][part] = (unsigned char)in_chunk(me0);
+    }
+    for (int base = 0; base < cnt; base += 64) {
+        lds_barrier();                                    // chunk `base` is prepared (dead_s / sup_s [cur]); nkept_s is final
+        const int nk0 = nkept_s;
+        if (nk0 >= max_det) break;
+        fetch(base + 128, nn);
+        const Box me2 = box_of(nxt, base + 64 + lane < cnt);
+        bool dead2 = !(base + 64 + lane < cnt);
+        sup_s[cur ^ 1][lane][part] = (unsigned char)in_chunk(me2);
         if (part == 0) {
+            const Box me = box_of(raw, base + lane < cnt);
             unsigned long long dm_all = 0ull;
 #pragma unroll
-            for (int q = 0; q < GREEDY_WAVES; ++q) dm_all |= dead_s[q];
-            const u32x4 sv = *reinterpret_cast<const u32x4*>(&sup_s[lane][0]);
+            for (int q = 0; q < GREEDY_WAVES; ++q) dm_all |= dead_s[cur][q];
+            const u32x4 sv = *reinterpret_cast<const u32x4*>(&sup_s[cur][lane][0]);
             unsigned long long sup = 0ull;
 #pragma unroll
             for (int q = 0; q < GREEDY_WAVES; ++q)
@@ -540,25 +561,38 @@ __global__ __launch_bounds__(GREEDY_WAVES * 64) void nms_greedy_kernel(const flo
             // (readfirstlane returns int: widen through unsigned, or bit 31 of the low word smears over the high one)
             unsigned long long alive = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) |
                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a0);
-            int nk = nkept;
+            // the serial part only decides (scalar mask arithmetic + one ballot per kept box); the kept boxes are written afterwards
+            // by their own lanes, in lane order = score order
+            int nk = nk0;
+            unsigned long long keepm = 0ull;
             while (alive != 0ull && nk < max_det) {          // wave-uniform
                 const int j = __ffsll((long long)alive) - 1;
-                if (lane == j) {
-                    kept[nk * 5] = me.x1; kept[nk * 5 + 1] = me.y1; kept[nk * 5 + 2] = me.x2; kept[nk * 5 + 3] = me.y2;
-                    kept[nk * 5 + 4] = me.area;
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) ob[nk * 6 + e] = raw[e];
-                }
+                keepm |= 1ull << j;
                 ++nk;
                 alive &= ~(1ull << j);
                 alive &= ~__ballot((sup >> j) & 1ull);
             }
-            if (lane == 0) nkept_s = nk;
-        }
-        lds_barrier();
+            if ((keepm >> lane) & 1ull) {
+                const int q = nk0 + __popcll(keepm & ((1ull << lane) - 1ull));
+                kept[q * 5] = me.x1; kept[q * 5 + 1] = me.y1; kept[q * 5 + 2] = me.x2; kept[q * 5 + 3] = me.y2;
+                kept[q * 5 + 4] = me.area;
 #pragma unroll
-        for (int e = 0; e < 6; ++e) raw[e] = nxt[e];
+                for (int e = 0; e < 6; ++e) ob[q * 6 + e] = raw[e];
+            }
+            if (lane == 0) nkept_s = nk;
+        } else {
+            dead2 = vs_kept(me2, 0, nk0, part - 1, GREEDY_WAVES - 1, dead2);      // against everything kept before this chunk
+        }
+        lds_barrier();                                    // the sweep of chunk `base` is done
+        const int nk1 = nkept_s;
+        dead2 = vs_kept(me2, nk0, nk1, part, GREEDY_WAVES, dead2);                // against what this chunk added
+        const unsigned long long dm2 = __ballot(dead2);
+        if (lane == 0) dead_s[cur ^ 1][part] = dm2;
+        cur ^= 1;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { raw[e] = nxt[e]; nxt[e] = nn[e]; }
     }
+    __syncthreads();
     if (tid == 0) out_count[b] = nkept_s;
 }
 
