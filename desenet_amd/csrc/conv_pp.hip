@@ -1150,7 +1150,8 @@ int dsn_conv3x3_pp_try(const dsn_tensor* s, const void* w, const float* bias, co
         static const int min_blocks = [] { const char* e = getenv("DSN_PP_MIN_BLOCKS"); return e ? atoi(e) : 160; }();
         const double fill = (double)s->h * s->w / ((double)ty * tx * PT * PT);
         const int64_t blocks = patches * ((d->c + 127) / 128);
-        if (d->c < 128 || fill < 0.8 || blocks < min_blocks) return 1;
+        static const double min_fill = [] { const char* e = getenv("DSN_PP_MIN_FILL"); return e ? atof(e) : 0.8; }();
+        if (d->c < 128 || fill < min_fill || blocks < min_blocks) return 1;
     }
     PGeom g{};
     g.N = s->n; g.H = s->h; g.W = s->w; g.Cs = s->c; g.Cd = d->c; g.flip = is_dgrad ? 1 : 0;
