@@ -260,7 +260,10 @@ template <typename T, int MI, int NV, int CPV> struct WsXState {
         *reinterpret_cast<u32x4*>(ov) = x.old[i][v];
         *reinterpret_cast<u32x4*>(yv) = segv[v] == 1 ? x.y1[i][v] : x.y0[i][v];
 #pragma unroll
-        for (int k = 0; k < CPV; ++k) o[k] += to_f32<T>(rv[k]) + to_f32<T>(ov[k]);       // (absent operands read as zeros)
+        for (int k = 0; k < CPV; ++k) {       // (absent operands read as zeros; the shortcut first, then the old value: the order of
+            o[k] += to_f32<T>(rv[k]);         //  every other epilogue -- with both present `o += rv + ov` rounds differently, round 4's
+            o[k] += to_f32<T>(ov[k]);         //  randomised sweep found 43 of 2.4 M elements one bf16 ulp apart)
+        }
         const u32x4 packed = pack_out<T, CPV>(o);
         if (segv[v] >= 0 && ok) {
             T outv[CPV];
