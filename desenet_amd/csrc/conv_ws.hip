@@ -525,15 +525,16 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
         }
         // ---- epilogue straight from the accumulators: lane (fg, fr) owns pixel fr of each 16-pixel tile, channels fg * CPV ..
         if constexpr (EX) {
-            // extras(t) were requested one tile ago: younger in the queue are DMA(t + 1), stores(t - 1), extras(t + 1), DMA(t + 2)
-            // (first tile: requested in the prologue, behind it only extras(t + 1) and DMA(t + 2))
-            // G = 2 (stride-2 data gradient): FULL drain.  The counted form below gave wrong BatchNorm-backward sums on grids with 1-4
-            // tiles per block (round 4: either wait replaced by vmcnt(0) cures it, tighter counts do not -- the operations that
-            // retire out of the assumed order are among the all-out-of-range ones of the tiles past a block's share); the drain
-            // costs the DMA prefetch of one tile per step of these HBM-bound launches.
-            if (G == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL + LPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT + ST + XS::XL) : "memory");
+            // extras(t) were requested one tile ago; younger in the queue: DMA(t + 1), stores(t - 1), extras(t + 1), DMA(t + 2).
+            // Rounds 2-3 waited with the full count of those (2 LPT + ST + XL).  That is UNSOUND on this part (round 4,
+            // tools/exp/oob_order.hip, profiles/r04g_vmcnt_order_probe.txt): vmcnt counts completions, and (a) an LDS-DMA whose lanes
+            // are ALL out of range retires immediately, (b) register loads and LDS-DMAs are not ordered with respect to each other
+            // -- only register loads among themselves return in issue order.  On blocks with 1-4 tiles DMA(t + 1) / DMA(t + 2)
+            // are the all-out-of-range padding DMAs, the counter fell below the count with extras(t) still in flight and the
+            // BatchNorm-backward sums were formed from stale registers (2-20 % off on the stride-2 gather form, once in ~700 runs
+            // on the 1x1 form).  Sound: allow only the YOUNGER REGISTER LOADS, extras(t + 1) -- then extras(t), older loads of the
+            // same kind, are back.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL) : "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1040,8 +1041,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
         if constexpr (EX) {     // (counts as in conv1x1_ws_kernel; c == patches done by this block)
-            if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL + IH) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IH + ST + XS::XL) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL) : "memory");      // only the younger REGISTER loads: see conv1x1_ws_kernel
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
