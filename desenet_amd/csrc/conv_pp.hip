@@ -59,6 +59,7 @@ struct PGeom {
     int64_t sld, dld, rld;
     uint32_t src_bytes, w_bytes;
     int32_t nslab;
+    int32_t tail;                // 1: exact wait counts where the younger DMAs are all-out-of-range padding (DSN_PP_TAIL=0: the counts of the steady state, A/B only)
     int32_t d2s_c, Hout, Wout;   // 2x2 form of the stride-2 data gradient: GEMM column c = parity (c / d2s_c) of channel c % d2s_c
 };
 
@@ -139,6 +140,25 @@ __host__ __device__ constexpr int pp_wait_count_g(int jj, int MH, int GW, int D,
         }
     }
     return n;
+}
+// The LAST slab of a block: the halo DMAs (next slab) and the weight DMAs of pieces past the end of K are all-out-of-range padding --
+// they retire IMMEDIATELY (tools/exp/oob_order.hip), so they must not be counted as operations that may still be in flight: only
+// the real pieces behind piece jj + 1 are.
+__host__ __device__ constexpr int pp_wait_count_last(int jj, int MH, int GW, int D, int NT) {
+    const int KH = 2 * NT;
+    if (jj + 1 >= KH) return 0;
+    int n = 0;
+    for (int ph = jj * MH + MH - 2; ph >= (jj - D - 2) * MH; --ph) {
+        const int i = ph >= 0 ? ph / MH : -((-ph + MH - 1) / MH);
+        if (i + D == jj + 1) return n;
+        if (i + D < KH) ++n;
+    }
+    return n;
+}
+// (run-time form for the 1x1 kernel, whose K is not unrolled by slab: real pieces behind piece j + 1, at most `cap`)
+__device__ __forceinline__ void pp_wait_vm_rt(int n) {
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else pp_wait_vm(n);
 }
 constexpr bool pp_wait_count_same(int MH, int GW, int D) {
     for (int jj = 0; jj < 18; ++jj)
@@ -370,6 +390,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
     u32x4 fa[4], fb[4];
     for (int s = 0; s < g.nslab; ++s) {
         const unsigned char* hb = sH + (TWO ? 0 : (s & 1) * HB);
+        const bool last = s == g.nslab - 1 && g.tail;   // (block-uniform) the padding DMAs of this slab retire at once: exact counts
         const int so = TWO ? (s & 1) * 2 : 0;        // TWO: 18 k-halves per slab over 4 stages: the ring position shifts by 2 per slab
 #pragma unroll
         for (int jj = 0; jj < KH; ++jj) {
@@ -391,7 +412,10 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
                 for (int i = 0; i < 4; ++i)
                     fa[i] = *reinterpret_cast<const u32x4*>(hb + a_base[ox][kk] + ((4 * mh + i + oy) * PHW + ox) * 128);
                 // piece j+1 (and, at jj == 17, the next halo patch) landed
-                if (mh == MH - 1) pp_wait_vm(TWO ? (D - 2) * GW : pp_wait_count_g(jj, MH, GW, D, NT));
+                if (mh == MH - 1) {
+                    if (last) pp_wait_vm(TWO ? (jj + 1 >= KH ? 0 : ((D - 2 < KH - 2 - jj ? D - 2 : KH - 2 - jj) * GW)) : pp_wait_count_last(jj, MH, GW, D, NT));
+                    else pp_wait_vm(TWO ? (D - 2) * GW : pp_wait_count_g(jj, MH, GW, D, NT));
+                }
                 if (NT == 4 && mh == 0 && pp_halo_at_g(jj, NT)) load_halo1(s + 1, (s + 1) & 1, jj - 1);
                 load_w1(s * KH + jj + D, slot_w, GW == 1 ? 0 : mh);
                 if (NT == 9 && !TWO && mh == 0 && pp_halo_at(jj)) load_halo1(s + 1, (s + 1) & 1, t - 1);
@@ -987,7 +1011,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
 #pragma unroll
         for (int part = 0; part < GW; ++part) load_b(i, i % R, part);
     }
-    pp_wait_vm((D - 1) * NPK);
+    // (pieces past the end of K are all-out-of-range padding DMAs: they retire at once and must not be counted as in flight)
+    if (T >= D || !g.tail) pp_wait_vm((D - 1) * NPK); else pp_wait_vm_rt((T - 1) * NPK);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1015,8 +1040,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + a_base + (4 * mh + i) * 1024);
+                const int rem = g.tail ? T - 2 - (jb + jj) : D;             // real pieces behind piece j + 1
                 if (MH == 1) {
-                    pp_wait_vm((D - 2) * NPK);                               // piece j+1 landed (this wave's share)
+                    if (rem >= D - 2) pp_wait_vm((D - 2) * NPK);            // piece j+1 landed (this wave's share)
+                    else pp_wait_vm_rt(rem * NPK);                          // (tail: the padding DMAs retire at once)
                     load_a(jb + jj + D, slot_w, 0);
                     load_a(jb + jj + D, slot_w, 1);
                     load_b(jb + jj + D, slot_w, 0);
@@ -1025,7 +1052,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
                     load_b(jb + jj + D, slot_w, 1);
                     load_a(jb + jj + D, slot_w, 0);
                 } else {
-                    pp_wait_vm((D - 2) * NPK + 3);
+                    if (rem >= D - 1) pp_wait_vm((D - 2) * NPK + 3);        // (+ 3: the first-phase DMAs of piece j + D)
+                    else pp_wait_vm_rt(rem * NPK);
                     load_a(jb + jj + D, slot_w, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1158,6 +1186,8 @@ int dsn_conv3x3_pp_try(const dsn_tensor* s, const void* w, const float* bias, co
     g.act = p->act; g.accumulate = p->accumulate;
     g.sld = s->ldc; g.dld = d->ldc; g.rld = r ? r->ldc : 0;
     g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
+    static const int tail_exact = [] { const char* e = getenv("DSN_PP_TAIL"); return e ? atoi(e) : 1; }();
+    g.tail = tail_exact;
     g.nslab = s->c / 64;
     BnAcc fin{};
     if (finp) fin = *finp;
@@ -1216,6 +1246,8 @@ int dsn_conv1x1_pp_try(const dsn_tensor* s, const void* w, const float* bias, co
     g.act = p->act; g.accumulate = p->accumulate;
     g.sld = s->ldc; g.dld = d->ldc; g.rld = r ? r->ldc : 0;
     g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
+    static const int tail_exact = [] { const char* e = getenv("DSN_PP_TAIL"); return e ? atoi(e) : 1; }();
+    g.tail = tail_exact;
     g.nslab = 0;
     BnAcc fin{};
     if (finp) fin = *finp;
@@ -1256,6 +1288,8 @@ int dsn_dgrad_s2_pp_try(const dsn_tensor* dy, const void* w_s2, const dsn_tensor
     g.act = DSN_ACT_NONE; g.accumulate = p->accumulate;
     g.sld = dy->ldc; g.dld = dx->ldc; g.rld = 0;
     g.src_bytes = (uint32_t)sb; g.w_bytes = (uint32_t)wb;
+    static const int tail_exact = [] { const char* e = getenv("DSN_PP_TAIL"); return e ? atoi(e) : 1; }();
+    g.tail = tail_exact;
     g.nslab = dy->c / 64;
     g.d2s_c = dx->c; g.Hout = dx->h; g.Wout = dx->w;
     const BnRed* brp = (br && br->nseg > 0) ? br : nullptr;
