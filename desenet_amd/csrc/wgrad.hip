@@ -948,8 +948,17 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + b_addr[kx][1][jn]));
                     b[kx][jn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
-            // k-step + 1 landed: the DMAs of k-steps + 2, + 3 (issued in the two phases before this one) may stay in flight
-            if (grp == 0) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>();
+            // k-step + 1 landed: the DMAs of k-steps + 2, + 3 (issued in the two phases before this one) may stay in flight.
+            // In the block's LAST patch the k-steps past its end are all-out-of-range padding DMAs: they retire at once
+            // (tools/exp/oob_order.hip) and must not be counted -- only the real k-steps behind k-step + 1 are.
+            if (pi == pe - 1 && hk + WPP_D > 8) {
+                const int real = 6 - hk < 0 ? 0 : (6 - hk < WPP_D - 2 ? 6 - hk : WPP_D - 2);       // of k-steps hk + 2 .. hk + D - 1, those < 8
+                if (real == 0) wpp_wait<0>();
+                else if (real == 1) { if (grp == 0) wpp_wait<3>(); else wpp_wait<2>(); }
+                else { if (grp == 0) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>(); }
+            } else {
+                if (grp == 0) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>();
+            }
             if (hk == 8 - WPP_D) cursor(pi + 1);                     // the prefetch enters the next patch (all lanes OOB past the range)
             int sd = sc + WPP_D;
             if (sd >= WPP_R) sd -= WPP_R;
