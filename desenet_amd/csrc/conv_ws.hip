@@ -573,9 +573,13 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
         }
         if constexpr (EX) {
             // DMA(t + 1) is older than stores(t - 1), extras(t + 1), DMA(t + 2), stores(t)  (first tile: extras(t), extras(t + 1),
-            // DMA(t + 2), stores(t))
-            if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XS::XL + LPT + ST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + XS::XL + LPT) : "memory");
+            // DMA(t + 2), stores(t)).  Of those only the STORES and a REAL DMA(t + 2) may be counted as still in flight (round 4,
+            // tools/exp/oob_order.hip): register loads overtake an older LDS-DMA, and the padding DMA of a tile past the block's
+            // share retires at once -- counting them let the wait go with DMA(t + 1) itself outstanding.  (Extras still in flight
+            // now hold the wait a little longer: they were requested a whole tile ago.)
+            const bool dma2 = tm + 2 * ngrp < g.tiles_m;
+            if (it == 0) { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory"); }
+            else { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + LPT) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST) : "memory"); }
         } else {
             // the next tile's DMA is older than (D - 2) younger tiles and the store groups issued since: min(it + 1, D - 1) of them
             wait_vm<(D - 2) * LPT, ST>(it + 1 < D - 1 ? it + 1 : D - 1);
@@ -1074,8 +1078,11 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             }
         }
         if constexpr (EX) {
-            if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XS::XL + IH + ST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + XS::XL + IH) : "memory");
+            // (as in conv1x1_ws_kernel: only the stores and a REAL halo DMA of patch + 2 may be counted as in flight -- register loads
+            //  overtake an older LDS-DMA, padding DMAs retire at once)
+            const bool dma2 = t_begin + (c + 2) / NS < t_end;          // the halo DMA issued in this chunk (chunk c + 2) is a real one
+            if (c == 0) { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IH + ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory"); }
+            else { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + IH) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST) : "memory"); }
             ++c;
         } else {   // as above, after this patch's ST stores (chunk c is a last-slab chunk)
             int nst = 0;
