@@ -205,7 +205,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             // BELOW this barrier (registers only: the "memory" clobbers do not hold them), which would leave ds_reads of ring stage
             // `lbuf` merely issued when another wave's LDS-DMA starts overwriting it after the barrier.  Observed: sporadic wrong
             // patches on >= 800-block bf16 launches (tests/test_kernels_gpu.py: the 8 x 70 x 67 case).
-            if (EX > 0 && (t == 1 || t == 2)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + EX) : "memory");
+            // Round 4 (tools/exp/oob_order.hip): an LDS-DMA whose lanes are ALL out of range retires at once, so the padding operations
+            // of the LAST slab -- halo(s + 1) and, at the last tap, W(f + 1) -- must not be counted as operations still in flight.
+            const bool lasts = s == g.nslab - 1;
+            if (lasts && t == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (EX > 0 && (t == 1 || t == 2) && !lasts) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + EX) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
             // (the "memory" clobber already keeps every ds_read of the previous tap above the wait; sched_barrier pins the whole
             //  issue order at this point -- cdna_hip_programming.md 5: place reads by the count, not by clean runs)

@@ -80,6 +80,21 @@ template <int BASE, int STEP> __device__ __forceinline__ void wait_vm(int n) {
     else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 2 * STEP) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 3 * STEP) : "memory");
 }
+// The same with `real` (0 .. D - 2) of the younger DMA groups being REAL ones: the groups requested for tiles past a block's share are
+// all-out-of-range padding DMAs, which retire at once (round 4, tools/exp/oob_order.hip) and must not stand for operations in flight.
+template <int D, int GSZ, int STEP> __device__ __forceinline__ void wait_ring(int real, int n) {
+    static_assert(D >= 2 && D <= 4, "ring depth");
+    if constexpr (D == 2) { wait_vm<0, STEP>(n); }
+    else if constexpr (D == 3) { if (real >= 1) wait_vm<GSZ, STEP>(n); else wait_vm<0, STEP>(n); }
+    else { if (real >= 2) wait_vm<2 * GSZ, STEP>(n); else if (real == 1) wait_vm<GSZ, STEP>(n); else wait_vm<0, STEP>(n); }
+}
+// prologue: weights + the first group landed; of the D - 2 younger groups only the real ones may be counted (as above)
+template <int D, int GSZ> __device__ __forceinline__ void wait_prologue(int real) {
+    static_assert(D >= 2 && D <= 4, "ring depth");
+    if (D >= 4 && real >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GSZ) : "memory");
+    else if (D >= 3 && real >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GSZ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 template <int N> __device__ __forceinline__ void wait_lgkm() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -461,11 +476,12 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
     load_w();
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_a(grp + j * ngrp, j);
-    if constexpr (EX) {
-        issue_x(grp, xa);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPT + XS::XL) : "memory");    // weights + the first tile
-    } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * LPT) : "memory");        // weights + the first tile
+    {   // weights + the first tile (the extras just requested are register loads: they overtake DMAs and are not counted)
+        if constexpr (EX) issue_x(grp, xa);
+        int real = 0;
+#pragma unroll
+        for (int j = 1; j <= D - 2; ++j) real += (grp + j * ngrp < g.tiles_m) ? 1 : 0;
+        wait_prologue<D, LPT>(real);
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -582,7 +598,10 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
             else { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + LPT) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST) : "memory"); }
         } else {
             // the next tile's DMA is older than (D - 2) younger tiles and the store groups issued since: min(it + 1, D - 1) of them
-            wait_vm<(D - 2) * LPT, ST>(it + 1 < D - 1 ? it + 1 : D - 1);
+            int real = 0;
+#pragma unroll
+            for (int k = 2; k <= D - 1; ++k) real += (tm + k * ngrp < g.tiles_m) ? 1 : 0;
+            wait_ring<D, LPT, ST>(real, it + 1 < D - 1 ? it + 1 : D - 1);
         }
         stage = stage + 1 == D ? 0 : stage + 1;
     };
@@ -934,11 +953,12 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
     load_w();
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_halo(j, j);
-    if constexpr (EX) {
-        issue_x(t_begin, xa);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH + XS::XL) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");         // weights + the first chunk
+    {   // weights + the first chunk (chunk j belongs to patch t_begin + j / NS; register-load extras are not counted)
+        if constexpr (EX) issue_x(t_begin, xa);
+        int real = 0;
+#pragma unroll
+        for (int j = 1; j <= D - 2; ++j) real += (t_begin + j / NS < t_end) ? 1 : 0;
+        wait_prologue<D, IH>(real);
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -1036,7 +1056,10 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
                 int nst = 0;
 #pragma unroll
                 for (int b = 0; b <= D - 2; ++b) nst += (c - b >= 0 && (c - b) % NS == NS - 1) ? 1 : 0;
-                wait_vm<(D - 2) * IH, ST>(nst);
+                int real = 0;
+#pragma unroll
+                for (int k = 2; k <= D - 1; ++k) real += (t_begin + (c + k) / NS < t_end) ? 1 : 0;
+                wait_ring<D, IH, ST>(real, nst);
                 ++c;
             }
             stage = stage + 1 == D ? 0 : stage + 1;
@@ -1088,7 +1111,10 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             int nst = 0;
 #pragma unroll
             for (int b = 0; b <= D - 2; ++b) nst += (c - b >= 0 && (c - b) % NS == NS - 1) ? 1 : 0;
-            wait_vm<(D - 2) * IH, ST>(nst);
+            int real = 0;
+#pragma unroll
+            for (int k = 2; k <= D - 1; ++k) real += (t_begin + (c + k) / NS < t_end) ? 1 : 0;
+            wait_ring<D, IH, ST>(real, nst);
             ++c;
         }
     };
@@ -1324,7 +1350,12 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
     load_w();
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_halo(j, j);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");
+    {
+        int real = 0;
+#pragma unroll
+        for (int j = 1; j <= D - 2; ++j) real += (t_begin + j < t_end) ? 1 : 0;
+        wait_prologue<D, IH>(real);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -1389,7 +1420,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
                 __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
             }
         }
-        wait_vm<(D - 2) * IH, ST>(c + 1 < D - 1 ? c + 1 : D - 1);
+        int real = 0;
+#pragma unroll
+        for (int k = 2; k <= D - 1; ++k) real += (tile + k < t_end) ? 1 : 0;
+        wait_ring<D, IH, ST>(real, c + 1 < D - 1 ? c + 1 : D - 1);
         stage = stage + 1 == D ? 0 : stage + 1;
     }
 
@@ -1534,7 +1568,12 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
     load_w();
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_halo(j, j);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * IH) : "memory");
+    {
+        int real = 0;
+#pragma unroll
+        for (int j = 1; j <= D - 2; ++j) real += (t_begin + j < t_end) ? 1 : 0;
+        wait_prologue<D, IH>(real);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -1598,7 +1637,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
                 __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
             }
         }
-        wait_vm<(D - 2) * IH, ST>(c + 1 < D - 1 ? c + 1 : D - 1);
+        int real = 0;
+#pragma unroll
+        for (int k = 2; k <= D - 1; ++k) real += (tile + k < t_end) ? 1 : 0;
+        wait_ring<D, IH, ST>(real, c + 1 < D - 1 ? c + 1 : D - 1);
         stage = stage + 1 == D ? 0 : stage + 1;
     }
 
