@@ -449,6 +449,17 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
                 for (int j = 0; j < NI; ++j) HMma<T>::run(acc[i][j], fa[i], fb[j]);
         }
     };
+    // A wave one of whose DMA instructions has ALL lanes out of range (rows past M in the last pixel tile, channels past Cd in a
+    // partial tile) drains instead: such a DMA retires at once (round 4, tools/exp/oob_order.hip), so the counts below would let
+    // the wave go with real DMAs of the slab it needs still in flight -- and its share of the weight rows is read by every wave.
+    {
+        bool full = true;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) full = full && __ballot(aoff[i] != OOB) != 0ull;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) full = full && __ballot(boff[i] != OOB) != 0ull;
+        if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // (the waits are immediates: one statement per slab; slab s may leave the LDS-DMA of the NS - 1 - s younger slabs in flight)
     if constexpr (NS > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPC) : "memory"); slab(0); }
     if constexpr (NS > 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPC) : "memory"); slab(1); }
