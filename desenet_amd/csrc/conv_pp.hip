@@ -160,6 +160,28 @@ __device__ __forceinline__ void pp_wait_vm_rt(int n) {
     if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else pp_wait_vm(n);
 }
+// Which halo DMAs (bit q = DMA q of the patch) pp_wait_count_g(jj, ...) counts as possibly in flight.  A wave whose halo DMA q has
+// ALL lanes out of range (border patches: its eight pixels lie outside the image) must subtract it: that DMA retires at once.
+__host__ __device__ constexpr unsigned pp_wait_halo_mask(int jj, int MH, int GW, int D, int NT) {
+    const int KH = 2 * NT;
+    const bool need_halo = jj == KH - 1;
+    unsigned mask = 0u;
+    for (int ph = jj * MH + MH - 2; ph >= (jj - D - 2) * MH; --ph) {
+        const int i = ph >= 0 ? ph / MH : -((-ph + MH - 1) / MH), mh = ph - i * MH;
+        const bool h = mh == 0 && pp_halo_at_g(i, NT), hn = h && need_halo && i >= 0;
+        const bool wn = i + D == jj + 1;
+        const int m = ((i % KH) + KH) % KH;
+        const unsigned bit = 1u << (NT == 9 ? (m >> 1) - 1 : m - 1);
+        if (NT == 9) {
+            if (h) { if (hn) return mask; mask |= bit; }
+            if (wn) return mask;
+        } else {
+            if (wn) return mask;
+            if (h) { if (hn) return mask; mask |= bit; }
+        }
+    }
+    return mask;
+}
 constexpr bool pp_wait_count_same(int MH, int GW, int D) {
     for (int jj = 0; jj < 18; ++jj)
         if (pp_wait_count_g(jj, MH, GW, D, 9) != pp_wait_count(jj, MH, GW, D)) return false;
@@ -339,6 +361,17 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         const int ls = (lane & 3) ^ ((-(lane >> 4)) & 3);             // ((prow >> 2) & 3) == lane >> 4: logical slot of this lane
         woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * NT * g.Cs + ls * VEC) * 2u : OOB;
     }
+    // Per-wave facts about DMA instructions whose lanes are ALL out of range (they retire at once, tools/exp/oob_order.hip, so
+    // the wait counts must not include them): hoob = such halo DMAs (border patches), wall = every weight DMA of this wave is real
+    // (false: rows past Cd in a partial channel tile -- that wave simply drains).
+    unsigned hoob = 0u;
+    if constexpr (!TWO) {
+#pragma unroll
+        for (int q = 0; q < PIHN; ++q) hoob |= (__ballot(hoff[q] != OOB) == 0ull) ? 1u << q : 0u;
+    }
+    bool wall = true;
+#pragma unroll
+    for (int part = 0; part < GW; ++part) wall = wall && __ballot(woff[part] != OOB) != 0ull;
     const int T_ALL = g.nslab * KH;                                   // k-halves
     // piece jp (global k-half index): slab jp / KH, weight tap (jp % KH) / 2, channel half jp & 1
     auto load_w1 = [&](int jp, int slot, int part) {
@@ -414,7 +447,16 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
                 // piece j+1 (and, at jj == 17, the next halo patch) landed
                 if (mh == MH - 1) {
                     if (last) pp_wait_vm(TWO ? (jj + 1 >= KH ? 0 : ((D - 2 < KH - 2 - jj ? D - 2 : KH - 2 - jj) * GW)) : pp_wait_count_last(jj, MH, GW, D, NT));
-                    else pp_wait_vm(TWO ? (D - 2) * GW : pp_wait_count_g(jj, MH, GW, D, NT));
+                    else if (TWO) pp_wait_vm((D - 2) * GW);
+                    else if (hoob) {                                        // (wave-uniform; border patches only)
+                        const unsigned HM = pp_wait_halo_mask(jj, MH, GW, D, NT);    // (folds: jj is an unrolled index)
+                        const int CNT = pp_wait_count_g(jj, MH, GW, D, NT), k = (int)__popc(hoob & HM);
+                        if (k == 0) pp_wait_vm(CNT);                       // (short compare chain: k is mostly 0 .. 2)
+                        else if (k == 1) pp_wait_vm(CNT - 1);
+                        else if (k == 2) pp_wait_vm(CNT - 2);
+                        else pp_wait_vm_rt(CNT - k);
+                    } else pp_wait_vm(pp_wait_count_g(jj, MH, GW, D, NT));
+                    if (!wall) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (NT == 4 && mh == 0 && pp_halo_at_g(jj, NT)) load_halo1(s + 1, (s + 1) & 1, jj - 1);
                 load_w1(s * KH + jj + D, slot_w, GW == 1 ? 0 : mh);
@@ -982,6 +1024,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
         woff[part] = n0 + row < g.Cd ? (uint32_t)((int64_t)(n0 + row) * g.Cs + dls * VEC) * 2u : OOB;
     }
     const int T = g.Cs >> 5;                                                 // k-halves
+    // (a wave one of whose DMA instructions has all lanes out of range -- rows past M in the last pixel tile, channels past Cd in a
+    //  partial tile -- drains at every wait: such DMAs retire at once and the counts would stand for nothing)
+    bool wall = true;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wall = wall && __ballot(aoff[q] != OOB) != 0ull;
+#pragma unroll
+    for (int part = 0; part < GW; ++part) wall = wall && __ballot(woff[part] != OOB) != 0ull;
     auto load_a = [&](int jp, int slot, int q) {
         const uint32_t off = (aoff[q] == OOB || jp >= T) ? OOB : aoff[q] + (uint32_t)jp * 64u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(smem + slot * PIECE + apy[q] * 1024), 16, off, 0, 0, 0);
@@ -1042,7 +1091,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
                 for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + a_base + (4 * mh + i) * 1024);
                 const int rem = g.tail ? T - 2 - (jb + jj) : D;             // real pieces behind piece j + 1
                 if (MH == 1) {
-                    if (rem >= D - 2) pp_wait_vm((D - 2) * NPK);            // piece j+1 landed (this wave's share)
+                    if (!wall) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (rem >= D - 2) pp_wait_vm((D - 2) * NPK);       // piece j+1 landed (this wave's share)
                     else pp_wait_vm_rt(rem * NPK);                          // (tail: the padding DMAs retire at once)
                     load_a(jb + jj + D, slot_w, 0);
                     load_a(jb + jj + D, slot_w, 1);
@@ -1052,7 +1102,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
                     load_b(jb + jj + D, slot_w, 1);
                     load_a(jb + jj + D, slot_w, 0);
                 } else {
-                    if (rem >= D - 1) pp_wait_vm((D - 2) * NPK + 3);        // (+ 3: the first-phase DMAs of piece j + D)
+                    if (!wall) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (rem >= D - 1) pp_wait_vm((D - 2) * NPK + 3);   // (+ 3: the first-phase DMAs of piece j + D)
                     else pp_wait_vm_rt(rem * NPK);
                     load_a(jb + jj + D, slot_w, 1);
                 }
