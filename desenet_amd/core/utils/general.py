@@ -3,8 +3,8 @@ box_iou (:626-648), scale_coords / clip_coords (:598-623) and non_max_suppressio
 
 `non_max_suppression` keeps the reference signature and return type (a list of (n_i, 6) tensors [xyxy, conf, cls]) but
 runs as three HIP kernels (candidate keys -> per-image bitonic sort -> greedy suppression; csrc/detect_nms.hip) instead of
-a Python loop over images around torchvision.ops.nms.  Unsupported reference options raise instead of silently differing:
-`labels` (auto-labelling apriori boxes) and merge-NMS (disabled in the reference, `merge = False`).
+a Python loop over images around torchvision.ops.nms.  `labels` (auto-labelling apriori boxes, general.py:690-697) are appended
+to the predictions as rows before the kernels run; merge-NMS is disabled in the reference (`merge = False`) and absent here.
 """
 from __future__ import annotations
 
