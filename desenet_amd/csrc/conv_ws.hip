@@ -95,6 +95,46 @@ template <int D, int GSZ> __device__ __forceinline__ void wait_prologue(int real
     else if (D >= 3 && real >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GSZ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// (A wave with dead operations among the counted ones -- see DeadOps below -- DRAINS: an exact runtime count needs a compare tree
+//  over the 6-bit immediate at every wait, measured +11 % on the short 3x3 kernels of the 20x20 / 40x40 maps for its code size alone.)
+__device__ __forceinline__ void wait_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Per-wave ledger of the vector-memory operations that retire AT ONCE because every lane is out of range (tools/exp/oob_order.hip):
+// border rows of a halo, pixel rows past M, channel tiles past Cd, padding pixels of a halo stage -- DMAs and stores alike (a dead
+// store is taken for instant too: subtracting it can only lengthen a wait).  The static counts of the ring waits take every counted
+// operation for one in flight; a wave subtracts its dead ones among them.  g0 / g1: dead DMAs of the youngest / second youngest DMA
+// group (0 for the padding groups past a block's share: the static counts leave those out already), s0 .. s2: of the youngest store groups.
+struct DeadOps {
+    int g0, g1, s0, s1, s2;
+    __device__ __forceinline__ void init() { g0 = g1 = s0 = s1 = s2 = 0; }
+    __device__ __forceinline__ void dma(int d) { g1 = g0; g0 = d; }
+    __device__ __forceinline__ void st(int d) { s2 = s1; s1 = s0; s0 = d; }
+    template <int D> __device__ __forceinline__ int among(int nst) const {
+        return (D >= 3 ? g0 : 0) + (D >= 4 ? g1 : 0) + (nst >= 1 ? s0 : 0) + (nst >= 2 ? s1 : 0) + (nst >= 3 ? s2 : 0);
+    }
+};
+__device__ __forceinline__ int all_out(bool lane_in_range) { return __builtin_amdgcn_readfirstlane(__ballot(lane_in_range) == 0ull ? 1 : 0); }
+// (the ballots are skipped where a wave-uniform test on the tile's position rules dead operations out: interior tiles)
+__device__ __forceinline__ int all_out(bool check, bool lane_in_range) { return check ? all_out(lane_in_range) : 0; }
+template <int D, int GSZ, int STEP> __device__ __forceinline__ void wait_ring(int real, int n, int dead) {
+    if (dead == 0) wait_ring<D, GSZ, STEP>(real, n);
+    else wait_vm_drain();
+}
+template <int D, int GSZ> __device__ __forceinline__ void wait_prologue(int real, int dead) {
+    if (dead == 0) wait_prologue<D, GSZ>(real);
+    else wait_vm_drain();
+}
+// The same for a wave `pad` of whose GSZ DMAs per group are dead in EVERY group (the padding pixels past the end of a halo stage):
+// those are not kept in the ledger, the wave's groups simply are GSZ - pad operations long (one more static form).
+template <int D, int GSZ, int STEP> __device__ __forceinline__ void wait_ring(int real, int n, int dead, int pad) {
+    if (pad == 0) wait_ring<D, GSZ, STEP>(real, n, dead);
+    else if (dead == 0 && pad == 1) wait_ring<D, GSZ - 1, STEP>(real, n);
+    else wait_vm_drain();
+}
+template <int D, int GSZ> __device__ __forceinline__ void wait_prologue(int real, int dead, int pad) {
+    if (pad == 0) wait_prologue<D, GSZ>(real, dead);
+    else if (dead == 0 && pad == 1) wait_prologue<D, GSZ - 1>(real);
+    else wait_vm_drain();
+}
 template <int N> __device__ __forceinline__ void wait_lgkm() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -372,7 +412,17 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
             }
         }
     };
+    DeadOps dead;
+    dead.init();
+    // The plain 1x1 form needs no ledger: its only dead operations are those of the last pixel tile when M % BM != 0 (that tile is
+    // simply not counted as a real one: tiles_cnt), a short K (kin) and a partial channel tile -- blocks with either of those drain.
+    bool kall = true;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kall = kall && kin[s];
+    const int tiles_cnt = G == 0 ? (int)(M / BM) : g.tiles_m;
+    const bool blk_drain = G == 0 && (!kall || n0 + BN > g.Cd);
     auto load_a = [&](int tm, int stage) {
+        int nd = 0;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int64_t m = (int64_t)tm * BM + 32 * i + r0;
@@ -393,10 +443,12 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                     const int iy = y * g.gS + gdy[s], ix = x * g.gS + gdx[s];
                     const bool ok = live && kin[s] && (unsigned)iy < (unsigned)g.gHs && (unsigned)ix < (unsigned)g.gWs;
                     const uint32_t off = ok ? (uint32_t)(((int64_t)(n * g.gHs + iy) * g.gWs + ix) * g.sld) * (uint32_t)sizeof(T) + gco[s] : OOB;
+                    nd += all_out(ok);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
                 }
             }
         }
+        if constexpr (G != 0) dead.dma(tm < g.tiles_m ? nd : 0); // (a padding group is not counted by the waits at all)
     };
 
     // per-lane epilogue constants: bias of the lane's channel vectors
@@ -480,8 +532,10 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
         if constexpr (EX) issue_x(grp, xa);
         int real = 0;
 #pragma unroll
-        for (int j = 1; j <= D - 2; ++j) real += (grp + j * ngrp < g.tiles_m) ? 1 : 0;
-        wait_prologue<D, LPT>(real);
+        for (int j = 1; j <= D - 2; ++j) real += (grp + j * ngrp < tiles_cnt) ? 1 : 0;
+        if (blk_drain) wait_vm_drain();
+        else if constexpr (G == 0) wait_prologue<D, LPT>(real);
+        else wait_prologue<D, LPT>(real, dead.template among<D>(0));
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -540,6 +594,16 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                 for (int j = 0; j < NI; ++j) WMma<T>::run(acc[i][j], fw[k % (PF + 1)][j], fx[k % (PF + 1)][i]);
         }
         // ---- epilogue straight from the accumulators: lane (fg, fr) owns pixel fr of each 16-pixel tile, channels fg * CPV ..
+        int sd = 0;                                                 // dead stores of this tile (see DeadOps)
+        if constexpr (G == 1) {
+            if ((int64_t)(tm + 1) * BM > M || n0 + BN > g.Cd) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                        sd += all_out((int64_t)tm * BM + (wm * MI + i) * 16 + fr < M && n0 + OV::ch(wn, v, fg) < g.Cd);
+            }
+        }
         if constexpr (EX) {
             // extras(t) were requested one tile ago; younger in the queue: DMA(t + 1), stores(t - 1), extras(t + 1), DMA(t + 2).
             // Rounds 2-3 waited with the full count of those (2 LPT + ST + XL).  That is UNSOUND on this part (round 4,
@@ -570,6 +634,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                 } else {
                     off = ok ? (uint32_t)(m * g.dld + c) * (uint32_t)sizeof(T) : OOB;
                 }
+                if constexpr (G == 2) sd += all_out(ok);
                 if constexpr (EX) {
                     __builtin_amdgcn_raw_buffer_store_b128(xs.apply(cur, i, v, o, ok), drsrc, off, 0, 0);
                 } else {
@@ -593,15 +658,25 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
             // tools/exp/oob_order.hip): register loads overtake an older LDS-DMA, and the padding DMA of a tile past the block's
             // share retires at once -- counting them let the wait go with DMA(t + 1) itself outstanding.  (Extras still in flight
             // now hold the wait a little longer: they were requested a whole tile ago.)
-            const bool dma2 = tm + 2 * ngrp < g.tiles_m;
-            if (it == 0) { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory"); }
+            const bool dma2 = tm + 2 * ngrp < tiles_cnt;
+            if constexpr (G != 0) dead.st(sd);
+            const int dd = G == 0 ? (blk_drain ? 1 : 0) : dead.template among<3>(it == 0 ? 1 : 2);
+            if (dd) wait_vm_drain();
+            else if (it == 0) { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT + ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory"); }
             else { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + LPT) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST) : "memory"); }
         } else {
             // the next tile's DMA is older than (D - 2) younger tiles and the store groups issued since: min(it + 1, D - 1) of them
             int real = 0;
 #pragma unroll
-            for (int k = 2; k <= D - 1; ++k) real += (tm + k * ngrp < g.tiles_m) ? 1 : 0;
-            wait_ring<D, LPT, ST>(real, it + 1 < D - 1 ? it + 1 : D - 1);
+            for (int k = 2; k <= D - 1; ++k) real += (tm + k * ngrp < tiles_cnt) ? 1 : 0;
+            const int nst = it + 1 < D - 1 ? it + 1 : D - 1;
+            if constexpr (G == 0) {
+                if (blk_drain) wait_vm_drain();
+                else wait_ring<D, LPT, ST>(real, nst);
+            } else {
+                dead.st(sd);
+                wait_ring<D, LPT, ST>(real, nst, dead.template among<D>(nst));
+            }
         }
         stage = stage + 1 == D ? 0 : stage + 1;
     };
@@ -875,11 +950,16 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
     };
     // ---- halo: instruction j of this wave covers halo pixels 32 j + 8 wave .. + 8; lane -> pixel p, physical slot lane & 7
     // chunk c of this block = (patch t_begin + c / NS, slab c % NS); chunks past the block's range: every lane out of range
+    DeadOps dead;
+    dead.init();
     auto load_halo = [&](int c, int stage) {
         const int tile = t_begin + c / NS, slab = c % NS;
         const bool live = tile < t_end;
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        int nd = 0;
+        static_assert(IH <= 8, "halo offsets are kept in eight registers");
+        uint32_t off[8];           // (an array bound naming IH here makes hipcc drop the kernel's host stub)
 #pragma unroll
         for (int j = 0; j < IH; ++j) {
             const int p = 32 * j + 8 * wave + (lane >> 3);
@@ -887,10 +967,21 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             const int gy = y0 - g.d + hy, gx = x0 - g.d + hx;
             const int ls = hslot(lane & 7, hx);
             const bool ok = live && p < g.NP && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W && slab * KC + ls * VEC < g.Cs;
-            const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + slab * KC + ls * VEC) * (uint32_t)sizeof(T) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (32 * j + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            off[j] = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + slab * KC + ls * VEC) * (uint32_t)sizeof(T) : OOB;
         }
+        if (live && (y0 < g.d || x0 < g.d || y0 + TH + g.d > g.H || x0 + TW + g.d > g.W)) {       // a patch at the image border
+#pragma unroll
+            for (int j = 0; j < IH; ++j)
+                nd += (32 * j + 8 * wave < g.NP) ? all_out(off[j] != OOB) : 0;     // (groups wholly past the stage's pixels: `pad` below)
+        }
+#pragma unroll
+        for (int j = 0; j < IH; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (32 * j + 8 * wave) * ROWB), 16, off[j], 0, 0, 0);
+        dead.dma(nd);                                             // (0 for a padding group: the waits do not count those at all)
     };
+    int pad = 0;                                                  // this wave's DMAs that are dead in every group
+#pragma unroll
+    for (int j = 0; j < IH; ++j) pad += (32 * j + 8 * wave < g.NP) ? 0 : 1;
 
     float bv[NV][CPV];
 #pragma unroll
@@ -958,7 +1049,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
         int real = 0;
 #pragma unroll
         for (int j = 1; j <= D - 2; ++j) real += (t_begin + j / NS < t_end) ? 1 : 0;
-        wait_prologue<D, IH>(real);
+        wait_prologue<D, IH>(real, dead.template among<D>(0), pad);
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -1059,14 +1150,23 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
                 int real = 0;
 #pragma unroll
                 for (int k = 2; k <= D - 1; ++k) real += (t_begin + (c + k) / NS < t_end) ? 1 : 0;
-                wait_ring<D, IH, ST>(real, nst);
+                wait_ring<D, IH, ST>(real, nst, dead.template among<D>(nst), pad);
                 ++c;
             }
             stage = stage + 1 == D ? 0 : stage + 1;
         }
+        int sd = 0;                                                 // dead stores of this patch (see DeadOps)
         // ---- epilogue: lane (fg, fr) owns patch pixel (r / TW, r % TW) of each 16-pixel tile, channels fg * CPV ..
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        if (y0 + TH > g.H || x0 + TW > g.W || n0 + BN > g.Cd) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = (wm * MI + i) * 16 + fr;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) sd += all_out(y0 + r / TW < g.H && x0 + r % TW < g.W && n0 + OV::ch(wn, v, fg) < g.Cd);
+            }
+        }
         if constexpr (EX) {     // (counts as in conv1x1_ws_kernel; c == patches done by this block)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XS::XL) : "memory");      // only the younger REGISTER loads: see conv1x1_ws_kernel
             __builtin_amdgcn_sched_barrier(0);
@@ -1104,7 +1204,10 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             // (as in conv1x1_ws_kernel: only the stores and a REAL halo DMA of patch + 2 may be counted as in flight -- register loads
             //  overtake an older LDS-DMA, padding DMAs retire at once)
             const bool dma2 = t_begin + (c + 2) / NS < t_end;          // the halo DMA issued in this chunk (chunk c + 2) is a real one
-            if (c == 0) { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IH + ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory"); }
+            dead.st(sd);
+            const int dd = dead.template among<3>(c == 0 ? 1 : 2) + (dma2 ? pad : 0);
+            if (dd) wait_vm_drain();
+            else if (c == 0) { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IH + ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory"); }
             else { if (dma2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST + IH) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ST) : "memory"); }
             ++c;
         } else {   // as above, after this patch's ST stores (chunk c is a last-slab chunk)
@@ -1114,7 +1217,8 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
             int real = 0;
 #pragma unroll
             for (int k = 2; k <= D - 1; ++k) real += (t_begin + (c + k) / NS < t_end) ? 1 : 0;
-            wait_ring<D, IH, ST>(real, nst);
+            dead.st(sd);
+            wait_ring<D, IH, ST>(real, nst, dead.template among<D>(nst), pad);
             ++c;
         }
     };
@@ -1321,11 +1425,15 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
         }
     };
     // halo patch c of this block: rows y0 - 1 .. y0 + TH, columns x0 - 1 .. x0 + TW, stored row after row as in memory
+    DeadOps dead;
+    dead.init();
     auto load_halo = [&](int c, int stage) {
         const int tile = t_begin + c;
         const bool live = tile < t_end;
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        int nd = 0;
+        const bool chk = y0 < 1 || x0 < 1 || y0 + TH + 1 > g.H || x0 + TW + 1 > g.W || IH * 256 > NPIECE;
 #pragma unroll
         for (int j = 0; j < IH; ++j) {
             const int q = j * 256 + tid;
@@ -1333,8 +1441,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
             const int gy = y0 - 1 + hy, gx = x0 - 1 + (piece >> 1);
             const bool ok = live && q < NPIECE && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + (piece & 1) * 8) * 2u : OOB;
+            nd += all_out(chk, ok);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
         }
+        dead.dma(live ? nd : 0);                                  // (a padding group is not counted by the waits at all)
     };
 
     float bv[NV][CPV];
@@ -1354,7 +1464,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
         int real = 0;
 #pragma unroll
         for (int j = 1; j <= D - 2; ++j) real += (t_begin + j < t_end) ? 1 : 0;
-        wait_prologue<D, IH>(real);
+        wait_prologue<D, IH>(real, dead.template among<D>(0));
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -1396,6 +1506,8 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
         }
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        int sd = 0;                                                 // dead stores of this patch (see DeadOps)
+        const bool schk = y0 + TH > g.H || x0 + TW > g.W || n0 + BN > g.Cd;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int y = y0 + wm * MI + i, x = x0 + fr;
@@ -1417,13 +1529,16 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
                     for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
                 }
                 const uint32_t off = ok ? (uint32_t)(m * g.dld + cc) * 2u : OOB;
+                sd += all_out(schk, ok);
                 __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
             }
         }
         int real = 0;
 #pragma unroll
         for (int k = 2; k <= D - 1; ++k) real += (tile + k < t_end) ? 1 : 0;
-        wait_ring<D, IH, ST>(real, c + 1 < D - 1 ? c + 1 : D - 1);
+        dead.st(sd);
+        const int nst = c + 1 < D - 1 ? c + 1 : D - 1;
+        wait_ring<D, IH, ST>(real, nst, dead.template among<D>(nst));
         stage = stage + 1 == D ? 0 : stage + 1;
     }
 
@@ -1538,11 +1653,15 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
         }
     };
+    DeadOps dead;
+    dead.init();
     auto load_halo = [&](int c, int stage) {
         const int tile = t_begin + c;
         const bool live = tile < t_end;
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        int nd = 0;
+        const bool chk = y0 < 1 || x0 < 1 || y0 + TH + 1 > g.H || x0 + TW + 1 > g.W || IH * 256 > NPIECE;
 #pragma unroll
         for (int j = 0; j < IH; ++j) {
             const int q = j * 256 + tid;
@@ -1551,8 +1670,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
             const int gy = y0 - 1 + hy, gx = x0 - 1 + px;
             const bool ok = live && q < NPIECE && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + sub * 4) * 4u : OOB;
+            nd += all_out(chk, ok);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
         }
+        dead.dma(live ? nd : 0);                                  // (a padding group is not counted by the waits at all)
     };
 
     float bv[NV][CPV];
@@ -1572,7 +1693,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
         int real = 0;
 #pragma unroll
         for (int j = 1; j <= D - 2; ++j) real += (t_begin + j < t_end) ? 1 : 0;
-        wait_prologue<D, IH>(real);
+        wait_prologue<D, IH>(real, dead.template among<D>(0));
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -1613,6 +1734,8 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
         }
         const int n = tile / tiles_img, trem = tile - n * tiles_img;
         const int y0 = (trem / g.tiles_x) * TH, x0 = (trem % g.tiles_x) * TW;
+        int sd = 0;                                                 // dead stores of this patch (see DeadOps)
+        const bool schk = y0 + TH > g.H || x0 + TW > g.W || n0 + BN > g.Cd;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int y = y0 + wm * MI + i, x = x0 + fr;
@@ -1634,13 +1757,16 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
                     for (int k = 0; k < CPV; ++k) o[k] = sigmoidf_(o[k]);
                 }
                 const uint32_t off = ok ? (uint32_t)(m * g.dld + cc) * 4u : OOB;
+                sd += all_out(schk, ok);
                 __builtin_amdgcn_raw_buffer_store_b128(pack_out<T, CPV>(o), drsrc, off, 0, 0);
             }
         }
         int real = 0;
 #pragma unroll
         for (int k = 2; k <= D - 1; ++k) real += (tile + k < t_end) ? 1 : 0;
-        wait_ring<D, IH, ST>(real, c + 1 < D - 1 ? c + 1 : D - 1);
+        dead.st(sd);
+        const int nst = c + 1 < D - 1 ? c + 1 : D - 1;
+        wait_ring<D, IH, ST>(real, nst, dead.template among<D>(nst));
         stage = stage + 1 == D ? 0 : stage + 1;
     }
 
