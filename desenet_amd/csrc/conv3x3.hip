@@ -137,6 +137,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
         const int nn = n0 + r0 + 32 * i;
         woff[i] = nn < g.Cd ? (uint32_t)((int64_t)nn * 9 * g.Cs + lsb * VEC) * (uint32_t)sizeof(T) : OOB;
     }
+    // Per-wave facts about DMA instructions whose lanes are ALL out of range: they retire at once (tools/exp/oob_order.hip) and must not
+    // stand for operations in flight in the counted waits below.  hdead: such halo DMAs per slab (border patches: rows / columns of
+    // the halo outside the image, the padding pixels past the patch); wfull: every weight DMA of this wave is a real one (false:
+    // rows past Cd of a partial channel tile -- that wave drains at every wait).
+    int hdead = 0;
+#pragma unroll
+    for (int j = 0; j < IH; ++j) hdead += (__ballot(hoff[j] != OOB) == 0ull) ? 1 : 0;
+    hdead = __builtin_amdgcn_readfirstlane(hdead);
+    bool wfull = true;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) wfull = wfull && __ballot(woff[i] != OOB) != 0ull;
     const int F = g.nslab * 9;
     auto load_w = [&](int f, int buf) {           // flat index f = slab * 9 + tap: K offset = tap * Cs + slab * KC
         const int s = f / 9, t = f - s * 9;
@@ -208,9 +219,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
             // Round 4 (tools/exp/oob_order.hip): an LDS-DMA whose lanes are ALL out of range retires at once, so the padding operations
             // of the LAST slab -- halo(s + 1) and, at the last tap, W(f + 1) -- must not be counted as operations still in flight.
             const bool lasts = s == g.nslab - 1;
-            if (lasts && t == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if (EX > 0 && (t == 1 || t == 2) && !lasts) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + EX) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
+            if ((lasts && t == 8) || !wfull) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (EX > 0 && (t == 1 || t == 2) && !lasts) {
+                // W(f + 1) and the REAL DMAs of halo(s + 1): BR + IH - hdead (a per-wave constant: a short compare chain)
+#define DSN_HWAIT(k) else if (EX >= k && hdead == k) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + (EX >= k ? EX - k : 0)) : "memory");
+                if (hdead == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + EX) : "memory");
+                DSN_HWAIT(1) DSN_HWAIT(2) DSN_HWAIT(3) DSN_HWAIT(4) DSN_HWAIT(5) DSN_HWAIT(6) DSN_HWAIT(7) DSN_HWAIT(8)
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
+#undef DSN_HWAIT
+            } else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
             // (the "memory" clobber already keeps every ds_read of the previous tap above the wait; sched_barrier pins the whole
             //  issue order at this point -- cdna_hip_programming.md 5: place reads by the count, not by clean runs)
             __builtin_amdgcn_sched_barrier(0);

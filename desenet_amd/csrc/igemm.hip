@@ -229,6 +229,22 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
             voffB[i] = (uint32_t)(n * g.Ktot + v * VEC) * (uint32_t)sizeof(T);
         }
     }
+    // LDS-DMA ring, uniform taps: the chunks of which taps carry a DMA instruction of this wave with ALL lanes out of range (bit t;
+    // bit 31: every chunk -- a weight DMA past Cd).  Such DMAs retire at once (tools/exp/oob_order.hip): see the ring below.
+    uint32_t u_deadtaps = 0;
+    if constexpr (GL > 0) {
+        if (UNI) {
+            for (int t = 0; t < g.KH * g.KW && t < 31; ++t) {
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) any = any || __ballot((tapmask[i] >> t) & 1u) == 0ull;
+                u_deadtaps |= any ? 1u << t : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) u_deadtaps |= __ballot(bok[i]) == 0ull ? 0x80000000u : 0u;
+            u_deadtaps = __builtin_amdgcn_readfirstlane(u_deadtaps);
+        }
+    }
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto fetchA = [&](u32x4& dstv, int i, uint32_t off, int gbuf) {
@@ -243,8 +259,14 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
         else
             dstv = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
     };
+    // LDS-DMA ring only: DMA instructions of the chunk just requested whose lanes are ALL out of range (a tap outside the image for
+    // the wave's eight rows, rows past M, channels past Cd).  They retire at once (tools/exp/oob_order.hip), so a wave with such
+    // operations among the chunks a ring wait counts as in flight drains instead (see the ring below).
+    int gl_dead = 0;
+    auto all_out = [&](bool lane_in_range) -> int { return __builtin_amdgcn_readfirstlane(__ballot(lane_in_range) == 0ull ? 1 : 0); };
     auto load_chunk = [&](int ch, u32x4 (&ra)[AR], u32x4 (&rb)[BR], int gbuf = 0) {
         const int k0 = ch * KC + v * VEC;
+        int nd = 0;
         if (UNI) {
             constexpr uint32_t OOB = 0xFFFFFFF0u;
 #pragma unroll
@@ -258,6 +280,7 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
                 const uint32_t off = bok[i] ? voffB[i] + u_offB : OOB;
                 fetchB(rb[i], i, off, gbuf);
             }
+            if constexpr (GL > 0) gl_dead = (u_tap >= 31 || (u_deadtaps & (0x80000000u | (1u << (u_tap & 31))))) ? 1 : 0;
             u_offB += ROWB;
             if (++u_cc == u_cpt) {
                 u_cc = 0;
@@ -292,13 +315,15 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
                     const bool ok = kok && rowok[i] && (unsigned)(py[i] + dyo) < (unsigned)g.Hs &&
                                     (unsigned)(px[i] + dxo) < (unsigned)g.Ws;
                     const uint32_t off = ok ? (uint32_t)(base_off[i] + off_tap) * (uint32_t)sizeof(T) : OOB;
-                        fetchA(ra[i], i, off, gbuf);
+                    if constexpr (GL > 0) nd += all_out(ok);
+                    fetchA(ra[i], i, off, gbuf);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < AR; ++i) {
                     const T* p = kok ? src_row(i, ky, kx) : nullptr;
                     const uint32_t off = p ? (uint32_t)((p + c) - src) * (uint32_t)sizeof(T) : OOB;
+                    if constexpr (GL > 0) nd += all_out(p != nullptr);
                     fetchA(ra[i], i, off, gbuf);
                 }
             }
@@ -307,8 +332,10 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
                 const int r = r0 + 32 * i, n = n0 + r;
                 const bool ok = kok && r < BN && n < g.Cd;
                 const uint32_t off = ok ? (uint32_t)(n * g.Ktot + kb) * (uint32_t)sizeof(T) : OOB;
+                if constexpr (GL > 0) nd += all_out(ok);
                 fetchB(rb[i], i, off, gbuf);
             }
+            if constexpr (GL > 0) gl_dead = nd;
         } else {   // generic path: per-element tap decode (channel counts that are not a multiple of the vector width)
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
@@ -394,8 +421,10 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
         // (out-of-range offsets: zeros, no traffic) so that the counted wait is the same constant in every iteration.
         constexpr int LPC = AR + BR;                       // LDS-DMA instructions per chunk per wave
         static_assert((GL - 2) * LPC < 64, "vmcnt is a 6-bit counter");
+        static_assert(GL <= 4, "the dead-operation window below holds GL - 2 <= 2 chunks");
+        int dq0 = 0, dq1 = 0;                              // dead DMAs of the youngest / second youngest chunk requested
 #pragma unroll
-        for (int s = 0; s < GL - 1; ++s) load_chunk(s, rga[0], rgb[0], s);
+        for (int s = 0; s < GL - 1; ++s) { load_chunk(s, rga[0], rgb[0], s); dq1 = dq0; dq0 = s < nchunks ? gl_dead : 0; }
         int lbuf = GL - 1, cbuf = 0;                       // stage the next load goes to / stage of the chunk to compute
         for (int i = 0; i < nchunks; ++i) {
             // (lgkmcnt(0): this wave's fragment reads of chunk i - 1 have COMPLETED, not merely issued, before anyone may overwrite
@@ -405,7 +434,10 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
             // the constant count the last GL - 2 chunks of a block were read on trust.
             {
                 const int rem = nchunks - 1 - i;
-                if (rem >= GL - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GL - 2) * LPC) : "memory");
+                // (the GL - 2 chunks younger than chunk i are the last GL - 2 requested; padding chunks enter the window as 0: the
+                //  tail counts leave them out already)
+                if (dq0 + (GL >= 4 ? dq1 : 0) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else if (rem >= GL - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GL - 2) * LPC) : "memory");
                 else if (GL >= 4 && rem == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPC) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
@@ -413,6 +445,7 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
             __builtin_amdgcn_s_barrier();                  // everyone's have; and everyone is done reading stage lbuf (chunk i-1)
             asm volatile("" ::: "memory");
             load_chunk(i + GL - 1, rga[0], rgb[0], lbuf);
+            dq1 = dq0; dq0 = i + GL - 1 < nchunks ? gl_dead : 0;
             compute(cbuf);
             lbuf = lbuf + 1 == GL ? 0 : lbuf + 1;
             cbuf = cbuf + 1 == GL ? 0 : cbuf + 1;
