@@ -857,12 +857,24 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
     uint32_t a_off = 0, b_off[2] = {0, 0};
     bool a_ok = false, b_ok[2] = {false, false};
     int a_ylim = 0, b_y[2] = {0, 0};
+    // Round 4 (tools/exp/oob_order.hip): a DMA whose lanes are ALL out of range retires at once and must not stand for an operation in
+    // flight in the counted waits.  (a) Only wave 0 issues the second x instruction (pixel slots 32 .. 35): for waves 1 .. 3 it
+    // covered the never-read padding slots 36 .. 47 and was dead in every k-step -- their waits were short of two operations.
+    // (b) c_edge: the cursor's patch can have dead DMAs at all (ragged patches, the zero-padding rows above / below the image, partial
+    // channel tiles) -- only then are the k-step's DMAs checked (one ballot each) and a wave with dead ones among the two k-steps a
+    // wait counts subtracts them (at most five operations are ever allowed in flight: a six-way chain).
+    const int npk = wave == 0 ? 3 : 2;                              // DMA instructions of this wave per k-step
+    bool c_edge = false;
+    int dq0 = 0, dq1 = 0;                                           // dead DMAs of the youngest / second youngest k-step requested
     auto cursor = [&](int patch) {                                  // per-lane source offsets of k-step 0 of `patch`
         a_ok = false; b_ok[0] = false; b_ok[1] = false;
+        c_edge = false;
         if (patch >= pe) return;
         const int per = g.npy * g.npx;
         const int n = patch / per, rem = patch - n * per;
         const int y0 = (rem / g.npx) * 16, x0 = (rem % g.npx) * 16;
+        c_edge = y0 + ky - 1 < 0 || y0 + ky + 15 > g.Hi || x0 + 17 > g.Wi || y0 + 16 > g.Ho || x0 + 16 > g.Wo || co0 + 128 > g.Co ||
+                 ci0 + 128 > g.CiLoad;
         const int ya = y0 + (ka >> 4), xa = x0 + (ka & 15);
         a_ylim = g.Ho - ya;
         a_ok = xa < g.Wo && co0 + lsa < g.Co;
@@ -878,13 +890,17 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
     auto issue = [&](int hk, int slot) {                            // LDS-DMA of k-step hk of the cursor's patch into ring stage `slot`
         unsigned char* st = smem + slot * WPP_STAGE;
         const uint32_t oa = (a_ok && 2 * hk < a_ylim) ? a_off + (uint32_t)hk * arow : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(st + wave * 1024), 16, oa, 0, 0, 0);
         const uint32_t o0 = (b_ok[0] && (unsigned)(b_y[0] + 2 * hk) < (unsigned)g.Hi) ? b_off[0] + (uint32_t)hk * brow : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + wave * 1024), 16, o0, 0, 0, 0);
-        if (grp == 0) {
-            const uint32_t o1 = (b_ok[1] && (unsigned)(b_y[1] + 2 * hk) < (unsigned)g.Hi) ? b_off[1] + (uint32_t)hk * brow : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + (wave + 8) * 1024), 16, o1, 0, 0, 0);
+        const uint32_t o1 = (b_ok[1] && (unsigned)(b_y[1] + 2 * hk) < (unsigned)g.Hi) ? b_off[1] + (uint32_t)hk * brow : OOB;
+        int nd = 0;
+        if (c_edge) {
+            nd = (__ballot(oa != OOB) == 0ull ? 1 : 0) + (__ballot(o0 != OOB) == 0ull ? 1 : 0) + ((wave == 0 && __ballot(o1 != OOB) == 0ull) ? 1 : 0);
+            nd = __builtin_amdgcn_readfirstlane(nd);
         }
+        dq1 = dq0; dq0 = nd;                                        // (k-steps past the block's range: c_edge is off, the tail waits leave them out)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(st + wave * 1024), 16, oa, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + wave * 1024), 16, o0, 0, 0, 0);
+        if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + (wave + 8) * 1024), 16, o1, 0, 0, 0);
     };
 
     // ---- fragment addresses (stage-relative) -----------------------------------------------------------------------------------
@@ -923,7 +939,11 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
     cursor(pb);
 #pragma unroll
     for (int j = 0; j < WPP_D; ++j) issue(j, j);
-    if (grp == 0) wpp_wait<3 * (WPP_D - 1)>(); else wpp_wait<2 * (WPP_D - 1)>();
+    // (k-step 0 landed; younger: k-steps 1 .. D - 1 -- a wave with dead DMAs anywhere in the prologue drains)
+    {
+        if (c_edge) wpp_wait<0>();                                  // (conservative: the first patch touches an edge)
+        else if (npk == 3) wpp_wait<3 * (WPP_D - 1)>(); else wpp_wait<2 * (WPP_D - 1)>();
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -951,13 +971,22 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
             // k-step + 1 landed: the DMAs of k-steps + 2, + 3 (issued in the two phases before this one) may stay in flight.
             // In the block's LAST patch the k-steps past its end are all-out-of-range padding DMAs: they retire at once
             // (tools/exp/oob_order.hip) and must not be counted -- only the real k-steps behind k-step + 1 are.
-            if (pi == pe - 1 && hk + WPP_D > 8) {
+            if (dq0 + dq1 != 0) {                                   // dead DMAs among k-steps + 2, + 3 (patches at an edge): exact count
+                const int real = (pi == pe - 1 && hk + WPP_D > 8) ? (6 - hk < 0 ? 0 : (6 - hk < WPP_D - 2 ? 6 - hk : WPP_D - 2)) : WPP_D - 2;
+                const int al = real * npk - (dq0 + dq1);
+                if (al <= 0) wpp_wait<0>();
+                else if (al == 1) wpp_wait<1>();
+                else if (al == 2) wpp_wait<2>();
+                else if (al == 3) wpp_wait<3>();
+                else if (al == 4) wpp_wait<4>();
+                else wpp_wait<5>();
+            } else if (pi == pe - 1 && hk + WPP_D > 8) {
                 const int real = 6 - hk < 0 ? 0 : (6 - hk < WPP_D - 2 ? 6 - hk : WPP_D - 2);       // of k-steps hk + 2 .. hk + D - 1, those < 8
                 if (real == 0) wpp_wait<0>();
-                else if (real == 1) { if (grp == 0) wpp_wait<3>(); else wpp_wait<2>(); }
-                else { if (grp == 0) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>(); }
+                else if (real == 1) { if (npk == 3) wpp_wait<3>(); else wpp_wait<2>(); }
+                else { if (npk == 3) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>(); }
             } else {
-                if (grp == 0) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>();
+                if (npk == 3) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>();
             }
             if (hk == 8 - WPP_D) cursor(pi + 1);                     // the prefetch enters the next patch (all lanes OOB past the range)
             int sd = sc + WPP_D;
