@@ -810,8 +810,12 @@ __global__ __launch_bounds__(256, 2) void wgrad128_kernel(const bf16_t* __restri
 //   Borders: dy / x pixels outside the image (ragged patches, the halo columns and rows of the zero padding) and channels beyond
 //   Co / Ci are out-of-range DMA lanes = zeros.
 constexpr int WPP_STAGE = 32 * 256 + 48 * 256;       // dy tile + x tile (48 pixel slots, 36 used) = 20480 B
-constexpr int WPP_R = 6, WPP_D = 4;                   // ring stages, prefetch distance (a stage is refilled >= 2 phases after its read)
-constexpr int WPP_LDS = WPP_R * WPP_STAGE;            // 122880 B
+#ifndef DSN_WPP_D
+#define DSN_WPP_D 4                                   // (5 measured: config 5 18.84 vs 18.79 ms -- the latency is covered at 4)
+#endif
+constexpr int WPP_D = DSN_WPP_D, WPP_R = WPP_D + 2;   // prefetch distance, ring stages (a stage is refilled >= 2 phases after its read)
+constexpr int WPP_LDS = WPP_R * WPP_STAGE;            // 122880 B (D = 4)
+static_assert(WPP_D >= 4 && WPP_D <= 5 && WPP_LDS <= 160 * 1024, "ring depth");
 
 __device__ __forceinline__ int wpp_f(int s) { return (s & 3) | (((s >> 3) & 1) << 2); }
 template <int N> __device__ __forceinline__ void wpp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -865,7 +869,7 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
     // wait counts subtracts them (at most five operations are ever allowed in flight: a six-way chain).
     const int npk = wave == 0 ? 3 : 2;                              // DMA instructions of this wave per k-step
     bool c_edge = false;
-    int dq0 = 0, dq1 = 0;                                           // dead DMAs of the youngest / second youngest k-step requested
+    int dq0 = 0, dq1 = 0, dq2 = 0;                                  // dead DMAs of the youngest .. third youngest k-step requested
     auto cursor = [&](int patch) {                                  // per-lane source offsets of k-step 0 of `patch`
         a_ok = false; b_ok[0] = false; b_ok[1] = false;
         c_edge = false;
@@ -897,7 +901,7 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
             nd = (__ballot(oa != OOB) == 0ull ? 1 : 0) + (__ballot(o0 != OOB) == 0ull ? 1 : 0) + ((wave == 0 && __ballot(o1 != OOB) == 0ull) ? 1 : 0);
             nd = __builtin_amdgcn_readfirstlane(nd);
         }
-        dq1 = dq0; dq0 = nd;                                        // (k-steps past the block's range: c_edge is off, the tail waits leave them out)
+        dq2 = dq1; dq1 = dq0; dq0 = nd;                                      // (k-steps past the block's range: c_edge is off, the tail waits leave them out)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(st + wave * 1024), 16, oa, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + wave * 1024), 16, o0, 0, 0, 0);
         if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + (wave + 8) * 1024), 16, o1, 0, 0, 0);
@@ -971,19 +975,24 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
             // k-step + 1 landed: the DMAs of k-steps + 2, + 3 (issued in the two phases before this one) may stay in flight.
             // In the block's LAST patch the k-steps past its end are all-out-of-range padding DMAs: they retire at once
             // (tools/exp/oob_order.hip) and must not be counted -- only the real k-steps behind k-step + 1 are.
-            if (dq0 + dq1 != 0) {                                   // dead DMAs among k-steps + 2, + 3 (patches at an edge): exact count
+            const int dd = dq0 + dq1 + (WPP_D >= 5 ? dq2 : 0);      // dead DMAs among k-steps + 2 .. + D - 1 (patches at an edge)
+            if (dd != 0) {                                          // exact count
                 const int real = (pi == pe - 1 && hk + WPP_D > 8) ? (6 - hk < 0 ? 0 : (6 - hk < WPP_D - 2 ? 6 - hk : WPP_D - 2)) : WPP_D - 2;
-                const int al = real * npk - (dq0 + dq1);
+                const int al = real * npk - dd;
                 if (al <= 0) wpp_wait<0>();
                 else if (al == 1) wpp_wait<1>();
                 else if (al == 2) wpp_wait<2>();
                 else if (al == 3) wpp_wait<3>();
                 else if (al == 4) wpp_wait<4>();
-                else wpp_wait<5>();
+                else if (al == 5) wpp_wait<5>();
+                else if (al == 6) wpp_wait<6>();
+                else if (al == 7) wpp_wait<7>();
+                else wpp_wait<8>();
             } else if (pi == pe - 1 && hk + WPP_D > 8) {
                 const int real = 6 - hk < 0 ? 0 : (6 - hk < WPP_D - 2 ? 6 - hk : WPP_D - 2);       // of k-steps hk + 2 .. hk + D - 1, those < 8
                 if (real == 0) wpp_wait<0>();
                 else if (real == 1) { if (npk == 3) wpp_wait<3>(); else wpp_wait<2>(); }
+                else if (real == 2) { if (npk == 3) wpp_wait<6>(); else wpp_wait<4>(); }
                 else { if (npk == 3) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>(); }
             } else {
                 if (npk == 3) wpp_wait<3 * (WPP_D - 2)>(); else wpp_wait<2 * (WPP_D - 2)>();
