@@ -408,7 +408,8 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int part = 0; part < GW; ++part) load_w1(i, i % R, part);
-    pp_wait_vm((D - 1) * GW);
+    if (!wall) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (dead weight DMAs must not stand for the halo DMAs in front of them)
+    else pp_wait_vm((D - 1) * GW);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1061,7 +1062,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
         for (int part = 0; part < GW; ++part) load_b(i, i % R, part);
     }
     // (pieces past the end of K are all-out-of-range padding DMAs: they retire at once and must not be counted as in flight)
-    if (T >= D || !g.tail) pp_wait_vm((D - 1) * NPK); else pp_wait_vm_rt((T - 1) * NPK);
+    if (!wall) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (T >= D || !g.tail) pp_wait_vm((D - 1) * NPK); else pp_wait_vm_rt((T - 1) * NPK);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
