@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 
     // ---- main loop: slabs x 9 taps, one barrier per tap -------------------------------------------------------------------------
     // Issue order: prologue halo(0), W(0), W(1); iteration f = (s, t) after its barrier: W(f + 2), and at t == 0 halo(s + 1).
-    // vmcnt retires in order, so before the barrier of (s, t) a wave may leave outstanding: W(f + 1) always, plus halo(s + 1) while it
+    // Real LDS-DMAs complete in issue order (tools/exp/oob_order.hip), so before the barrier of (s, t) a wave may leave outstanding: W(f + 1) always, plus halo(s + 1) while it
     // is younger than W(f) (t == 1) or sits between W(f) and W(f + 1) (t == 2).
     load_halo(0, 0);
     load_w(0, 0);

@@ -72,7 +72,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // that no MFMA is hoisted above the wait).  addr: 32-bit LDS byte address.
 #define DS_READ_B128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 // s_waitcnt vmcnt(BASE + n * STEP) for a wave-uniform n in 0 .. 3: the DMA ring waits leave (D - 2) younger tiles and the n store
-// groups issued since the awaited tile's DMA in flight (vmcnt retires in issue order, loads, LDS-DMA and stores alike)
+// groups issued since the awaited tile's DMA in flight.  (The counts rest on what tools/exp/oob_order.hip measured on this part: cold
+// LDS-DMAs of distinct lines and stores complete in issue order; register loads overtake DMAs and DMAs whose lanes are all out of
+// range retire at once -- neither is ever counted: see wait_ring / DeadOps below.)
 template <int BASE, int STEP> __device__ __forceinline__ void wait_vm(int n) {
     static_assert(BASE + 3 * STEP <= 63, "vmcnt is a 6-bit counter");
     if (n <= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
