@@ -35,6 +35,12 @@ void dsn_set_error(const char* fmt, ...);
 // Opt a kernel into more than 64 KB of dynamic LDS: once per (kernel, device ordinal), checked.  Returns DSN_OK or the HIP error
 // (message set): a launch site returns it instead of failing later with "invalid argument" at launch time.
 int dsn_lds_attr(const void* kern, int bytes);
+// Cache policy of every LDS-DMA load (last operand of __builtin_amdgcn_raw_ptr_buffer_load_lds; gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// The counted s_waitcnt vmcnt schedules need DMAs to complete in issue order, which holds for loads served from L2 / HBM but not for
+// hits in the CU's vector L1 (tools/exp/oob_order.hip).
+#ifndef DSN_DMA_AUX
+#define DSN_DMA_AUX 0
+#endif
 #define DSN_LDS_ATTR(kern, bytes)                                         \
     do {                                                                  \
         const int a_ = dsn_lds_attr((const void*)(kern), (bytes));        \

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < IH; ++j) {
             const uint32_t off = (hoff[j] == OOB || add == OOB) ? OOB : hoff[j] + add;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + hbuf * g.halo_stride + (32 * j + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + hbuf * g.halo_stride + (32 * j + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
         }
     };
     // ---- weight fetch plan: thread (row r0 + 32 i, physical slot tid & 7) of stage `buf`
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const T* __restrict__
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const uint32_t off = (woff[i] == OOB || add == OOB) ? OOB : woff[i] + add;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + (buf * BN + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + (buf * BN + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
         }
     };
 
@@ -428,12 +428,12 @@ __global__ __launch_bounds__(256) void conv1x1_dma_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const uint32_t off = aoff[i] == OOB ? OOB : aoff[i] + (uint32_t)(s * ROWB);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + ((s * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + ((s * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
             }
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
                 const uint32_t off = boff[i] == OOB ? OOB : boff[i] + (uint32_t)(s * ROWB);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + ((s * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + ((s * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
             }
         }
     };

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         const uint32_t add = slab < g.nslab ? (uint32_t)slab * 128u : OOB;
         const uint32_t ho = TWO ? halo_off(q, tq) : hoff[TWO ? 0 : q];
         const uint32_t off = (ho == OOB || add == OOB) ? OOB : ho + add;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + hbuf * HB + (64 * q + 8 * wave) * 128), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + hbuf * HB + (64 * q + 8 * wave) * 128), 16, off, 0, 0, DSN_DMA_AUX);
     };
     // ---- weight fetch plan: DMA `part` of this wave covers rows 16 (wave + 8 part) .. + 16 of the piece; lane -> row, physical slot
     uint32_t woff[GW];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void conv3x3_pp_kernel(const bf16
         const int s = jp / KH, jj = jp - s * KH, t = jj >> 1, kk = jj & 1;
         const uint32_t add = jp < T_ALL ? (uint32_t)(t * g.Cs + s * 64 + kk * 32) * 2u : OOB;
         const uint32_t off = (woff[part] == OOB || add == OOB) ? OOB : woff[part] + add;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + slot * PIECE + (wave + 8 * part) * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + slot * PIECE + (wave + 8 * part) * 1024), 16, off, 0, 0, DSN_DMA_AUX);
     };
 
     // ---- fragment addressing ------------------------------------------------------------------------------------------------
@@ -1034,11 +1034,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(const bf16_t* __rest
     for (int part = 0; part < GW; ++part) wall = wall && __ballot(woff[part] != OOB) != 0ull;
     auto load_a = [&](int jp, int slot, int q) {
         const uint32_t off = (aoff[q] == OOB || jp >= T) ? OOB : aoff[q] + (uint32_t)jp * 64u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(smem + slot * PIECE + apy[q] * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(smem + slot * PIECE + apy[q] * 1024), 16, off, 0, 0, DSN_DMA_AUX);
     };
     auto load_b = [&](int jp, int slot, int part) {
         const uint32_t off = (woff[part] == OOB || jp >= T) ? OOB : woff[part] + (uint32_t)jp * 64u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(smem + slot * PIECE + APIECE + (wave + 8 * part) * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(smem + slot * PIECE + APIECE + (wave + 8 * part) * 1024), 16, off, 0, 0, DSN_DMA_AUX);
     };
 
     const int swz = (fg ^ ((-(fr >> 2)) & 3)) << 4;

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const uint32_t off = (base == OOB || !kin[s]) ? OOB : base + (uint32_t)(s * ROWB);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + ((s * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + ((s * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
             }
         }
     };
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const uint32_t off = (base == OOB || !kin[s]) ? OOB : base + (uint32_t)(s * ROWB);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
                 }
             } else {
                 const int mi = live ? (int)m : 0;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const T* __restrict__ s
                     const bool ok = live && kin[s] && (unsigned)iy < (unsigned)g.gHs && (unsigned)ix < (unsigned)g.gWs;
                     const uint32_t off = ok ? (uint32_t)(((int64_t)(n * g.gHs + iy) * g.gWs + ix) * g.sld) * (uint32_t)sizeof(T) + gco[s] : OOB;
                     nd += all_out(ok);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (((stage * NS + s) * BM) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
                 }
             }
         }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
                 for (int s = 0; s < NS; ++s) {
                     const bool kin = s * KC + lsw * VEC < g.Cs;
                     const uint32_t off = (base == OOB || !kin) ? OOB : base + (uint32_t)((t * g.Cs + s * KC) * (int)sizeof(T));
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (((t * NS + s) * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (((t * NS + s) * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
                 }
         }
     };
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const T* __restrict__ s
         }
 #pragma unroll
         for (int j = 0; j < IH; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (32 * j + 8 * wave) * ROWB), 16, off[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (32 * j + 8 * wave) * ROWB), 16, off[j], 0, 0, DSN_DMA_AUX);
         dead.dma(nd);                                             // (0 for a padding group: the waits do not count those at all)
     };
     int pad = 0;                                                  // this wave's DMAs that are dead in every group
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const uint32_t off = (ch < g.Cd && lsw < 6) ? (uint32_t)(((int64_t)ch * 9 + ky * 3) * 16 + lsw * 8) * 2u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + ((ky * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + ((ky * BN) + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
             }
         }
     };
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_ws_kernel(const bf16_t* __re
             const bool ok = live && q < NPIECE && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + (piece & 1) * 8) * 2u : OOB;
             nd += all_out(chk, ok);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, DSN_DMA_AUX);
         }
         dead.dma(live ? nd : 0);                                  // (a padding group is not counted by the waits at all)
     };
@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
             const int pp = st * 4 + pc;                       // 16-byte piece of the 144-byte coefficient run
             const int ch = n0 + row;
             const uint32_t off = (q < WPIECE && ch < g.Cd && pp < 9) ? (uint32_t)(((int64_t)ch * 9 + ky * 3) * 12 * 4 + pp * 16) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sW + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, DSN_DMA_AUX);
         }
     };
     DeadOps dead;
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_f32_ws_kernel(const float* _
             const bool ok = live && q < NPIECE && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             const uint32_t off = ok ? (uint32_t)((((int64_t)n * g.H + gy) * g.W + gx) * g.sld + sub * 4) * 4u : OOB;
             nd += all_out(chk, ok);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sH + stage * HSTAGE + (j * 256 + 64 * wave) * 16), 16, off, 0, 0, DSN_DMA_AUX);
         }
         dead.dma(live ? nd : 0);                                  // (a padding group is not counted by the waits at all)
     };

@@ -249,13 +249,13 @@ __global__ __launch_bounds__(256, (GL ? 2 : MI * NI <= 4 ? (WGM == 4 ? 3 : 4) : 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto fetchA = [&](u32x4& dstv, int i, uint32_t off, int gbuf) {
         if constexpr (GL > 0)     // 8 rows x 128 B per wave-instruction, lane-linear: rows 32*i + 8*wave .. +8 of stage gbuf
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (gbuf * BM + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_ptr)(sA + (gbuf * BM + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
         else
             dstv = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
     };
     auto fetchB = [&](u32x4& dstv, int i, uint32_t off, int gbuf) {
         if constexpr (GL > 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + (gbuf * BN + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + (gbuf * BN + 32 * i + 8 * wave) * ROWB), 16, off, 0, 0, DSN_DMA_AUX);
         else
             dstv = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
     };

@@ -902,9 +902,9 @@ __device__ __forceinline__ void wgrad_pp_body(const bf16_t* __restrict__ x, cons
             nd = __builtin_amdgcn_readfirstlane(nd);
         }
         dq2 = dq1; dq1 = dq0; dq0 = nd;                                      // (k-steps past the block's range: c_edge is off, the tail waits leave them out)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(st + wave * 1024), 16, oa, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + wave * 1024), 16, o0, 0, 0, 0);
-        if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + (wave + 8) * 1024), 16, o1, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr)(st + wave * 1024), 16, oa, 0, 0, DSN_DMA_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + wave * 1024), 16, o0, 0, 0, DSN_DMA_AUX);
+        if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(st + 8192 + (wave + 8) * 1024), 16, o1, 0, 0, DSN_DMA_AUX);
     };
 
     // ---- fragment addresses (stage-relative) -----------------------------------------------------------------------------------

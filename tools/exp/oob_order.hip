@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <vector>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef DSN_PROBE_AUX
+#define DSN_PROBE_AUX 0     // cache policy of the "hot" younger LDS-DMAs (gfx950: 1 = sc0, 2 = nt, 16 = sc1): does an L1 bypass keep them in order?
+#endif
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <int K, int KIND>   // KIND 0: younger = OOB register loads through a ZERO-record resource; 1: OOB offsets on the real resource;
@@ -64,12 +67,12 @@ __global__ void probe_dma(const u32x4* __restrict__ src, unsigned bytes, u32x4* 
         else if (KIND == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, (off + 16 * (i + 1)) % bytes, 0, 0, 0);
         else if (KIND == 5) {       // in-range DMA from a ZERO PAGE through its own resource (what replaces an all-out-of-range DMA)
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)zero_page, 0, 1024, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, lane * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, lane * 16, 0, 0, DSN_PROBE_AUX);
         } else if (KIND == 10) {    // in-range DMA from a small hipMalloc'd buffer (ordinary device memory, L2-hot), own resource
             const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc((void*)hot_buf, 0, 1024, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, lane * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, lane * 16, 0, 0, DSN_PROBE_AUX);
         } else if (KIND == 11) {    // in-range DMA from the SAME resource as the older one, but a small L2-hot part of it (its first KB)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, lane * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, lane * 16, 0, 0, DSN_PROBE_AUX);
         } else if (KIND == 6) {     // a DMA with HALF of its lanes out of range
             const unsigned o = (lane & 1) ? 0xFFFFFFF0u : (off + 16 * (i + 1)) % bytes;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + 8192 + wave * 1024), 16, o, 0, 0, 0);
